@@ -1,0 +1,213 @@
+"""ctypes binding of oracle/libtron_oracle.so (see tron_oracle.h).
+
+TEST INFRASTRUCTURE ONLY: never imported by deep-q-learning_tron_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libtron_oracle.so")
+
+MODE_NONE, MODE_ICE, MODE_TEMPER = 0, 1, 2
+MODES = {None: 0, "none": 0, "ice": 1, "temper": 2}
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("tron_oracle.c", "tron_oracle.h")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libtron_oracle.so"])
+    return _LIB_PATH
+
+
+class Reward(C.Structure):
+    _fields_ = [("step", C.c_float), ("win", C.c_float), ("lose", C.c_float),
+                ("draw", C.c_float), ("step_is_index", C.c_int32)]
+
+
+# the reference's three literal reward tables
+REWARD_DDQN = dict(step=-1.0, win=100.0, lose=-100.0, draw=0.0, step_is_index=0)   # DDQN.py:289-305
+REWARD_DQN = dict(step=0.0, win=100.0, lose=-25.0, draw=0.0, step_is_index=1)      # DQN.py:224-241
+REWARD_ACKTR = dict(step=-1.0, win=10.0, lose=-10.0, draw=0.0, step_is_index=0)    # ACKTR.py:294-317, config.py:37
+
+
+class _Vec(C.Structure):
+    _fields_ = [("N", C.c_int32), ("W", C.c_int32), ("mode", C.c_int32), ("fair", C.c_int32),
+                ("seed", C.c_uint32), ("stream", C.c_uint32), ("reward", Reward),
+                ("grid", C.c_void_p), ("pos", C.c_void_p), ("alive", C.c_void_p), ("dir", C.c_void_p),
+                ("done", C.c_void_p), ("winner", C.c_void_p), ("weight", C.c_void_p),
+                ("degree", C.c_void_p), ("slide", C.c_void_p), ("tick", C.c_void_p),
+                ("episode", C.c_void_p), ("eplen", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_get_rate.restype = C.c_double
+        L.orc_get_rate.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.orc_degree_slide.restype = C.c_double
+        L.orc_degree_slide.argtypes = [C.c_double]
+        L.orc_step.restype = C.c_int
+        L.orc_step.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_double, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_make_game.restype = C.c_int
+        L.orc_make_game.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_map_init.argtypes = [C.c_void_p, C.c_int]
+        L.orc_game_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_state_for_player.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_pop_up.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_rewards.argtypes = [C.POINTER(Reward), C.c_int, C.c_int, C.c_uint32, C.c_void_p]
+        L.orc_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_vec_reset_env.argtypes = [C.POINTER(_Vec), C.c_int]
+        L.orc_vec_step.argtypes = [C.POINTER(_Vec), C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def philox(ctr, key):
+    c = np.asarray(ctr, np.uint32)
+    k = np.asarray(key, np.uint32)
+    o = np.zeros(4, np.uint32)
+    lib().orc_philox4x32_10(_p(c), _p(k), _p(o))
+    return o
+
+
+def get_rate(degree, weight=None):
+    return lib().orc_get_rate(int(degree), 0 if weight is None else int(weight), 0 if weight is None else 1)
+
+
+def degree_slide(slide):
+    return lib().orc_degree_slide(float(slide))
+
+
+def game_init(W, start):
+    g = np.zeros((W + 2, W + 2), np.int8)
+    s = np.asarray(start, np.int8)
+    lib().orc_game_init(_p(g), W, _p(s))
+    return g
+
+
+def state_for_player(grid, player):
+    grid = np.ascontiguousarray(grid, np.int8)
+    out = np.empty_like(grid)
+    lib().orc_state_for_player(_p(grid), grid.size, int(player), _p(out))
+    return out
+
+
+def pop_up(codes):
+    codes = np.ascontiguousarray(codes, np.int8)
+    out = np.empty((3,) + codes.shape, np.float32)
+    lib().orc_pop_up(_p(codes), codes.size, _p(out))
+    return out
+
+
+def make_game(W, fair, stream):
+    s = np.ascontiguousarray(stream, np.uint32)
+    start = np.zeros(4, np.int8)
+    weight = np.zeros(2, np.int16)
+    degree = np.zeros(1, np.int16)
+    n = lib().orc_make_game(W, int(bool(fair)), _p(s), _p(start), _p(weight), _p(degree))
+    return start, weight, int(degree[0]), n
+
+
+def rewards(table, done, winner, step_index=0):
+    r = Reward(**table)
+    out = np.zeros(2, np.float32)
+    lib().orc_rewards(C.byref(r), int(done), int(winner), int(step_index), _p(out))
+    return out
+
+
+class ScalarGame:
+    """One env, stepped with orc_step — mirrors Game(width,height,pps,mode,slide_pram)."""
+
+    def __init__(self, W, start, mode=None, slide=0.15, weight=(70, 70), degree=0):
+        self.W = W
+        self.mode = MODES[mode]
+        self.grid = game_init(W, start)
+        self.pos = np.array(start, np.int8)
+        self.alive = np.ones(2, np.int8)
+        self.dir = np.zeros(2, np.int8)
+        self.done = np.zeros(1, np.int8)
+        self.winner = np.zeros(1, np.int8)
+        self.slide = float(slide)
+        self.weight = np.array(weight, np.int16)
+        self.degree = int(degree)
+        self.consumed = np.zeros(2, np.int8)
+
+    def step(self, a1, a2, u=(0.0, 0.0)):
+        act = np.array([a1, a2], np.int8)
+        uu = np.array(u, np.float32)
+        return lib().orc_step(self.W, self.mode, _p(self.grid), _p(self.pos), _p(self.alive), _p(self.dir),
+                              _p(self.done), _p(self.winner), _p(act), _p(uu), self.slide,
+                              _p(self.weight), self.degree, _p(self.consumed))
+
+
+class VecOracle:
+    """Batched env on host arrays, env-major — the checker for the HIP VecTron."""
+
+    def __init__(self, N, W, mode=None, seed=0x5EED, stream=0, fair=False, reward=REWARD_DDQN, slide=0.15):
+        G = (W + 2) * (W + 2)
+        self.N, self.W, self.G = N, W, G
+        self.grid = np.zeros((N, G), np.int8)
+        self.pos = np.zeros((N, 4), np.int8)
+        self.alive = np.ones((N, 2), np.int8)
+        self.dir = np.zeros((N, 2), np.int8)
+        self.done = np.zeros(N, np.int8)
+        self.winner = np.zeros(N, np.int8)
+        self.weight = np.full((N, 2), 70, np.int16)
+        self.degree = np.zeros(N, np.int16)
+        self.slide = np.full(N, float(slide), np.float64)
+        self.tick = np.zeros(N, np.uint32)
+        self.episode = np.zeros(N, np.uint32)
+        self.eplen = np.zeros(N, np.uint32)
+        self.v = _Vec(N=N, W=W, mode=MODES[mode], fair=int(bool(fair)), seed=seed & 0xFFFFFFFF,
+                      stream=stream & 0xFFFFFFFF, reward=Reward(**reward),
+                      grid=self.grid.ctypes.data, pos=self.pos.ctypes.data, alive=self.alive.ctypes.data,
+                      dir=self.dir.ctypes.data, done=self.done.ctypes.data, winner=self.winner.ctypes.data,
+                      weight=self.weight.ctypes.data, degree=self.degree.ctypes.data,
+                      slide=self.slide.ctypes.data, tick=self.tick.ctypes.data,
+                      episode=self.episode.ctypes.data, eplen=self.eplen.ctypes.data)
+
+    def reset_all(self):
+        for i in range(self.N):
+            lib().orc_vec_reset_env(C.byref(self.v), i)
+
+    def set_starts(self, starts, weight=None, degree=None):
+        """Explicit start positions (parity mode): Game.__init__ with given pps."""
+        starts = np.asarray(starts, np.int8).reshape(self.N, 4)
+        for i in range(self.N):
+            self.grid[i] = game_init(self.W, starts[i]).reshape(-1)
+        self.pos[:] = starts
+        self.alive[:] = 1
+        self.dir[:] = 0
+        self.done[:] = 0
+        self.winner[:] = 0
+        self.eplen[:] = 0
+        if weight is not None:
+            self.weight[:] = np.asarray(weight, np.int16).reshape(self.N, 2)
+        if degree is not None:
+            self.degree[:] = np.asarray(degree, np.int16).reshape(self.N)
+
+    def step(self, actions=None, uniforms=None, autoreset=False, want_obs=True):
+        a = None if actions is None else np.ascontiguousarray(actions, np.int8)
+        u = None if uniforms is None else np.ascontiguousarray(uniforms, np.float32)
+        obs = np.empty((self.N, 2, self.G), np.int8) if want_obs else None
+        done = np.empty(self.N, np.int8)
+        winner = np.empty(self.N, np.int8)
+        reward = np.empty((self.N, 2), np.float32)
+        lib().orc_vec_step(C.byref(self.v), _p(a), _p(u), int(bool(autoreset)), _p(obs), _p(done), _p(winner),
+                           _p(reward))
+        return obs, done, winner, reward

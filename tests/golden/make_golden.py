@@ -1,0 +1,365 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (the reference lives at /root/reference and
+never travels to the GPU box).  Nothing from the reference is copied: this
+script imports it, drives it with recorded inputs, and stores inputs + outputs
+as small .npz files.  The tests then check oracle/ (the C restatement) and the
+HIP path against those files.
+
+Import recipe: tron.game pulls in two third-party modules that
+the hot path never uses (`orderedset`, `torchvision.models`); both are absent
+here and are satisfied with inert stub modules.
+
+Usage:  python tests/golden/make_golden.py            (writes next to itself)
+"""
+import os
+import sys
+import types
+import random as pyrandom
+
+_ORIG_RANDOM = pyrandom.random
+_ORIG_RANDINT = pyrandom.randint
+
+import numpy as np
+
+REF = "/root/reference/Deep-Q-learning_TRON"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+_os = types.ModuleType("orderedset")
+
+
+class _OrderedSet(list):  # only used by dead code paths (SetQueue, minimax)
+    def add(self, x):
+        if x not in self:
+            self.append(x)
+
+
+_os.OrderedSet = _OrderedSet
+sys.modules["orderedset"] = _os
+_tv = types.ModuleType("torchvision")
+_tvm = types.ModuleType("torchvision.models")
+_tv.models = _tvm
+sys.modules["torchvision"] = _tv
+sys.modules["torchvision.models"] = _tvm
+
+import tron.game as RG  # noqa: E402
+import tron.util as RU  # noqa: E402
+import tron.map as RM  # noqa: E402
+from tron.player import ACPlayer  # noqa: E402
+
+TILE_VALUE = np.vectorize(lambda t: t.value, otypes=[np.int8])
+
+
+def raw_grid(game):
+    """int8 Tile.value image of the newest map, storage order [row+1][col+1]."""
+    return TILE_VALUE(game.history[-1].map._data)
+
+
+def new_game(W, starts, mode=None, slide_pram=None, weight=None, degree=None):
+    g = RG.Game(W, W, [RG.PositionPlayer(1, ACPlayer(), [int(starts[0]), int(starts[1])]),
+                       RG.PositionPlayer(2, ACPlayer(), [int(starts[2]), int(starts[3])])],
+                mode, slide_pram)
+    if weight is not None:
+        g.weight = [int(weight[0]), int(weight[1])]
+    if degree is not None:
+        g.degree = int(degree)
+    return g
+
+
+def snapshot(g):
+    pos = [g.pps[0].position[0], g.pps[0].position[1], g.pps[1].position[0], g.pps[1].position[1]]
+    alive = [int(g.pps[0].alive), int(g.pps[1].alive)]
+    return pos, alive
+
+
+# --------------------------------------------------------------------------
+# G-step-exhaustive: every start pair x every action pair, one step, 4x4 board
+# --------------------------------------------------------------------------
+def gen_step_exhaustive(W=4):
+    starts, actions, grids, poss, alives, dones, winners, obs1, obs2 = ([] for _ in range(9))
+    cells = [(r, c) for r in range(W) for c in range(W)]
+    for a in cells:
+        for b in cells:
+            if a == b:
+                continue
+            for a1 in range(4):
+                for a2 in range(4):
+                    g = new_game(W, (a[0], a[1], b[0], b[1]))
+                    n1, n2, done = g.step(a1, a2)
+                    pos, alive = snapshot(g)
+                    starts.append([a[0], a[1], b[0], b[1]])
+                    actions.append([a1, a2])
+                    grids.append(raw_grid(g))
+                    poss.append(pos)
+                    alives.append(alive)
+                    dones.append(int(done))
+                    winners.append(0 if g.winner is None else int(g.winner))
+                    obs1.append(np.asarray(n1, dtype=np.int8))
+                    obs2.append(np.asarray(n2, dtype=np.int8))
+    np.savez_compressed(
+        os.path.join(OUT, "step_exhaustive_4x4.npz"),
+        W=np.int32(W), starts=np.array(starts, np.int8), actions=np.array(actions, np.int8),
+        grid=np.array(grids, np.int8), pos=np.array(poss, np.int8), alive=np.array(alives, np.int8),
+        done=np.array(dones, np.int8), winner=np.array(winners, np.int8),
+        obs1=np.array(obs1, np.int8), obs2=np.array(obs2, np.int8))
+    print("step_exhaustive_4x4:", len(starts), "cases")
+
+
+# --------------------------------------------------------------------------
+# Episodes (mode None / ice / temper) with recorded actions and uniforms
+# --------------------------------------------------------------------------
+class UniformFeeder:
+    """Replaces tron.game.random.random.  The reference draws one uniform per
+    player per step, and only when that player's first target cell is in-bounds
+    and EMPTY (game.py:163-169).  We hand it the value recorded for that
+    (step, player) slot; the player index is the `id` local of next_frame."""
+
+    def __init__(self):
+        self.slots = None
+        self.consumed = None
+
+    def arm(self, u2):
+        self.slots = u2
+        self.consumed = [0, 0]
+
+    def __call__(self):
+        pid = sys._getframe(1).f_locals["id"]
+        self.consumed[pid] += 1
+        return float(self.slots[pid])
+
+
+def safe_actions(g, W, rng, p_safe):
+    """Action pair from a 'mostly avoid obstacles' policy so episodes get long."""
+    m = g.history[-1].map
+    out = []
+    for pp in g.pps:
+        if rng.random() < p_safe:
+            ok = []
+            for a, (dr, dc) in enumerate(((-1, 0), (0, 1), (1, 0), (0, -1))):
+                r, c = pp.position[0] + dr, pp.position[1] + dc
+                if 0 <= r < W and 0 <= c < W and m[r, c] is RM.Tile.EMPTY:
+                    ok.append(a)
+            out.append(rng.choice(ok) if ok else rng.randrange(4))
+        else:
+            out.append(rng.randrange(4))
+    return out
+
+
+def gen_episodes(name, W, n_eps, seed, mode=None, p_safe=0.8, keep_steps=False, slide_choices=(None,)):
+    rng = pyrandom.Random(seed)
+    feeder = UniformFeeder()
+    RG.random.random = feeder  # tron.game's `random` module object (same as stdlib's)
+    ep_off = [0]
+    starts, slides, weights, degrees, finals, winners, fobs1, fobs2 = ([] for _ in range(8))
+    acts, unis, cons, poss, alives, dones = ([] for _ in range(6))
+    step_grids, step_obs1, step_obs2 = [], [], []
+    try:
+        for _ in range(n_eps):
+            while True:
+                s = [rng.randrange(W) for _ in range(4)]
+                if (s[0], s[1]) != (s[2], s[3]):
+                    break
+            sp = rng.choice(slide_choices)
+            w = [rng.randint(40, 101), rng.randint(40, 101)]
+            d = rng.randint(-30, 30)
+            g = new_game(W, s, mode, sp, w, d)
+            starts.append(s)
+            slides.append(float(g.slide))
+            weights.append(w)
+            degrees.append(d)
+            done = False
+            while not done:
+                a = safe_actions(g, W, rng, p_safe)
+                # f32-exact uniforms; now and then sit exactly on / next to the rate
+                u = [rng.randrange(1 << 24) / float(1 << 24) for _ in range(2)]
+                if mode is not None and rng.random() < 0.05:
+                    u[rng.randrange(2)] = float(np.float32(g.slide))
+                feeder.arm(u)
+                n1, n2, done = g.step(a[0], a[1])
+                pos, alive = snapshot(g)
+                acts.append(a)
+                unis.append(u)
+                cons.append(list(feeder.consumed))
+                poss.append(pos)
+                alives.append(alive)
+                dones.append(int(done))
+                if keep_steps:
+                    step_grids.append(raw_grid(g))
+                    step_obs1.append(np.asarray(n1, np.int8))
+                    step_obs2.append(np.asarray(n2, np.int8))
+            ep_off.append(len(acts))
+            finals.append(raw_grid(g))
+            winners.append(0 if g.winner is None else int(g.winner))
+            fobs1.append(np.asarray(g.next_p1, np.int8))
+            fobs2.append(np.asarray(g.next_p2, np.int8))
+    finally:
+        RG.random.random = _ORIG_RANDOM
+    d = dict(W=np.int32(W), mode=np.array(mode if mode else "none"),
+             ep_off=np.array(ep_off, np.int32), starts=np.array(starts, np.int8),
+             slide=np.array(slides, np.float64), weight=np.array(weights, np.int16),
+             degree=np.array(degrees, np.int16),
+             actions=np.array(acts, np.int8), uniforms=np.array(unis, np.float32),
+             consumed=np.array(cons, np.int8), pos=np.array(poss, np.int8),
+             alive=np.array(alives, np.int8), done=np.array(dones, np.int8),
+             winner=np.array(winners, np.int8), final_grid=np.array(finals, np.int8),
+             final_obs1=np.array(fobs1, np.int8), final_obs2=np.array(fobs2, np.int8))
+    if keep_steps:
+        d.update(step_grid=np.array(step_grids, np.int8), step_obs1=np.array(step_obs1, np.int8),
+                 step_obs2=np.array(step_obs2, np.int8))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    lens = np.diff(ep_off)
+    print(f"{name}: {n_eps} episodes, {len(acts)} steps, mean len {lens.mean():.1f}, max {lens.max()},"
+          f" winners {np.bincount(np.array(winners), minlength=3).tolist()},"
+          f" uniforms consumed {int(np.array(cons).sum())}")
+
+
+# --------------------------------------------------------------------------
+# G-encode: arbitrary tile images -> state_for_player -> pop_up (+ prob plane)
+# --------------------------------------------------------------------------
+def gen_encode():
+    rng = np.random.RandomState(7)
+    tiles = {t.value: t for t in RM.Tile}
+    out = {}
+    for W, n in ((4, 64), (10, 32), (24, 6)):
+        S = W + 2
+        raw = rng.randint(-1, 7, size=(n, S, S)).astype(np.int8)
+        codes = np.zeros((n, 2, S, S), np.int8)
+        planes = np.zeros((n, 2, 3, S, S), np.float64)
+        for k in range(n):
+            m = RM.Map(W, W, RM.Tile.EMPTY, RM.Tile.WALL)
+            m._data = np.array([[tiles[int(v)] for v in row] for row in raw[k]])
+            for p in (1, 2):
+                c = m.state_for_player(p)
+                codes[k, p - 1] = c
+                planes[k, p - 1] = RU.pop_up(c)
+        out[f"raw_{W}"] = raw
+        out[f"codes_{W}"] = codes
+        out[f"planes_{W}"] = planes
+    # env scalars: Game.get_rate / get_degree_silde / get_multy / prob_map (game.py:96-147)
+    g = new_game(10, (0, 0, 5, 5))
+    degs = np.arange(-30, 31)
+    wts = np.arange(40, 102)
+    rate = np.zeros((len(degs), len(wts)), np.float64)
+    rate_none = np.zeros(len(degs), np.float64)
+    for i, dg in enumerate(degs):
+        g.degree = int(dg)
+        rate_none[i] = g.get_rate()
+        for j, wt in enumerate(wts):
+            g.weight = [int(wt), 40]
+            rate[i, j] = g.get_rate(0)
+    slides = np.array([0.0, 0.03, 0.06, 0.09, 0.12, 0.15, 0.18, 0.21, 0.24, 0.27, 0.3, 0.33, 0.36, 0.25, 0.5])
+    dslide = np.zeros(len(slides), np.float64)
+    for i, s in enumerate(slides):
+        g.slide = float(s)
+        dslide[i] = g.get_degree_silde()
+    g.slide = 0.15
+    g.degree = -7
+    g.weight = [55, 99]
+    out.update(rate_degrees=degs.astype(np.int16), rate_weights=wts.astype(np.int16), rate=rate,
+               rate_none=rate_none, slides=slides, degree_slide=dslide,
+               prob_map_015=np.asarray(g.prob_map(), np.float64),
+               degree_map_m7=np.asarray(g.degree_map(), np.float64),
+               multy0=np.array(g.get_multy(0), np.float64), multy1=np.array(g.get_multy(1), np.float64),
+               util_prob_map_3=np.asarray(RU.prob_map(3.0), np.float64))
+    np.savez_compressed(os.path.join(OUT, "encode.npz"), **out)
+    print("encode: done")
+
+
+# --------------------------------------------------------------------------
+# G-reset: make_game / Game.__init__ under a replayed randint stream
+# --------------------------------------------------------------------------
+class RandintFeeder:
+    """random.randint(a, b) := a + ((u32 * (b - a + 1)) >> 32) over a recorded
+    u32 stream, so the order AND the ranges of the reference's draws are pinned
+    (util.py:48-78, game.py:83,87)."""
+
+    def __init__(self, stream):
+        self.stream = [int(x) for x in stream]
+        self.i = 0
+        self.calls = []
+
+    def __call__(self, a, b):
+        u = self.stream[self.i]
+        self.i += 1
+        self.calls.append((a, b))
+        return a + ((u * (b - a + 1)) >> 32)
+
+
+def gen_reset():
+    rng = np.random.RandomState(11)
+    out = {}
+    for W in (4, 10, 24):
+        RU.MAP_WIDTH = RU.MAP_HEIGHT = W
+        for mode in (None, "fair"):
+            n = 400 if W == 4 else 150
+            streams = rng.randint(0, 1 << 32, size=(n, 48), dtype=np.uint64).astype(np.uint32)
+            if W == 4 and mode is None:
+                # force clashes: x2,y2 equal to x1,y1 for several redraw rounds
+                for k in range(0, 60):
+                    streams[k, 2] = streams[k, 0]
+                    streams[k, 3] = streams[k, 1]
+                for k in range(0, 20):
+                    streams[k, 4] = streams[k, 0]
+                    streams[k, 5] = streams[k, 1]
+            res = np.zeros((n, 8), np.int16)  # x1 y1 x2 y2 w0 w1 degree ndraws
+            grids = np.zeros((n, W + 2, W + 2), np.int8)
+            for k in range(n):
+                f = RandintFeeder(streams[k])
+                RU.random.randint = f
+                try:
+                    g = RU.make_game(True, True, mode=mode, gamemode="temper")
+                finally:
+                    RU.random.randint = _ORIG_RANDINT
+                p1, p2 = g.pps[0].position, g.pps[1].position
+                res[k] = [p1[0], p1[1], p2[0], p2[1], g.weight[0], g.weight[1], g.degree, f.i]
+                grids[k] = raw_grid(g)
+            tag = f"{W}_{mode or 'default'}"
+            out["stream_" + tag] = streams
+            out["result_" + tag] = res
+            out["grid_" + tag] = grids
+    RU.MAP_WIDTH = RU.MAP_HEIGHT = 10
+    np.savez_compressed(os.path.join(OUT, "reset.npz"), **out)
+    print("reset: done")
+
+
+# --------------------------------------------------------------------------
+# G-reward: get_reward (util.py:87-94) + the trainers' literal tables
+# --------------------------------------------------------------------------
+def gen_reward():
+    import config as RC
+    rows = []
+    g = new_game(4, (0, 0, 3, 3))
+    for ci, cons in enumerate((RC.reward_cons1, RC.reward_cons2, RC.reward_cons3)):
+        for w in (None, 1, 2):
+            g.winner = w
+            r = RU.get_reward(g, cons)
+            rows.append([ci, 0 if w is None else w, float(cons[0]), float(cons[1]), float(r[0]), float(r[1])])
+    np.savez_compressed(os.path.join(OUT, "reward.npz"), get_reward=np.array(rows, np.float64))
+    print("reward: done")
+
+
+def main():
+    gen_step_exhaustive()
+    gen_episodes("episodes_none_4", 4, 300, 101, None, p_safe=0.6, keep_steps=True)
+    gen_episodes("episodes_none_10", 10, 200, 102, None, p_safe=0.85, keep_steps=True)
+    gen_episodes("episodes_none_24", 24, 40, 103, None, p_safe=0.93)
+    gen_episodes("episodes_none_32", 32, 24, 104, None, p_safe=0.93)
+    gen_episodes("episodes_uniform_10", 10, 400, 105, None, p_safe=0.0)
+    sl = (None, 0.0, 0.03, 0.25, 0.36, 0.5, 1.0)
+    gen_episodes("episodes_ice_4", 4, 300, 201, "ice", p_safe=0.6, keep_steps=True, slide_choices=sl)
+    gen_episodes("episodes_ice_10", 10, 200, 202, "ice", p_safe=0.85, slide_choices=sl)
+    gen_episodes("episodes_ice_24", 24, 30, 203, "ice", p_safe=0.93, slide_choices=sl)
+    gen_episodes("episodes_temper_4", 4, 300, 301, "temper", p_safe=0.6, keep_steps=True)
+    gen_episodes("episodes_temper_10", 10, 200, 302, "temper", p_safe=0.85)
+    gen_episodes("episodes_temper_24", 24, 30, 303, "temper", p_safe=0.93)
+    gen_encode()
+    gen_reset()
+    gen_reward()
+
+
+if __name__ == "__main__":
+    main()
