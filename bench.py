@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the HIP TRON env path on MI355X.
+
+One "step" = one launch of the fused step + observation-encode + autoreset kernel over
+every env of this rank: both players of each env move once (i.i.d. uniform actions drawn
+in-kernel from Philox-4x32-10, as BASELINE.md §3 specifies), both players' int8 code-plane
+observations are written, finished games are replaced by fresh ones.  Workload =
+BASELINE.json configs[2]'s env side: 65 536 parallel 24x24 envs per GPU, mode=None.
+
+Multi-GPU: envs are independent, so each rank owns its own 65 536 envs and its own Philox
+stream (weak scaling, no data-path collective).  Launch as the driver does:
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "deep-q-learning_tron_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+N_ENVS = 65536          # per GPU (BASELINE.json configs[2] / [3])
+WIDTH = 24
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def alg_bytes_per_env_step(width):
+    """fused step+encode, int8 state, int8 code planes for both players:
+    read G + 16, write 2G + 16  =>  3G + 32 bytes per env-step."""
+    g = (width + 2) * (width + 2)
+    return 3 * g + 32
+
+
+def cpu_baseline(width, budget_s=12.0):
+    """The CPU oracle (C restatement of the reference, `kind: port`) on one host core, same
+    unit of work: step + both observations + autoreset, i.i.d. uniform actions."""
+    import oracle
+    n = 4096
+    ref = oracle.VecOracle(n, width, seed=0x5EED)
+    ref.reset_all()
+    ref.step(autoreset=True)                       # warm
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < budget_s:
+        ref.step(autoreset=True)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} steps x {n} envs {width}x{width}, mode=None, autoreset, Philox actions, "
+                      f"{dt:.1f} s on 1 host core (oracle/libtron_oracle.so)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs", type=int, default=N_ENVS, help="envs per GPU")
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--obs", default="codes", choices=["codes", "planes3", "planes4"])
+    ap.add_argument("--mode", default="none", choices=["none", "ice", "temper"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tron.vec import VecTron
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    env = VecTron(args.envs, args.width, mode=None if args.mode == "none" else args.mode, seed=0x5EED, rank=rank,
+                  obs_format=args.obs)
+    env.reset()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        env.step(autoreset=True)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()                                   # same stream the kernels are launched on
+    for _ in range(args.steps):
+        env.step(autoreset=True)
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps   # avg fused-kernel launch, HIP events
+
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+
+    if rank == 0:
+        total_env_steps = args.envs * world * args.steps
+        b_alg = alg_bytes_per_env_step(args.width)
+        if args.obs != "codes":                    # f32 planes: 2 players x C planes x 4 B per cell
+            g = (args.width + 2) ** 2
+            b_alg = g + 32 + 2 * (3 if args.obs == "planes3" else 4) * g * 4
+        achieved = b_alg * args.envs / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec",
+            "value": total_env_steps / wall,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "i8",
+            "data": "synthetic",
+            "config": {"workload": f"{args.envs} parallel {args.width}x{args.width} TRON envs per GPU, "
+                                   f"mode={args.mode}, random actions (in-kernel Philox), autoreset, "
+                                   f"obs={args.obs} for both players",
+                       "envs_per_gpu": args.envs, "grid": f"{args.width}x{args.width}",
+                       "parallelism": f"env-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_step_encode", "kernel_ms": kern_ms,
+                         "alg_bytes_per_env_step": b_alg},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.width)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,8 @@
+#!/usr/bin/env bash
+# Builds libtron_hip.so (gfx950 only) in-tree so it travels with the snapshot.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared \
+    -o libtron_hip.so tron_env.hip tron_replay.hip "$@"
+echo "built $(pwd)/libtron_hip.so"

@@ -1,0 +1,181 @@
+// Device-side building blocks of the gfx950 TRON env path.
+// Rules restated from the reference are cited as file:line into
+// Deep-Q-learning_TRON/; nothing here is shared with oracle/ (the CPU checker).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tron {
+
+// ---- env state held by a handle, all in HBM, struct-of-arrays --------------
+struct Params {
+    int32_t N, W, S, G;        // envs, board side, S = W+2, G = S*S cells
+    int32_t mode, fair;        // game.py:86 mode; util.py:48 "fair" start placement
+    uint32_t seed, stream;     // Philox key
+    float r_step, r_win, r_lose, r_draw;
+    int32_t r_index;           // DQN.py:224-225: non-terminal reward = step index
+    uint32_t d_magic;          // ceil(2^32 / D), D = G/4 (G%4==0) — exact q = n/D for n < 2^32/D
+    int8_t *grid;              // [N][G] Tile values (map.py:9-17), storage [row+1][col+1] (map.py:86-92)
+    uint32_t *pos;             // [N] r1 | c1<<8 | r2<<16 | c2<<24 (int8 each; game.py:36-41)
+    uint32_t *meta;            // [N] alive0 | alive1<<1 | done<<2 | winner<<4 | dir0<<8 | dir1<<12
+    uint32_t *envp;            // [N] weight0 | weight1<<8 | (int8)degree<<16 (game.py:83,87)
+    double *slide;             // [N] game.py:88
+    uint32_t *tick;            // [N] steps taken since create (RNG counter)
+    uint32_t *episode;         // [N] games started (RNG counter)
+    uint32_t *eplen;           // [N] steps in the current game
+    const int8_t *fresh;       // [G] empty board with WALL border (map.py:45-48)
+};
+
+enum { RNG_STEP = 0, RNG_RESET = 2, RNG_INIT = 3 };
+enum { META_ALIVE0 = 1u, META_ALIVE1 = 2u, META_DONE = 4u };
+
+// ---- Philox-4x32-10 (Salmon et al., SC'11) ----------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// random.randint(a, b) over one u32: a + floor(u * (b-a+1) / 2^32)
+__device__ __forceinline__ int randint_u32(uint32_t u, int a, int b)
+{
+    return a + (int)__umulhi(u, (uint32_t)(b - a + 1));
+}
+
+// Sequential u32 draws from the reset stream of (env, episode): block b of four
+// values is Philox(ctr = {env, episode, RNG_RESET, b}).
+struct ResetStream {
+    uint32_t env, ep, k0, k1;
+    uint32_t b0, b1, b2, b3;
+    int n;
+    __device__ __forceinline__ uint32_t next()
+    {
+        const int j = n & 3;
+        if (j == 0) {
+            uint32_t o[4];
+            philox4x32_10(env, ep, RNG_RESET, (uint32_t)(n >> 2), k0, k1, o);
+            b0 = o[0]; b1 = o[1]; b2 = o[2]; b3 = o[3];
+        }
+        ++n;
+        return j == 0 ? b0 : j == 1 ? b1 : j == 2 ? b2 : b3;
+    }
+};
+
+struct NewGame {
+    int r1, c1, r2, c2, w0, w1, degree;
+};
+
+// util.make_game start placement + Game.__init__ draws (util.py:46-84, game.py:83,87).
+// (x, y) of the reference are (row, col).  Only player 1 is re-drawn on a clash
+// (util.py:76-78); the loop is bounded at 16 rounds for the GPU.
+__device__ inline NewGame make_game(const Params &P, uint32_t env, uint32_t episode)
+{
+    ResetStream s{env, episode, P.seed, P.stream, 0, 0, 0, 0, 0};
+    const int W = P.W;
+    int lb1x = 0, lb1y = 0, lb2x = 0, lb2y = 0;
+    int ub1x = W - 1, ub1y = W - 1, ub2x = W - 1, ub2y = W - 1;
+    if (P.fair) {                                       // util.py:48-62
+        const int py = randint_u32(s.next(), 0, W - 1);
+        const int px = randint_u32(s.next(), 0, W - 1);
+        lb1x = max(0, px - 1); ub1x = min(W - 1, px + 1);
+        lb1y = max(0, py - 1); ub1y = min(W - 1, py + 1);
+        lb2x = W - 1 - ub1x;   ub2x = W - 1 - lb1x;
+        lb2y = W - 1 - ub1y;   ub2y = W - 1 - lb1y;
+    }
+    NewGame g;
+    g.r1 = randint_u32(s.next(), lb1x, ub1x);
+    g.c1 = randint_u32(s.next(), lb1y, ub1y);
+    g.r2 = randint_u32(s.next(), lb2x, ub2x);
+    g.c2 = randint_u32(s.next(), lb2y, ub2y);
+    int rounds = 0;
+    while (g.r1 == g.r2 && g.c1 == g.c2) {
+        if (rounds++ == 16) {
+            g.r1 = (g.r1 == ub1x) ? lb1x : g.r1 + 1;
+            break;
+        }
+        g.r1 = randint_u32(s.next(), lb1x, ub1x);
+        g.c1 = randint_u32(s.next(), lb1y, ub1y);
+    }
+    g.w0 = randint_u32(s.next(), 40, 101);              // game.py:83
+    g.w1 = randint_u32(s.next(), 40, 101);
+    g.degree = randint_u32(s.next(), -30, 30);          // game.py:87
+    return g;
+}
+
+// Game.get_rate(player) in float64, same operation order as game.py:100-102.
+__device__ __forceinline__ double get_rate(int degree, int weight)
+{
+    const double a = __dmul_rn((double)(degree - 30), 0.6);
+    const double b = __ddiv_rn(-a, 100.0);
+    const double c = __ddiv_rn((double)(70 - weight), 100.0);
+    return __dsub_rn(b, c);
+}
+
+// Game.get_degree_silde(): (-slide*100)*(10/6)+30, game.py:110-112.
+__device__ __forceinline__ double degree_slide(double slide)
+{
+    const double t = __dmul_rn(-slide, 100.0);
+    const double k = 10.0 / 6.0;
+    return __dadd_rn(__dmul_rn(t, k), 30.0);
+}
+
+// ---- observation codes (Map.color, map.py:67-81) as a v_perm_b32 byte LUT ----
+// index = tile & 7: EMPTY 0, P1_BODY 1, P1_HEAD 2, P2_BODY 3, P2_HEAD 4,
+// P1_slide 5, P2_slide 6, WALL (-1) 7.
+constexpr uint32_t pack4(int a, int b, int c, int d)
+{
+    return (uint32_t)(uint8_t)a | ((uint32_t)(uint8_t)b << 8) | ((uint32_t)(uint8_t)c << 16) |
+           ((uint32_t)(uint8_t)d << 24);
+}
+constexpr uint32_t CODE_LO_P1 = pack4(1, -2, 10, -3), CODE_HI_P1 = pack4(-10, -2, -3, -1);
+constexpr uint32_t CODE_LO_P2 = pack4(1, -3, -10, -2), CODE_HI_P2 = pack4(10, -3, -2, -1);
+
+// four tiles -> four codes for `player_is_2`
+__device__ __forceinline__ uint32_t codes4(uint32_t tiles, bool player_is_2)
+{
+    const uint32_t sel = tiles & 0x07070707u;
+    return player_is_2 ? __builtin_amdgcn_perm(CODE_HI_P2, CODE_LO_P2, sel)
+                       : __builtin_amdgcn_perm(CODE_HI_P1, CODE_LO_P1, sel);
+}
+__device__ __forceinline__ int8_t code1(int tile, bool player_is_2)
+{
+    const uint32_t sh = (uint32_t)(tile & 3) * 8u;
+    const bool hi = (tile & 4) != 0;
+    const uint32_t w = player_is_2 ? (hi ? CODE_HI_P2 : CODE_LO_P2) : (hi ? CODE_HI_P1 : CODE_LO_P1);
+    return (int8_t)(w >> sh);
+}
+
+// ---- pop_up planes (util.py:11-37): 2 bits per tile index, 0 / 1 / 2(=10.0) ----
+// channel order (wall, my, enemy).
+constexpr uint32_t lut2(int i0, int i1, int i2, int i3, int i4, int i5, int i6, int i7)
+{
+    return (uint32_t)i0 | (i1 << 2) | (i2 << 4) | (i3 << 6) | (i4 << 8) | (i5 << 10) | (i6 << 12) | (i7 << 14);
+}
+constexpr uint32_t PLANE_WALL = lut2(0, 0, 0, 0, 0, 0, 0, 1);
+constexpr uint32_t PLANE_P1 = lut2(0, 1, 2, 0, 0, 1, 0, 0);   // P1 body/slide 1, P1 head 10
+constexpr uint32_t PLANE_P2 = lut2(0, 0, 0, 1, 2, 0, 1, 0);   // P2 body/slide 1, P2 head 10
+
+__device__ __forceinline__ uint32_t plane_bits(int channel, bool player_is_2)
+{
+    if (channel == 0) return PLANE_WALL;
+    const bool mine = (channel == 1);
+    return (mine != player_is_2) ? PLANE_P1 : PLANE_P2;
+}
+__device__ __forceinline__ float plane_val(uint32_t bits, uint32_t tile)
+{
+    const uint32_t v = (bits >> ((tile & 7u) * 2u)) & 3u;
+    return v == 0u ? 0.0f : (v == 1u ? 1.0f : 10.0f);
+}
+
+}  // namespace tron

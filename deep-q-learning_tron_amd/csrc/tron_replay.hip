@@ -1,0 +1,281 @@
+// Device-resident replay memory (include/tron_hip.h, tron_replay_*).
+//
+// Replaces DDQN.ReplayBuffer (DDQN.py:167-203): deque(maxlen) -> a ring in HBM,
+// random.sample -> distinct uniform slots drawn in-kernel (Philox + rejection of
+// duplicates), np.vstack + .to(device) -> one gather kernel that also expands
+// the stored int8 code planes (map.py:67-84) into the f32 pop_up planes
+// (util.py:11-37) the CNN reads.  Nothing crosses PCIe.
+#include "tron_device.hpp"
+#include "../../include/tron_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <new>
+
+using namespace tron;
+
+struct tron_replay {
+    int64_t capacity, size, head;
+    int32_t cells;
+    uint32_t seed, stream, calls;
+    int device;
+    int8_t *states, *next_states, *actions, *dones;
+    float *rewards;
+    int64_t *indices;      // last sampled slots
+    int32_t max_batch;
+    void *blob;
+};
+
+namespace {
+
+constexpr int MAX_DISTINCT_BATCH = 1024;   // above this, slots are drawn with replacement
+constexpr int MAX_BATCH = 1 << 20;
+
+inline hipStream_t S_(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline int launch_status() { return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH; }
+
+// rows [0,n) of src -> slots [slot0, slot0+n) (no wrap inside one launch)
+__global__ void k_push_planes(const int8_t *__restrict__ src, int8_t *__restrict__ dst, size_t nbytes)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | nbytes) & 3u) == 0) {
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
+        uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+        for (size_t i = tid; i < nbytes / 4; i += stride) d[i] = s[i];
+    } else {
+        for (size_t i = tid; i < nbytes; i += stride) dst[i] = src[i];
+    }
+}
+
+__global__ void k_push_scalars(int64_t n, const int8_t *__restrict__ action, const float *__restrict__ reward,
+                               const int8_t *__restrict__ done, int8_t *__restrict__ actions,
+                               float *__restrict__ rewards, int8_t *__restrict__ dones)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    actions[i] = action[i];
+    rewards[i] = reward[i];
+    dones[i] = done[i];
+}
+
+// random.sample(memory, k): k distinct uniform slots.  One workgroup; thread j owns
+// draw j; a draw that collides with a lower-numbered one is redrawn until none collide
+// (rejection keeps the joint distribution uniform over distinct tuples).
+__global__ __launch_bounds__(256) void k_sample_indices(int64_t size, int batch, uint32_t seed, uint32_t stream,
+                                                        uint32_t call, int distinct, int64_t *__restrict__ out)
+{
+    extern __shared__ int64_t sidx[];   // [batch] when distinct
+    __shared__ int any_dup;
+    const int tid = threadIdx.x;
+    auto draw = [&](int j, uint32_t attempt) -> int64_t {
+        uint32_t x[4];
+        philox4x32_10((uint32_t)j, call, attempt, 0x5A4D504Cu /* "SMPL" */, seed, stream, x);
+        const uint64_t u = ((uint64_t)x[0] << 32) | x[1];
+        return (int64_t)__umul64hi(u, (uint64_t)size);
+    };
+    if (!distinct) {
+        for (int j = blockIdx.x * blockDim.x + tid; j < batch; j += gridDim.x * blockDim.x) out[j] = draw(j, 0u);
+        return;
+    }
+    for (int j = tid; j < batch; j += 256) sidx[j] = draw(j, 0u);
+    __syncthreads();
+    for (uint32_t attempt = 1; attempt < 64u; ++attempt) {
+        if (tid == 0) any_dup = 0;
+        __syncthreads();
+        // decide first, redraw after a barrier so every thread judged the same snapshot
+        bool dup[(MAX_DISTINCT_BATCH + 255) / 256];
+        int k = 0;
+        for (int j = tid; j < batch; j += 256, ++k) {
+            const int64_t v = sidx[j];
+            bool d = false;
+            for (int i = 0; i < j; ++i) d |= (sidx[i] == v);
+            dup[k] = d;
+            if (d) any_dup = 1;
+        }
+        __syncthreads();
+        if (!any_dup) break;
+        k = 0;
+        for (int j = tid; j < batch; j += 256, ++k)
+            if (dup[k]) sidx[j] = draw(j, attempt);
+        __syncthreads();
+    }
+    for (int j = tid; j < batch; j += 256) out[j] = sidx[j];
+}
+
+// gather + expand: codes int8[cells] -> planes f32[channels][cells]
+__global__ __launch_bounds__(256) void k_sample_gather(const int64_t *__restrict__ idx, int batch, int cells,
+                                                       int channels, float plane4,
+                                                       const int8_t *__restrict__ states,
+                                                       const int8_t *__restrict__ next_states,
+                                                       const int8_t *__restrict__ actions,
+                                                       const float *__restrict__ rewards,
+                                                       const int8_t *__restrict__ dones, float *__restrict__ o_s,
+                                                       int64_t *__restrict__ o_a, float *__restrict__ o_r,
+                                                       float *__restrict__ o_s2, float *__restrict__ o_d)
+{
+    const int b = blockIdx.x >> 1;          // batch row
+    const int which = blockIdx.x & 1;       // 0: state, 1: next_state
+    const int64_t slot = idx[b];
+    const int8_t *src = (which ? next_states : states) + (size_t)slot * cells;
+    float *dst = (which ? o_s2 : o_s) + (size_t)b * channels * cells;
+    if (!which && threadIdx.x == 0) {
+        o_a[b] = (int64_t)actions[slot];
+        o_r[b] = rewards[slot];
+        o_d[b] = (float)dones[slot];
+    }
+    if ((cells & 3) == 0) {
+        const int D = cells >> 2;
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (int i = threadIdx.x; i < D; i += blockDim.x) {
+            const uint32_t w = s32[i];
+            float wl[4], my[4], en[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int v = (int)(int8_t)(w >> (8 * k));
+                wl[k] = (v == -1) ? 1.0f : 0.0f;                                  // util.py:18-19
+                my[k] = (v == -2) ? 1.0f : (v == 10) ? 10.0f : 0.0f;              // util.py:20-21,26-27
+                en[k] = (v == -3) ? 1.0f : (v == -10) ? 10.0f : 0.0f;             // util.py:22-25
+            }
+            d4[i] = make_float4(wl[0], wl[1], wl[2], wl[3]);
+            d4[D + i] = make_float4(my[0], my[1], my[2], my[3]);
+            d4[2 * D + i] = make_float4(en[0], en[1], en[2], en[3]);
+            if (channels == 4) d4[3 * D + i] = make_float4(plane4, plane4, plane4, plane4);
+        }
+    } else {
+        for (int i = threadIdx.x; i < cells; i += blockDim.x) {
+            const int v = src[i];
+            dst[i] = (v == -1) ? 1.0f : 0.0f;
+            dst[cells + i] = (v == -2) ? 1.0f : (v == 10) ? 10.0f : 0.0f;
+            dst[2 * cells + i] = (v == -3) ? 1.0f : (v == -10) ? 10.0f : 0.0f;
+            if (channels == 4) dst[3 * cells + i] = plane4;
+        }
+    }
+}
+
+__global__ void k_copy_i64(const int64_t *src, int64_t *dst, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+inline bool bad(tron_replay_handle r)
+{
+    if (!r) return true;
+    int dev = -1;
+    return hipGetDevice(&dev) != hipSuccess || dev != r->device;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tron_replay_create(int64_t capacity, int32_t cells, uint32_t seed, uint32_t rng_stream, tron_replay_handle *out)
+{
+    if (!out) return TRON_ERR_BAD_ARG;
+    *out = nullptr;
+    if (capacity < 1 || cells < 1 || cells > 98 * 98) return TRON_ERR_BAD_ARG;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
+    tron_replay *r = new (std::nothrow) tron_replay();
+    if (!r) return TRON_ERR_ALLOC;
+    r->capacity = capacity; r->size = 0; r->head = 0; r->cells = cells;
+    r->seed = seed; r->stream = rng_stream; r->calls = 0; r->device = dev;
+    r->max_batch = (int32_t)(capacity < MAX_BATCH ? capacity : MAX_BATCH);
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t cap = (size_t)capacity;
+    const size_t o_s = 0, o_s2 = align(o_s + cap * cells + 16), o_a = align(o_s2 + cap * cells + 16),
+                 o_d = align(o_a + cap), o_r = align(o_d + cap), o_i = align(o_r + 4 * cap),
+                 total = align(o_i + 8 * (size_t)r->max_batch);
+    char *blob = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&blob), total) != hipSuccess) {
+        (void)hipGetLastError();
+        delete r;
+        return TRON_ERR_ALLOC;
+    }
+    r->blob = blob;
+    r->states = reinterpret_cast<int8_t *>(blob + o_s);
+    r->next_states = reinterpret_cast<int8_t *>(blob + o_s2);
+    r->actions = reinterpret_cast<int8_t *>(blob + o_a);
+    r->dones = reinterpret_cast<int8_t *>(blob + o_d);
+    r->rewards = reinterpret_cast<float *>(blob + o_r);
+    r->indices = reinterpret_cast<int64_t *>(blob + o_i);
+    *out = r;
+    return TRON_OK;
+}
+
+int tron_replay_destroy(tron_replay_handle r)
+{
+    if (!r) return TRON_ERR_BAD_ARG;
+    (void)hipFree(r->blob);
+    delete r;
+    return TRON_OK;
+}
+
+int tron_replay_size(tron_replay_handle r, int64_t *size, int64_t *capacity)
+{
+    if (!r) return TRON_ERR_BAD_ARG;
+    if (size) *size = r->size;
+    if (capacity) *capacity = r->capacity;
+    return TRON_OK;
+}
+
+int tron_replay_push(tron_replay_handle r, int64_t n, const int8_t *state, const int8_t *action, const float *reward,
+                     const int8_t *next_state, const int8_t *done, void *stream)
+{
+    if (bad(r)) return r ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
+    if (n < 0 || n > r->capacity || (n > 0 && (!state || !action || !reward || !next_state || !done)))
+        return TRON_ERR_BAD_ARG;
+    int64_t row = 0;
+    while (row < n) {                                   // at most two segments (ring wrap)
+        const int64_t seg = (n - row < r->capacity - r->head) ? n - row : r->capacity - r->head;
+        const size_t nbytes = (size_t)seg * r->cells;
+        size_t blocks = (nbytes / 4 + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_push_planes, dim3((unsigned)blocks), dim3(256), 0, S_(stream), state + (size_t)row * r->cells,
+                           r->states + (size_t)r->head * r->cells, nbytes);
+        hipLaunchKernelGGL(k_push_planes, dim3((unsigned)blocks), dim3(256), 0, S_(stream),
+                           next_state + (size_t)row * r->cells, r->next_states + (size_t)r->head * r->cells, nbytes);
+        hipLaunchKernelGGL(k_push_scalars, dim3((unsigned)((seg + 255) / 256)), dim3(256), 0, S_(stream), seg,
+                           action + row, reward + row, done + row, r->actions + r->head, r->rewards + r->head,
+                           r->dones + r->head);
+        if (launch_status() != TRON_OK) return TRON_ERR_LAUNCH;
+        row += seg;
+        r->head = (r->head + seg) % r->capacity;
+        r->size = (r->size + seg < r->capacity) ? r->size + seg : r->capacity;
+    }
+    return TRON_OK;
+}
+
+int tron_replay_sample(tron_replay_handle r, int32_t batch, int32_t channels, float plane4, float *states,
+                       int64_t *actions, float *rewards, float *next_states, float *dones, void *stream)
+{
+    if (bad(r)) return r ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
+    if (batch < 1 || batch > r->max_batch || (channels != 3 && channels != 4)) return TRON_ERR_BAD_ARG;
+    if (!states || !actions || !rewards || !next_states || !dones) return TRON_ERR_BAD_ARG;
+    if (r->size < batch) return TRON_ERR_BAD_ARG;       // random.sample raises ValueError likewise
+    const int distinct = batch <= MAX_DISTINCT_BATCH;
+    const uint32_t call = r->calls++;
+    if (distinct)
+        hipLaunchKernelGGL(k_sample_indices, dim3(1), dim3(256), (size_t)batch * sizeof(int64_t), S_(stream), r->size,
+                           batch, r->seed, r->stream, call, 1, r->indices);
+    else
+        hipLaunchKernelGGL(k_sample_indices, dim3((batch + 255) / 256), dim3(256), 0, S_(stream), r->size, batch,
+                           r->seed, r->stream, call, 0, r->indices);
+    hipLaunchKernelGGL(k_sample_gather, dim3(2 * batch), dim3(256), 0, S_(stream), r->indices, batch, r->cells,
+                       channels, plane4, r->states, r->next_states, r->actions, r->rewards, r->dones, states, actions,
+                       rewards, next_states, dones);
+    return launch_status();
+}
+
+int tron_replay_indices(tron_replay_handle r, int32_t batch, int64_t *indices_out, void *stream)
+{
+    if (bad(r)) return r ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
+    if (batch < 1 || batch > r->max_batch || !indices_out) return TRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_copy_i64, dim3((batch + 255) / 256), dim3(256), 0, S_(stream), r->indices, indices_out, batch);
+    return launch_status();
+}
+
+}  // extern "C"

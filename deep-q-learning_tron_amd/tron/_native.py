@@ -1,0 +1,90 @@
+"""ctypes binding of csrc/libtron_hip.so — the C ABI declared in include/tron_hip.h.
+
+There is no CPU implementation behind this module: if the HIP library is
+missing, importing the symbols fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libtron_hip.so")
+
+OK = 0
+MODE = {None: 0, "none": 0, "ice": 1, "temper": 2}                 # tron/game.py:86,163
+OBS_NONE, OBS_CODES_I8, OBS_PLANES3_F32, OBS_PLANES4_F32 = 0, 1, 2, 3
+OBS = {None: OBS_NONE, "none": OBS_NONE, "codes": OBS_CODES_I8, "planes3": OBS_PLANES3_F32,
+       "planes4": OBS_PLANES4_F32}
+STEP_AUTORESET = 1
+
+_vp, _i32, _i64, _u32, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_double
+
+# name -> (restype, argtypes); must list every symbol of include/tron_hip.h
+SIGNATURES = {
+    "tron_abi_version": (C.c_int, []),
+    "tron_strerror": (C.c_char_p, [C.c_int]),
+    "tron_create": (C.c_int, [_i32, _i32, _i32, _i32, _u32, _u32, C.POINTER(_vp)]),
+    "tron_destroy": (C.c_int, [_vp]),
+    "tron_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "tron_set_reward": (C.c_int, [_vp, _f32, _f32, _f32, _f32, _i32]),
+    "tron_set_slide": (C.c_int, [_vp, _f64, _vp, _vp]),
+    "tron_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "tron_step_encode": (C.c_int, [_vp, _vp, _vp, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "tron_step": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "tron_encode": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "tron_rollout_random": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "tron_get_grid": (C.c_int, [_vp, _vp, _vp]),
+    "tron_get_state": (C.c_int, [_vp] + [_vp] * 10),
+    "tron_encode_codes": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "tron_pop_up": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "tron_replay_create": (C.c_int, [_i64, _i32, _u32, _u32, C.POINTER(_vp)]),
+    "tron_replay_destroy": (C.c_int, [_vp]),
+    "tron_replay_push": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tron_replay_sample": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tron_replay_size": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "tron_replay_indices": (C.c_int, [_vp, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+class TronNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libtron_hip.so once; raise if it was not built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TronNativeError(
+                f"{LIB_PATH} is missing: build it with deep-q-learning_tron_amd/csrc/build.sh "
+                "(or __graft_entry__.build()). This package has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError here = ABI mismatch, also loud
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != OK:
+        msg = lib().tron_strerror(rc).decode()
+        raise TronNativeError(f"{what or 'tron call'} failed: {msg} ({rc})")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise TronNativeError("tron kernels take device tensors; got a CPU tensor")
+    if not t.is_contiguous():
+        raise TronNativeError("tron kernels take contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,242 @@
+"""VecTron — N independent TRON games stepped by one HIP kernel launch.
+
+The batched counterpart of the reference's `envs = [make_game(...)] * N` list and
+its `for i in range(N): envs[i].step(a1, a2)` loop (ACKTR.py:183,285-317).  All
+state lives in HBM behind a `tron_handle` (include/tron_hip.h); this class only
+owns the output tensors and launches kernels on torch's current stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as nat
+
+# reward tables of the three reference trainers
+REWARDS = {
+    "ddqn": dict(step=-1.0, win=100.0, lose=-100.0, draw=0.0, step_is_index=0),   # DDQN.py:289-305
+    "dqn": dict(step=0.0, win=100.0, lose=-25.0, draw=0.0, step_is_index=1),      # DQN.py:224-241
+    "acktr": dict(step=-1.0, win=10.0, lose=-10.0, draw=0.0, step_is_index=0),    # ACKTR.py:294-317 + config.py:37
+}
+
+
+class VecTron:
+    def __init__(self, n_envs, width=10, mode=None, fair=False, seed=0x5EED, rank=0, device=None,
+                 obs_format="codes", reward="ddqn", slide=None):
+        if not torch.cuda.is_available():
+            raise nat.TronNativeError("VecTron needs a HIP device (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.N, self.W = int(n_envs), int(width)
+        self.S = self.W + 2
+        self.G = self.S * self.S
+        self.mode = mode
+        self.obs_format = obs_format
+        self._fmt = nat.OBS[obs_format]
+        self._lib = nat.lib()
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_create(self.N, self.W, nat.MODE[mode], int(bool(fair)), seed & 0xFFFFFFFF,
+                                            rank & 0xFFFFFFFF, C.byref(h)), "tron_create")
+        self._h = h
+        self.set_reward(**(REWARDS[reward] if isinstance(reward, str) else reward))
+        if slide is not None:
+            self.set_slide(slide)
+        dev = self.device
+        self.obs = self._alloc_obs(self._fmt)
+        self.done = torch.zeros(self.N, dtype=torch.int8, device=dev)
+        self.winner = torch.zeros(self.N, dtype=torch.int8, device=dev)
+        self.reward = torch.zeros(self.N, 2, dtype=torch.float32, device=dev)
+
+    # -- plumbing ---------------------------------------------------------
+    def _alloc_obs(self, fmt):
+        N, S = self.N, self.S
+        if fmt == nat.OBS_NONE:
+            return None
+        if fmt == nat.OBS_CODES_I8:
+            return torch.empty(N, 2, S, S, dtype=torch.int8, device=self.device)
+        ch = 3 if fmt == nat.OBS_PLANES3_F32 else 4
+        return torch.empty(N, 2, ch, S, S, dtype=torch.float32, device=self.device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.tron_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _dev_arg(self, t, dtype, shape):
+        if t is None:
+            return None
+        t = torch.as_tensor(t, device=self.device).to(dtype).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    # -- configuration ----------------------------------------------------
+    def set_reward(self, step=-1.0, win=100.0, lose=-100.0, draw=0.0, step_is_index=0):
+        nat.check(self._lib.tron_set_reward(self._h, step, win, lose, draw, int(step_is_index)), "tron_set_reward")
+
+    def set_slide(self, slide):
+        """Game(..., slide_pram=slide) (game.py:88); a float or a float64 [N] tensor."""
+        with torch.cuda.device(self.device):
+            if torch.is_tensor(slide):
+                t = self._dev_arg(slide, torch.float64, (self.N,))
+                nat.check(self._lib.tron_set_slide(self._h, 0.0, nat.ptr(t), nat.stream_ptr()), "tron_set_slide")
+            else:
+                nat.check(self._lib.tron_set_slide(self._h, float(slide), None, nat.stream_ptr()), "tron_set_slide")
+
+    # -- reset / step / encode --------------------------------------------
+    def reset(self, mask=None, start_pos=None, weight=None, degree=None):
+        """make_game for the masked envs (all when mask is None); returns the observation."""
+        m = self._dev_arg(mask, torch.int8, (self.N,))
+        sp = self._dev_arg(start_pos, torch.int8, (self.N, 4))
+        w = self._dev_arg(weight, torch.int16, (self.N, 2))
+        d = self._dev_arg(degree, torch.int16, (self.N,))
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_reset(self._h, nat.ptr(m), nat.ptr(sp), nat.ptr(w), nat.ptr(d),
+                                           nat.stream_ptr()), "tron_reset")
+        return self.encode() if self._fmt != nat.OBS_NONE else None
+
+    def step(self, actions=None, uniforms=None, autoreset=True):
+        """One Game.step for every env.  actions int8 [N,2] in 0..3 (None: i.i.d. uniform
+        from the env's Philox stream); uniforms f32 [N,2] for ice/temper (None: Philox).
+        Returns (obs, reward, done, winner) — tensors owned by this object, overwritten by
+        the next call."""
+        a = self._dev_arg(actions, torch.int8, (self.N, 2))
+        u = self._dev_arg(uniforms, torch.float32, (self.N, 2))
+        flags = nat.STEP_AUTORESET if autoreset else 0
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_step_encode(self._h, nat.ptr(a), nat.ptr(u), flags, self._fmt,
+                                                 nat.ptr(self.obs), nat.ptr(self.done), nat.ptr(self.winner),
+                                                 nat.ptr(self.reward), nat.stream_ptr()), "tron_step_encode")
+        return self.obs, self.reward, self.done, self.winner
+
+    def encode(self, obs_format=None, out=None):
+        fmt = self._fmt if obs_format is None else nat.OBS[obs_format]
+        if out is None:
+            out = self.obs if fmt == self._fmt else self._alloc_obs(fmt)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_encode(self._h, fmt, nat.ptr(out), nat.stream_ptr()), "tron_encode")
+        return out
+
+    def rollout_random(self, k_steps, totals=None):
+        """k_steps random-action steps with autoreset (the BASELINE synthetic rollout)."""
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_rollout_random(self._h, int(k_steps), self._fmt, nat.ptr(self.obs),
+                                                    nat.ptr(totals), nat.stream_ptr()), "tron_rollout_random")
+
+    # -- read-back ---------------------------------------------------------
+    def grid(self):
+        """int8 [N, W+2, W+2] Tile values (map.py:9-17)."""
+        out = torch.empty(self.N, self.S, self.S, dtype=torch.int8, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_get_grid(self._h, nat.ptr(out), nat.stream_ptr()), "tron_get_grid")
+        return out
+
+    def state(self):
+        dev, N = self.device, self.N
+        out = dict(pos=torch.empty(N, 4, dtype=torch.int8, device=dev),
+                   alive=torch.empty(N, 2, dtype=torch.int8, device=dev),
+                   dir=torch.empty(N, 2, dtype=torch.int8, device=dev),
+                   done=torch.empty(N, dtype=torch.int8, device=dev),
+                   winner=torch.empty(N, dtype=torch.int8, device=dev),
+                   weight=torch.empty(N, 2, dtype=torch.int16, device=dev),
+                   degree=torch.empty(N, dtype=torch.int16, device=dev),
+                   slide=torch.empty(N, dtype=torch.float64, device=dev),
+                   counters=torch.empty(N, 3, dtype=torch.int32, device=dev))
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_get_state(self._h, *[nat.ptr(out[k]) for k in
+                                                          ("pos", "alive", "dir", "done", "winner", "weight",
+                                                           "degree", "slide", "counters")],
+                                               nat.stream_ptr()), "tron_get_state")
+        return out
+
+
+def encode_codes(tiles, player):
+    """Map.state_for_player(player) on a stack of raw tile images (map.py:67-84)."""
+    t = tiles.contiguous()
+    out = torch.empty_like(t)
+    n = t.shape[0] if t.dim() > 2 else 1
+    nat.check(nat.lib().tron_encode_codes(nat.ptr(t), n, t.numel() // n, int(player), nat.ptr(out),
+                                          nat.stream_ptr()), "tron_encode_codes")
+    return out
+
+
+def pop_up_planes(codes):
+    """util.pop_up on a stack of code planes [n, S, S] -> f32 [n, 3, S, S] (util.py:11-37)."""
+    c = codes.contiguous()
+    n, cells = c.shape[0], c[0].numel()
+    out = torch.empty((n, 3) + tuple(c.shape[1:]), dtype=torch.float32, device=c.device)
+    nat.check(nat.lib().tron_pop_up(nat.ptr(c), n, cells, nat.ptr(out), nat.stream_ptr()), "tron_pop_up")
+    return out
+
+
+class DeviceReplay:
+    """HBM ring of transitions — DDQN.ReplayBuffer (DDQN.py:167-203) without the host."""
+
+    def __init__(self, capacity, cells, seed=0x5EED, rank=0, device=None):
+        if not torch.cuda.is_available():
+            raise nat.TronNativeError("DeviceReplay needs a HIP device (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.capacity, self.cells = int(capacity), int(cells)
+        self._lib = nat.lib()
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_replay_create(self.capacity, self.cells, seed & 0xFFFFFFFF, rank & 0xFFFFFFFF,
+                                                   C.byref(h)), "tron_replay_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.tron_replay_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        size = C.c_int64()
+        nat.check(self._lib.tron_replay_size(self._h, C.byref(size), None))
+        return size.value
+
+    def add(self, state, action, reward, next_state, done):
+        """Batched ReplayBuffer.add: state/next_state int8 [n, cells...] codes, action int8 [n],
+        reward f32 [n], done int8 [n]."""
+        n = state.shape[0]
+        s = state.reshape(n, -1)
+        s2 = next_state.reshape(n, -1)
+        assert s.shape[1] == self.cells and s2.shape[1] == self.cells
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_replay_push(self._h, n, nat.ptr(s.contiguous()),
+                                                 nat.ptr(action.to(torch.int8).contiguous()),
+                                                 nat.ptr(reward.to(torch.float32).contiguous()),
+                                                 nat.ptr(s2.contiguous()), nat.ptr(done.to(torch.int8).contiguous()),
+                                                 nat.stream_ptr()), "tron_replay_push")
+
+    def sample(self, batch, channels=3, plane4=0.0, side=None):
+        """ReplayBuffer.sample(): (states, actions, rewards, next_states, dones) on the device,
+        states f32 [batch, channels, S, S], actions i64 [batch,1], rewards/dones f32 [batch,1]."""
+        dev = self.device
+        S = side if side is not None else int(round(self.cells ** 0.5))
+        st = torch.empty(batch, channels, S, S, dtype=torch.float32, device=dev)
+        s2 = torch.empty_like(st)
+        a = torch.empty(batch, 1, dtype=torch.int64, device=dev)
+        r = torch.empty(batch, 1, dtype=torch.float32, device=dev)
+        d = torch.empty(batch, 1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_replay_sample(self._h, batch, channels, float(plane4), nat.ptr(st), nat.ptr(a),
+                                                   nat.ptr(r), nat.ptr(s2), nat.ptr(d), nat.stream_ptr()),
+                      "tron_replay_sample")
+        return st, a, r, s2, d
+
+    def last_indices(self, batch):
+        out = torch.empty(batch, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_replay_indices(self._h, batch, nat.ptr(out), nat.stream_ptr()))
+        return out

@@ -1,0 +1,174 @@
+/*
+ * include/tron_hip.h — C ABI of libtron_hip.so, the MI355X (gfx950) TRON env path.
+ *
+ * The reference (ckawoalt/Deep-Q-Learning_TRON) has no FFI of its own: its hot
+ * path is a set of Python classes.  Each entry point below names the reference
+ * interface it replaces (paths relative to Deep-Q-learning_TRON/).  The Python
+ * host layer in deep-q-learning_tron_amd/tron/ binds these with ctypes and
+ * re-creates the reference's class surface on top.
+ *
+ * Conventions
+ *  - every function returns 0 (TRON_OK) or a negative tron_status; none throws,
+ *    none allocates after tron_create / tron_replay_create;
+ *  - all buffers are CALLER-OWNED DEVICE pointers (e.g. torch tensors), plain
+ *    pointers and sizes, no framework types; the handle owns only env state;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls
+ *    are asynchronous on it; one host thread per handle;
+ *  - boards are square, side W in [2, 96]; G = (W+2)*(W+2) cells incl. border;
+ *  - env-major layouts: grid [N][G] int8, observations [N][2][...] (player 1,
+ *    then player 2 of each env), so a [N*2, C, W+2, W+2] tensor view is free.
+ */
+#ifndef TRON_HIP_H
+#define TRON_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRON_ABI_VERSION 1
+
+typedef enum {
+    TRON_OK = 0,
+    TRON_ERR_BAD_ARG = -1,      /* NULL handle / out-of-range size, mode, format */
+    TRON_ERR_NO_DEVICE = -2,    /* no HIP device / wrong device current          */
+    TRON_ERR_ALLOC = -3,        /* hipMalloc failed in a *_create                */
+    TRON_ERR_LAUNCH = -4,       /* kernel launch rejected (hipGetLastError)      */
+    TRON_ERR_UNSUPPORTED = -5   /* valid request this build does not implement   */
+} tron_status;
+
+/* Tile codes stored in the grid — tron/map.py:9-17 (Tile) */
+enum { TRON_WALL = -1, TRON_EMPTY = 0, TRON_P1_BODY = 1, TRON_P1_HEAD = 2, TRON_P2_BODY = 3,
+       TRON_P2_HEAD = 4, TRON_P1_SLIDE = 5, TRON_P2_SLIDE = 6 };
+
+/* Game mode — tron/game.py:71,86,163 (mode=None | "ice" | "temper") */
+enum { TRON_MODE_NONE = 0, TRON_MODE_ICE = 1, TRON_MODE_TEMPER = 2 };
+
+/* Observation formats written by tron_step_encode / tron_encode */
+enum {
+    TRON_OBS_NONE = 0,
+    TRON_OBS_CODES_I8 = 1,     /* [N][2][G] int8: Map.state_for_player codes, tron/map.py:67-84       */
+    TRON_OBS_PLANES3_F32 = 2,  /* [N][2][3][G] f32: util.pop_up planes (wall,my,enemy), util.py:11-37 */
+    TRON_OBS_PLANES4_F32 = 3   /* + 4th plane Game.prob_map(), game.py:124-132,297                    */
+};
+
+/* tron_step_encode flags */
+#define TRON_STEP_AUTORESET 1u /* ACKTR.py:294-314: finished env -> fresh make_game, obs = new game */
+
+typedef struct tron_env *tron_handle;
+
+/* --- lifetime ---------------------------------------------------------------
+ * Replaces: constructing N `Game(width, height, pps, mode, slide_pram)` objects
+ * (tron/game.py:71-91), e.g. the `envs = [make_game(...)]*16` list of
+ * ACKTR.py:183.  `fair` selects make_game(mode="fair") start placement
+ * (util.py:48-62).  (seed, rng_stream) key the Philox-4x32-10 counter RNG used
+ * wherever the reference calls `random` (it never seeds; rng_stream = rank).
+ * Envs start un-initialised: call tron_reset before stepping.                */
+int tron_create(int32_t n_envs, int32_t W, int32_t mode, int32_t fair,
+                uint32_t seed, uint32_t rng_stream, tron_handle *out);
+int tron_destroy(tron_handle h);
+
+/* Reward tables — util.get_reward (util.py:87-94), DDQN.py:289-305,
+ * DQN.py:224-241, ACKTR.py:294-317.  step_is_index!=0: non-terminal reward is
+ * the 0-based step index of the episode (DQN.py:224-225).  Default = DDQN.   */
+int tron_set_reward(tron_handle h, float step, float win, float lose, float draw, int32_t step_is_index);
+
+/* `slide_pram` of Game.__init__ (game.py:88); default config.slide = 0.15.
+ * slide_dev: optional device double[N] for a per-env value (play.py:76-98
+ * sweeps it); NULL => broadcast `slide`.                                     */
+int tron_set_slide(tron_handle h, double slide, const double *slide_dev, void *stream);
+
+/* --- reset -------------------------------------------------------------------
+ * Replaces: util.make_game (util.py:46-84) + Game.__init__ (game.py:71-91).
+ * env_mask  int8[N] or NULL (= all): which envs to (re)start.
+ * start_pos int8[N][4] (row1,col1,row2,col2) or NULL: explicit `pps` positions
+ *           as in Game(w,h,[PositionPlayer(1,..,[x1,y1]),PositionPlayer(2,..)]);
+ *           NULL => drawn like make_game (P1-only redraw on clash).
+ * weight    int16[N][2] / degree int16[N] or NULL: explicit Game.weight /
+ *           Game.degree (game.py:83,87); NULL => drawn (randint(40,101) x2,
+ *           randint(-30,30)).                                                */
+int tron_reset(tron_handle h, const int8_t *env_mask, const int8_t *start_pos,
+               const int16_t *weight, const int16_t *degree, void *stream);
+
+/* --- step (+ observation encode), the hot path --------------------------------
+ * Replaces: Game.step(a1, a2) -> (next_p1, next_p2, done) for every env
+ * (tron/game.py:149-277), Map.state_for_player (map.py:83-84) and, for the
+ * PLANES formats, util.pop_up / Game.prob_map.
+ * actions   int8[N][2] in 0..3 (player.py:107-118) or NULL => Philox i.i.d.
+ * uniforms  f32[N][2]: the value player p's `random.random()` would return
+ *           (game.py:169), used only in ice/temper; NULL => Philox.
+ * obs       per obs_fmt, or NULL with TRON_OBS_NONE.
+ * out_done  int8[N]; out_winner int8[N] (0 = None, 1, 2); out_reward f32[N][2];
+ *           each may be NULL.  With TRON_STEP_AUTORESET they describe the game
+ *           that just finished while obs already shows the new one.
+ * A finished env that is stepped without autoreset is left untouched.        */
+int tron_step_encode(tron_handle h, const int8_t *actions, const float *uniforms, uint32_t flags,
+                     int32_t obs_fmt, void *obs, int8_t *out_done, int8_t *out_winner,
+                     float *out_reward, void *stream);
+/* Same without an observation (Game.next_frame, game.py:149-252).            */
+int tron_step(tron_handle h, const int8_t *actions, const float *uniforms, uint32_t flags,
+              int8_t *out_done, int8_t *out_winner, float *out_reward, void *stream);
+/* Encode the current state only: game.map().state_for_player(p) / pop_up of
+ * it (DDQN.py:243-255, game.py:294-304).                                      */
+int tron_encode(tron_handle h, int32_t obs_fmt, void *obs, void *stream);
+
+/* K random-action steps with autoreset, one launch per step on `stream`
+ * (the synthetic rollout of BASELINE.json).  totals u64[4] (device, may be
+ * NULL) accumulates {env_steps, p1_wins, p2_wins, draws}.                     */
+int tron_rollout_random(tron_handle h, int32_t k_steps, int32_t obs_fmt, void *obs,
+                        unsigned long long *totals, void *stream);
+
+/* --- state read-back (parity dumps, the scalar Game facade) --------------------
+ * Replaces: Game.history[-1].map / Map.array() (map.py:60-61), PositionPlayer
+ * .position/.alive (game.py:36-41), Game.winner/.done/.weight/.degree/.slide.
+ * Any pointer may be NULL.  pos int8[N][4]; alive int8[N][2]; dir int8[N][2]
+ * (Direction value 1..4 of the last move, 0 = none; player.py:4-8);
+ * done int8[N]; winner int8[N]; weight int16[N][2]; degree int16[N];
+ * slide f64[N]; counters u32[N][3] = {tick, episode, eplen}.                 */
+int tron_get_grid(tron_handle h, int8_t *grid_out, void *stream);
+int tron_get_state(tron_handle h, int8_t *pos, int8_t *alive, int8_t *dir, int8_t *done,
+                   int8_t *winner, int16_t *weight, int16_t *degree, double *slide,
+                   uint32_t *counters, void *stream);
+int tron_info(tron_handle h, int32_t *n_envs, int32_t *W, int32_t *G, int32_t *mode);
+
+/* --- stateless encoders (the Map / pop_up facade on arbitrary tile images) -----
+ * tron_encode_codes: Map.state_for_player(player) on n images of `cells` tiles
+ *   (map.py:67-84); player 1 or 2.
+ * tron_pop_up: util.pop_up on n code planes -> [n][3][cells] f32 (util.py:11-37). */
+int tron_encode_codes(const int8_t *tiles, int64_t n, int32_t cells, int32_t player,
+                      int8_t *codes_out, void *stream);
+int tron_pop_up(const int8_t *codes, int64_t n, int32_t cells, float *planes_out, void *stream);
+
+/* --- device replay memory -------------------------------------------------------
+ * Replaces: DDQN.ReplayBuffer (DDQN.py:167-203: deque(maxlen) + random.sample +
+ * np.vstack + .to(device)) and DQN.ReplayMemory (DQN.py:81-132).  A ring of
+ * `capacity` transitions in HBM; states are stored as int8 code planes
+ * (2*cells + 8 bytes per slot) and expanded to f32 planes when sampled.       */
+typedef struct tron_replay *tron_replay_handle;
+int tron_replay_create(int64_t capacity, int32_t cells, uint32_t seed, uint32_t rng_stream,
+                       tron_replay_handle *out);
+int tron_replay_destroy(tron_replay_handle r);
+/* Append n transitions (ReplayBuffer.add, DDQN.py:186-189), oldest overwritten.
+ * state/next_state int8[n][cells] codes; action int8[n]; reward f32[n]; done int8[n].
+ * Row i lands in slot (head + i) mod capacity: the ring order is deterministic. */
+int tron_replay_push(tron_replay_handle r, int64_t n, const int8_t *state, const int8_t *action,
+                     const float *reward, const int8_t *next_state, const int8_t *done,
+                     void *stream);
+/* Uniform sample of `batch` distinct slots (random.sample, DDQN.py:191-200),
+ * written as pop_up planes: states/next_states f32[batch][channels][cells]
+ * (channels 3, or 4 with the constant `plane4` value), actions i64[batch],
+ * rewards f32[batch], dones f32[batch].  Needs size >= batch.                  */
+int tron_replay_sample(tron_replay_handle r, int32_t batch, int32_t channels, float plane4,
+                       float *states, int64_t *actions, float *rewards, float *next_states,
+                       float *dones, void *stream);
+int tron_replay_size(tron_replay_handle r, int64_t *size, int64_t *capacity);
+/* The slots drawn by the last tron_replay_sample, i64[batch] (tests, logging). */
+int tron_replay_indices(tron_replay_handle r, int32_t batch, int64_t *indices_out, void *stream);
+
+const char *tron_strerror(int status);
+int tron_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRON_HIP_H */

@@ -260,6 +260,27 @@ void orc_vec_reset_env(orc_vec_t *v, int i)
     v->episode[i] += 1;
 }
 
+/* Game(w, h, pps) with explicit start positions; Game.__init__'s weight/degree draws
+ * (game.py:83,87) come from Philox(ctr = {env, episode, ORC_RNG_INIT, 0}) unless given. */
+void orc_vec_init_env(orc_vec_t *v, int i, const int8_t start[4], const int16_t *weight, const int16_t *degree)
+{
+    int G = (v->W + 2) * (v->W + 2);
+    uint32_t key[2] = { v->seed, v->stream };
+    uint32_t ctr[4] = { (uint32_t)i, v->episode[i], ORC_RNG_INIT, 0 }, x[4];
+    orc_philox4x32_10(ctr, key, x);
+    v->weight[2 * i]     = weight ? weight[0] : (int16_t)randint_u32(x[0], 40, 101);
+    v->weight[2 * i + 1] = weight ? weight[1] : (int16_t)randint_u32(x[1], 40, 101);
+    v->degree[i]         = degree ? *degree   : (int16_t)randint_u32(x[2], -30, 30);
+    orc_game_init(&v->grid[(size_t)i * G], v->W, start);
+    memcpy(&v->pos[4 * i], start, 4);
+    v->alive[2 * i] = v->alive[2 * i + 1] = 1;
+    v->dir[2 * i] = v->dir[2 * i + 1] = 0;
+    v->done[i] = 0;
+    v->winner[i] = 0;
+    v->eplen[i] = 0;
+    v->episode[i] += 1;
+}
+
 void orc_vec_step(orc_vec_t *v, const int8_t *actions, const float *uniforms, int autoreset,
                   int8_t *obs_codes, int8_t *out_done, int8_t *out_winner, float *out_reward)
 {

@@ -67,6 +67,7 @@ def lib():
         L.orc_rewards.argtypes = [C.POINTER(Reward), C.c_int, C.c_int, C.c_uint32, C.c_void_p]
         L.orc_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_vec_reset_env.argtypes = [C.POINTER(_Vec), C.c_int]
+        L.orc_vec_init_env.argtypes = [C.POINTER(_Vec), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_vec_step.argtypes = [C.POINTER(_Vec), C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -185,21 +186,21 @@ class VecOracle:
         for i in range(self.N):
             lib().orc_vec_reset_env(C.byref(self.v), i)
 
-    def set_starts(self, starts, weight=None, degree=None):
-        """Explicit start positions (parity mode): Game.__init__ with given pps."""
-        starts = np.asarray(starts, np.int8).reshape(self.N, 4)
+    def set_starts(self, starts, weight=None, degree=None, mask=None):
+        """Explicit start positions: Game(w, h, pps) for the masked envs (game.py:71-91)."""
+        starts = np.ascontiguousarray(starts, np.int8).reshape(self.N, 4)
+        w = None if weight is None else np.ascontiguousarray(weight, np.int16).reshape(self.N, 2)
+        d = None if degree is None else np.ascontiguousarray(degree, np.int16).reshape(self.N)
         for i in range(self.N):
-            self.grid[i] = game_init(self.W, starts[i]).reshape(-1)
-        self.pos[:] = starts
-        self.alive[:] = 1
-        self.dir[:] = 0
-        self.done[:] = 0
-        self.winner[:] = 0
-        self.eplen[:] = 0
-        if weight is not None:
-            self.weight[:] = np.asarray(weight, np.int16).reshape(self.N, 2)
-        if degree is not None:
-            self.degree[:] = np.asarray(degree, np.int16).reshape(self.N)
+            if mask is not None and not mask[i]:
+                continue
+            lib().orc_vec_init_env(C.byref(self.v), i, _p(starts[i]), None if w is None else _p(w[i]),
+                                   None if d is None else _p(d[i:i + 1]))
+
+    def reset_masked(self, mask):
+        for i in range(self.N):
+            if mask[i]:
+                lib().orc_vec_reset_env(C.byref(self.v), i)
 
     def step(self, actions=None, uniforms=None, autoreset=False, want_obs=True):
         a = None if actions is None else np.ascontiguousarray(actions, np.int8)

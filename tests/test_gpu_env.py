@@ -1,0 +1,257 @@
+"""GPU parity: the HIP path (through the C ABI) against (1) the golden vectors recorded
+from the reference and (2) the CPU oracle on the same seeds.  Bit-exact everywhere —
+this is integer/byte work; the only floats (rewards, pop_up planes) are exact small
+integers.  Run with `pytest -m gpu` on the MI355X box."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def T():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import tron.vec as tv
+    import oracle
+    return tv, oracle
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+# --------------------------------------------------------------------- golden --
+def test_golden_step_exhaustive_4x4(T):
+    tv, _ = T
+    g = load_golden("step_exhaustive_4x4")
+    n = len(g["starts"])
+    env = tv.VecTron(n, 4, obs_format="codes")
+    env.reset(start_pos=torch.from_numpy(g["starts"]))
+    obs, reward, done, winner = env.step(torch.from_numpy(g["actions"]), autoreset=False)
+    st = env.state()
+    assert np.array_equal(np_(env.grid()), g["grid"])
+    assert np.array_equal(np_(st["pos"]), g["pos"])
+    assert np.array_equal(np_(st["alive"]), g["alive"])
+    assert np.array_equal(np_(done), g["done"]) and np.array_equal(np_(winner), g["winner"])
+    assert np.array_equal(np_(st["dir"]), g["actions"] + 1)
+    assert np.array_equal(np_(obs[:, 0]), g["obs1"]) and np.array_equal(np_(obs[:, 1]), g["obs2"])
+    # DDQN reward table (DDQN.py:289-305)
+    r = np_(reward)
+    exp = np.where(g["done"][:, None] == 0, -1.0,
+                   np.stack([np.select([g["winner"] == 1, g["winner"] == 2], [100.0, -100.0], 0.0),
+                             np.select([g["winner"] == 2, g["winner"] == 1], [100.0, -100.0], 0.0)], 1))
+    assert np.array_equal(r, exp.astype(np.float32))
+
+
+EPISODE_SETS = ["episodes_none_4", "episodes_none_10", "episodes_none_24", "episodes_none_32",
+                "episodes_uniform_10", "episodes_ice_4", "episodes_ice_10", "episodes_ice_24",
+                "episodes_temper_4", "episodes_temper_10", "episodes_temper_24"]
+
+
+@pytest.mark.parametrize("name", EPISODE_SETS)
+def test_golden_episodes(T, name):
+    """Every recorded reference episode is one env of a batch; finished envs idle (no autoreset)."""
+    tv, _ = T
+    g = load_golden(name)
+    W, mode = int(g["W"]), str(g["mode"])
+    off = g["ep_off"].astype(np.int64)
+    n = len(off) - 1
+    lens = np.diff(off)
+    keep = "step_grid" in g.files
+    env = tv.VecTron(n, W, mode=None if mode == "none" else mode, obs_format="codes")
+    env.set_slide(torch.from_numpy(g["slide"]))
+    env.reset(start_pos=torch.from_numpy(g["starts"]), weight=torch.from_numpy(g["weight"]),
+              degree=torch.from_numpy(g["degree"]))
+    for t in range(int(lens.max())):
+        active = lens > t
+        rows = np.where(active, off[:-1] + t, 0)
+        a = np.where(active[:, None], g["actions"][rows], 0).astype(np.int8)
+        u = np.where(active[:, None], g["uniforms"][rows], 0).astype(np.float32)
+        obs, reward, done, winner = env.step(torch.from_numpy(a), torch.from_numpy(u), autoreset=False)
+        st = env.state()
+        act = np.nonzero(active)[0]
+        assert np.array_equal(np_(st["pos"])[act], g["pos"][rows[act]]), t
+        assert np.array_equal(np_(st["alive"])[act], g["alive"][rows[act]]), t
+        assert np.array_equal(np_(done)[act], g["done"][rows[act]]), t
+        if keep:
+            assert np.array_equal(np_(env.grid())[act], g["step_grid"][rows[act]]), t
+            assert np.array_equal(np_(obs[:, 0])[act], g["step_obs1"][rows[act]]), t
+            assert np.array_equal(np_(obs[:, 1])[act], g["step_obs2"][rows[act]]), t
+    assert np.all(np_(env.done) == 1)
+    assert np.array_equal(np_(env.winner), g["winner"])
+    assert np.array_equal(np_(env.grid()), g["final_grid"])
+    obs = env.encode()
+    assert np.array_equal(np_(obs[:, 0]), g["final_obs1"]) and np.array_equal(np_(obs[:, 1]), g["final_obs2"])
+
+
+def test_golden_encode_stateless(T):
+    tv, _ = T
+    g = load_golden("encode")
+    for W in (4, 10, 24):
+        raw = torch.from_numpy(g[f"raw_{W}"]).cuda()
+        for p in (1, 2):
+            codes = tv.encode_codes(raw, p)
+            assert np.array_equal(np_(codes), g[f"codes_{W}"][:, p - 1])
+            planes = tv.pop_up_planes(codes)
+            assert np.array_equal(np_(planes).astype(np.float64), g[f"planes_{W}"][:, p - 1])
+
+
+# --------------------------------------------------------------- HIP vs oracle --
+def _compare_state(env, ref, tag):
+    st = env.state()
+    N = ref.N
+    assert np.array_equal(np_(env.grid()).reshape(N, -1), ref.grid), tag
+    assert np.array_equal(np_(st["pos"]), ref.pos), tag
+    assert np.array_equal(np_(st["alive"]), ref.alive), tag
+    assert np.array_equal(np_(st["dir"]), ref.dir), tag
+    assert np.array_equal(np_(st["done"]), ref.done) and np.array_equal(np_(st["winner"]), ref.winner), tag
+    assert np.array_equal(np_(st["weight"]), ref.weight) and np.array_equal(np_(st["degree"]), ref.degree), tag
+    c = np_(st["counters"]).astype(np.uint32)
+    assert np.array_equal(c[:, 0], ref.tick) and np.array_equal(c[:, 1], ref.episode), tag
+    assert np.array_equal(c[:, 2], ref.eplen), tag
+
+
+CASES = [
+    # N,   W,  mode,     fair,  autoreset, reward
+    (64, 10, None, False, True, "ddqn"),
+    (100, 10, "temper", False, True, "acktr"),     # tail tile (100 = 64 + 36)
+    (37, 4, "ice", True, True, "dqn"),             # fair starts, step-index reward
+    (130, 7, "ice", False, True, "ddqn"),          # odd W: generic (G % 4 != 0) path
+    (33, 5, "temper", True, False, "ddqn"),        # odd W, no autoreset
+    (70, 24, None, False, True, "ddqn"),
+    (40, 32, "temper", False, True, "ddqn"),       # E = 32 tiles
+    (20, 47, "ice", False, True, "ddqn"),          # E = 16 tiles, odd W
+]
+
+
+@pytest.mark.parametrize("N,W,mode,fair,autoreset,reward", CASES)
+def test_hip_vs_oracle_philox(T, N, W, mode, fair, autoreset, reward):
+    tv, oracle = T
+    table = {"ddqn": oracle.REWARD_DDQN, "dqn": oracle.REWARD_DQN, "acktr": oracle.REWARD_ACKTR}[reward]
+    env = tv.VecTron(N, W, mode=mode, fair=fair, seed=1234, rank=3, obs_format="codes", reward=reward, slide=0.3)
+    ref = oracle.VecOracle(N, W, mode=mode, seed=1234, stream=3, fair=fair, reward=table, slide=0.3)
+    obs0 = env.reset()
+    ref.reset_all()
+    _compare_state(env, ref, "reset")
+    o_ref = np.stack([[oracle.state_for_player(ref.grid[i], p) for p in (1, 2)] for i in range(N)])
+    assert np.array_equal(np_(obs0).reshape(N, 2, -1), o_ref)
+    steps = 30 if W <= 10 else 12
+    for t in range(steps):
+        obs, r, d, w = env.step(autoreset=autoreset)
+        o, dd, ww, rr = ref.step(autoreset=autoreset)
+        assert np.array_equal(np_(obs).reshape(N, 2, -1), o), t
+        assert np.array_equal(np_(d), dd) and np.array_equal(np_(w), ww), t
+        assert np.array_equal(np_(r), rr), t
+        _compare_state(env, ref, t)
+        if not autoreset and t % 5 == 4:          # DDQN-style: reset the finished envs explicitly
+            mask = ref.done.copy()
+            env.reset(mask=torch.from_numpy(mask))
+            ref.reset_masked(mask)
+            _compare_state(env, ref, ("masked reset", t))
+    assert ref.episode.max() > 1
+
+
+@pytest.mark.parametrize("W,mode", [(10, None), (6, "ice"), (9, "temper")])
+def test_explicit_actions_and_planes(T, W, mode):
+    """Caller-supplied actions/uniforms + the f32 plane formats (pop_up, prob_map plane)."""
+    tv, oracle = T
+    N = 96
+    rng = np.random.RandomState(5)
+    slide = rng.choice([0.0, 0.03, 0.15, 0.36], size=N)
+    env3 = tv.VecTron(N, W, mode=mode, seed=9, obs_format="planes3")
+    env4 = tv.VecTron(N, W, mode=mode, seed=9, obs_format="planes4")
+    ref = oracle.VecOracle(N, W, mode=mode, seed=9)
+    ref.slide[:] = slide
+    for e in (env3, env4):
+        e.set_slide(torch.from_numpy(slide))
+        e.reset()
+    ref.reset_all()
+    for t in range(15):
+        a = rng.randint(0, 4, size=(N, 2)).astype(np.int8)
+        u = (rng.randint(0, 1 << 24, size=(N, 2)) / float(1 << 24)).astype(np.float32)
+        o3, r3, d3, w3 = env3.step(torch.from_numpy(a), torch.from_numpy(u), autoreset=True)
+        o4, r4, d4, w4 = env4.step(torch.from_numpy(a), torch.from_numpy(u), autoreset=True)
+        o, dd, ww, rr = ref.step(a, u, autoreset=True)
+        planes = np.stack([oracle.pop_up(o[i, p]) for i in range(N) for p in range(2)]).reshape(N, 2, 3, W + 2, W + 2)
+        assert np.array_equal(np_(o3), planes), t
+        assert np.array_equal(np_(o4)[:, :, :3], planes), t
+        p4 = np.array([np.float32(oracle.degree_slide(s)) for s in slide], np.float32)
+        assert np.array_equal(np_(o4)[:, :, 3], np.broadcast_to(p4[:, None, None, None], (N, 2, W + 2, W + 2))), t
+        assert np.array_equal(np_(d3), dd) and np.array_equal(np_(w4), ww) and np.array_equal(np_(r3), rr), t
+    # encode() in another format gives the same state
+    codes = env3.encode("codes")
+    assert np.array_equal(np_(codes).reshape(N, 2, -1),
+                          np.stack([[oracle.state_for_player(ref.grid[i], p) for p in (1, 2)] for i in range(N)]))
+
+
+def test_step_without_obs_and_totals(T):
+    tv, oracle = T
+    N, W = 256, 10
+    env = tv.VecTron(N, W, seed=77, obs_format=None)
+    ref = oracle.VecOracle(N, W, seed=77)
+    env.reset()
+    ref.reset_all()
+    totals = torch.zeros(4, dtype=torch.int64, device="cuda")
+    env.rollout_random(25, totals)
+    exp = np.zeros(4, np.int64)
+    for _ in range(25):
+        _, d, w, _ = ref.step(autoreset=True, want_obs=False)
+        exp += [N, int(((d == 1) & (w == 1)).sum()), int(((d == 1) & (w == 2)).sum()), int(((d == 1) & (w == 0)).sum())]
+    assert np.array_equal(np_(totals), exp)
+    _compare_state(env, ref, "rollout")
+
+
+# ----------------------------------------------------- full size: properties --
+def test_full_size_65536x24_properties(T):
+    """BASELINE config 3 size.  Size-independent checks: (a) the first 2048 envs equal the
+    oracle run on the same seed (Philox is keyed by env index, so a prefix is self-contained);
+    (b) obs is exactly the stateless encode of the grid; (c) per-env tile census matches
+    the counters: one head per player, bodies == eplen, intact border for live envs."""
+    tv, oracle = T
+    N, W, K, NP = 65536, 24, 16, 2048
+    env = tv.VecTron(N, W, seed=0x5EED, obs_format="codes")
+    ref = oracle.VecOracle(NP, W, seed=0x5EED)
+    env.reset()
+    ref.reset_all()
+    for _ in range(K):
+        obs, r, d, w = env.step(autoreset=True)
+        o, dd, ww, rr = ref.step(autoreset=True)
+    assert np.array_equal(np_(obs[:NP]).reshape(NP, 2, -1), o)
+    assert np.array_equal(np_(d[:NP]), dd) and np.array_equal(np_(w[:NP]), ww)
+    grid = env.grid()
+    assert np.array_equal(np_(grid[:NP]).reshape(NP, -1), ref.grid)
+    for p in (1, 2):
+        assert torch.equal(tv.encode_codes(grid, p), obs[:, p - 1])
+    st = env.state()
+    eplen = st["counters"][:, 2].to(torch.int64)
+    flat = grid.reshape(N, -1)
+    assert torch.all((flat == 2).sum(1) == 1) and torch.all((flat == 4).sum(1) == 1)
+    assert torch.equal((flat == 1).sum(1), eplen) and torch.equal((flat == 3).sum(1), eplen)
+    S = W + 2
+    border = torch.ones(S, S, dtype=torch.bool, device="cuda")
+    border[1:-1, 1:-1] = False
+    assert torch.all(grid[:, border] == -1)          # autoreset leaves only live boards behind
+    assert int(st["counters"][:, 1].max()) > 1
+
+
+# ----------------------------------------------------------------- ABI errors --
+def test_abi_error_codes(T):
+    import ctypes as C
+    from tron import _native as nat
+    L = nat.lib()
+    h = C.c_void_p()
+    assert L.tron_create(0, 10, 0, 0, 1, 0, C.byref(h)) == -1          # n_envs < 1
+    assert L.tron_create(8, 1, 0, 0, 1, 0, C.byref(h)) == -1           # W too small
+    assert L.tron_create(8, 10, 7, 0, 1, 0, C.byref(h)) == -1          # bad mode
+    assert L.tron_step_encode(None, None, None, 0, 0, None, None, None, None, None) == -1
+    assert L.tron_create(8, 10, 0, 0, 1, 0, C.byref(h)) == 0
+    assert L.tron_step_encode(h, None, None, 0, 1, None, None, None, None, None) == -1   # fmt without buffer
+    assert L.tron_step_encode(h, None, None, 8, 0, None, None, None, None, None) == -1   # unknown flag
+    assert L.tron_encode(h, 0, None, None) == -1
+    assert L.tron_destroy(h) == 0
+    assert nat.lib().tron_strerror(-1) == b"bad argument"
