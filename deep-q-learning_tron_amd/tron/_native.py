@@ -59,6 +59,9 @@ def lib():
             raise TronNativeError(
                 f"{LIB_PATH} is missing: build it with deep-q-learning_tron_amd/csrc/build.sh "
                 "(or __graft_entry__.build()). This package has no CPU fallback.")
+        # torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Load torch first so this
+        # library binds to THAT runtime: one HIP runtime per process, shared streams and pointers.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError here = ABI mismatch, also loud
