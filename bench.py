@@ -37,6 +37,23 @@ def alg_bytes_per_env_step(width):
     return 3 * g + 32
 
 
+def pmc_traffic(envs, width, obs, mode):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes
+    (profiles/r*_summary.json, made by scripts/pmc_summary.py: FETCH_SIZE x2 per the gfx950
+    correction + WRITE_SIZE, KiB -> bytes).  Only valid for the exact workload it was taken on."""
+    import glob
+    if (envs, width, obs, mode) != (N_ENVS, WIDTH, "codes", "none"):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
+    if not files:
+        return None, None
+    summ = json.load(open(files[-1]))
+    for name, k in summ["kernels"].items():
+        if "k_tile<1, true, true>" in name:
+            return k["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def cpu_baseline(width, budget_s=12.0):
     """The CPU oracle (C restatement of the reference, `kind: port`) on one host core, same
     unit of work: step + both observations + autoreset, i.i.d. uniform actions."""
@@ -115,6 +132,7 @@ def main():
             g = (args.width + 2) ** 2
             b_alg = g + 32 + 2 * (3 if args.obs == "planes3" else 4) * g * 4
         achieved = b_alg * args.envs / (kern_ms * 1e-3) / 1e9
+        hbm_bytes, hbm_src = pmc_traffic(args.envs, args.width, args.obs, args.mode)
         out = {
             "metric": "env-steps/sec",
             "value": total_env_steps / wall,
@@ -134,9 +152,11 @@ def main():
                        "envs_per_gpu": args.envs, "grid": f"{args.width}x{args.width}",
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_step_encode", "kernel_ms": kern_ms,
-                         "alg_bytes_per_env_step": b_alg},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None if hbm_bytes is None else hbm_bytes / (kern_ms * 1e-3) / 1e9,
+                         "traffic_bytes_per_launch": hbm_bytes, "traffic_source": hbm_src,
+                         "kernel": "k_tile<CODES_I8, step, 16B>", "kernel_ms": kern_ms,
+                         "alg_bytes_per_env_step": b_alg, "alg_bytes_per_launch": b_alg * args.envs},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.width)

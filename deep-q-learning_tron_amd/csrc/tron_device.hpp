@@ -1,33 +1,47 @@
 // Device-side building blocks of the gfx950 TRON env path.
 // Rules restated from the reference are cited as file:line into
-// Deep-Q-learning_TRON/; nothing here is shared with oracle/ (the CPU checker).
+// Deep-Q-learning_TRON/; nothing here is shared with the CPU checker.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace tron {
 
-// ---- env state held by a handle, all in HBM, struct-of-arrays --------------
+// ---- env state held by a handle, all in HBM ---------------------------------
+// Hot words are packed one uint4 per env so a step costs one 16-byte load and one
+// 16-byte store of state; the restart words are read every step, written on restart.
 struct Params {
     int32_t N, W, S, G;        // envs, board side, S = W+2, G = S*S cells
     int32_t mode, fair;        // game.py:86 mode; util.py:48 "fair" start placement
     uint32_t seed, stream;     // Philox key
     float r_step, r_win, r_lose, r_draw;
     int32_t r_index;           // DQN.py:224-225: non-terminal reward = step index
-    uint32_t d_magic;          // ceil(2^32 / D), D = G/4 (G%4==0) — exact q = n/D for n < 2^32/D
     int8_t *grid;              // [N][G] Tile values (map.py:9-17), storage [row+1][col+1] (map.py:86-92)
-    uint32_t *pos;             // [N] r1 | c1<<8 | r2<<16 | c2<<24 (int8 each; game.py:36-41)
-    uint32_t *meta;            // [N] alive0 | alive1<<1 | done<<2 | winner<<4 | dir0<<8 | dir1<<12
-    uint32_t *envp;            // [N] weight0 | weight1<<8 | (int8)degree<<16 (game.py:83,87)
+    uint4 *st4;                // [N] {pos, meta, eplen, tick}
+                               //   pos  = r1 | c1<<8 | r2<<16 | c2<<24 (int8 each; game.py:36-41)
+                               //   meta = alive0 | alive1<<1 | done<<2 | winner<<4 | dir0<<8 | dir1<<12
+                               //   eplen = steps in the current game; tick = steps since create (RNG counter)
+    uint4 *rs4;                // [N] {envp, episode, nstart, nenvp}
+                               //   envp = weight0 | weight1<<8 | (int8)degree<<16 (game.py:83,87)
+                               //   episode = games started (RNG counter)
+                               //   nstart / nenvp = pos / envp of the NEXT game (make_game at `episode`)
     double *slide;             // [N] game.py:88
-    uint32_t *tick;            // [N] steps taken since create (RNG counter)
-    uint32_t *episode;         // [N] games started (RNG counter)
-    uint32_t *eplen;           // [N] steps in the current game
     const int8_t *fresh;       // [G] empty board with WALL border (map.py:45-48)
 };
 
 enum { RNG_STEP = 0, RNG_RESET = 2, RNG_INIT = 3 };
 enum { META_ALIVE0 = 1u, META_ALIVE1 = 2u, META_DONE = 4u };
+
+__device__ __forceinline__ uint32_t pack_pos(int r1, int c1, int r2, int c2)
+{
+    return (uint32_t)(uint8_t)r1 | ((uint32_t)(uint8_t)c1 << 8) | ((uint32_t)(uint8_t)r2 << 16) |
+           ((uint32_t)(uint8_t)c2 << 24);
+}
+__device__ __forceinline__ uint32_t pack_envp(int w0, int w1, int degree)
+{
+    return (uint32_t)(uint8_t)w0 | ((uint32_t)(uint8_t)w1 << 8) | ((uint32_t)(uint8_t)(int8_t)degree << 16);
+}
+__device__ __forceinline__ int cell_index(int S, int r, int c) { return (r + 1) * S + (c + 1); }
 
 // ---- Philox-4x32-10 (Salmon et al., SC'11) ----------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -53,63 +67,81 @@ __device__ __forceinline__ int randint_u32(uint32_t u, int a, int b)
     return a + (int)__umulhi(u, (uint32_t)(b - a + 1));
 }
 
-// Sequential u32 draws from the reset stream of (env, episode): block b of four
-// values is Philox(ctr = {env, episode, RNG_RESET, b}).
-struct ResetStream {
-    uint32_t env, ep, k0, k1;
-    uint32_t b0, b1, b2, b3;
-    int n;
-    __device__ __forceinline__ uint32_t next()
-    {
-        const int j = n & 3;
-        if (j == 0) {
-            uint32_t o[4];
-            philox4x32_10(env, ep, RNG_RESET, (uint32_t)(n >> 2), k0, k1, o);
-            b0 = o[0]; b1 = o[1]; b2 = o[2]; b3 = o[3];
-        }
-        ++n;
-        return j == 0 ? b0 : j == 1 ? b1 : j == 2 ? b2 : b3;
-    }
-};
-
 struct NewGame {
     int r1, c1, r2, c2, w0, w1, degree;
 };
 
-// util.make_game start placement + Game.__init__ draws (util.py:46-84, game.py:83,87).
-// (x, y) of the reference are (row, col).  Only player 1 is re-drawn on a clash
-// (util.py:76-78); the loop is bounded at 16 rounds for the GPU.
-__device__ inline NewGame make_game(const Params &P, uint32_t env, uint32_t episode)
+// util.make_game start placement + Game.__init__ draws (util.py:46-84, game.py:83,87) over the
+// reset stream of (env, episode): u32 number n is word n%4 of Philox(ctr = {env, episode,
+// RNG_RESET, n/4}).  (x, y) of the reference are (row, col).  Only player 1 is re-drawn on a
+// clash (util.py:76-78); bounded at 16 redraw rounds for the GPU.  Written as one loop over the
+// draw index with a phase variable so the Philox body exists once in the code.
+__device__ inline NewGame make_game(uint32_t seed, uint32_t stream, int W, int fair, uint32_t env, uint32_t episode)
 {
-    ResetStream s{env, episode, P.seed, P.stream, 0, 0, 0, 0, 0};
-    const int W = P.W;
+    NewGame g{0, 0, 0, 0, 0, 0, 0};
     int lb1x = 0, lb1y = 0, lb2x = 0, lb2y = 0;
     int ub1x = W - 1, ub1y = W - 1, ub2x = W - 1, ub2y = W - 1;
-    if (P.fair) {                                       // util.py:48-62
-        const int py = randint_u32(s.next(), 0, W - 1);
-        const int px = randint_u32(s.next(), 0, W - 1);
-        lb1x = max(0, px - 1); ub1x = min(W - 1, px + 1);
-        lb1y = max(0, py - 1); ub1y = min(W - 1, py + 1);
-        lb2x = W - 1 - ub1x;   ub2x = W - 1 - lb1x;
-        lb2y = W - 1 - ub1y;   ub2y = W - 1 - lb1y;
-    }
-    NewGame g;
-    g.r1 = randint_u32(s.next(), lb1x, ub1x);
-    g.c1 = randint_u32(s.next(), lb1y, ub1y);
-    g.r2 = randint_u32(s.next(), lb2x, ub2x);
-    g.c2 = randint_u32(s.next(), lb2y, ub2y);
-    int rounds = 0;
-    while (g.r1 == g.r2 && g.c1 == g.c2) {
-        if (rounds++ == 16) {
-            g.r1 = (g.r1 == ub1x) ? lb1x : g.r1 + 1;
-            break;
+    int py = 0, rounds = 0;
+    bool have_p2 = false;
+    uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    // phases: 0 point_y, 1 point_x (fair only); 2 x1, 3 y1, 4 x2, 5 y2; 7 weight0, 8 weight1, 9 degree
+    int phase = fair ? 0 : 2;
+    for (int n = 0; phase < 10; ++n) {
+        const int j = n & 3;
+        if (j == 0) {
+            uint32_t o[4];
+            philox4x32_10(env, episode, RNG_RESET, (uint32_t)(n >> 2), seed, stream, o);
+            b0 = o[0]; b1 = o[1]; b2 = o[2]; b3 = o[3];
         }
-        g.r1 = randint_u32(s.next(), lb1x, ub1x);
-        g.c1 = randint_u32(s.next(), lb1y, ub1y);
+        const uint32_t u = j == 0 ? b0 : j == 1 ? b1 : j == 2 ? b2 : b3;
+        bool check = false;
+        if (phase == 0) {                                   // util.py:49
+            py = randint_u32(u, 0, W - 1);
+            phase = 1;
+        } else if (phase == 1) {                            // util.py:50-62
+            const int px = randint_u32(u, 0, W - 1);
+            lb1x = max(0, px - 1); ub1x = min(W - 1, px + 1);
+            lb1y = max(0, py - 1); ub1y = min(W - 1, py + 1);
+            lb2x = W - 1 - ub1x;   ub2x = W - 1 - lb1x;
+            lb2y = W - 1 - ub1y;   ub2y = W - 1 - lb1y;
+            phase = 2;
+        } else if (phase == 2) {                            // util.py:70 / :77
+            g.r1 = randint_u32(u, lb1x, ub1x);
+            phase = 3;
+        } else if (phase == 3) {                            // util.py:71 / :78
+            g.c1 = randint_u32(u, lb1y, ub1y);
+            phase = 4;
+            check = have_p2;
+        } else if (phase == 4) {                            // util.py:73
+            g.r2 = randint_u32(u, lb2x, ub2x);
+            phase = 5;
+        } else if (phase == 5) {                            // util.py:74
+            g.c2 = randint_u32(u, lb2y, ub2y);
+            have_p2 = true;
+            check = true;
+        } else if (phase == 7) {                            // game.py:83
+            g.w0 = randint_u32(u, 40, 101);
+            phase = 8;
+        } else if (phase == 8) {
+            g.w1 = randint_u32(u, 40, 101);
+            phase = 9;
+        } else {                                            // game.py:87
+            g.degree = randint_u32(u, -30, 30);
+            phase = 10;
+        }
+        if (check) {                                        // util.py:76: while x1 == x2 and y1 == y2
+            if (g.r1 == g.r2 && g.c1 == g.c2) {
+                if (rounds++ == 16) {
+                    g.r1 = (g.r1 == ub1x) ? lb1x : g.r1 + 1;
+                    phase = 7;
+                } else {
+                    phase = 2;
+                }
+            } else {
+                phase = 7;
+            }
+        }
     }
-    g.w0 = randint_u32(s.next(), 40, 101);              // game.py:83
-    g.w1 = randint_u32(s.next(), 40, 101);
-    g.degree = randint_u32(s.next(), -30, 30);          // game.py:87
     return g;
 }
 

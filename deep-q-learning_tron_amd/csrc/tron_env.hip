@@ -1,16 +1,27 @@
 // gfx950 kernels + C ABI for the vectorised TRON env (include/tron_hip.h).
 //
-// Layout.  Everything is env-major: grid[N][G] int8, obs[N][2][...].  One
-// workgroup owns a tile of E consecutive envs:
-//   A  stream the tile's E*G grid bytes HBM -> LDS with 16-byte loads (coalesced:
-//      the tile is one contiguous, 16-byte aligned span because E % 16 == 0);
-//   B  wave 0 plays the move: ONE ENV PER LANE, neighbourhood reads and trail
-//      writes hit the LDS copy; the <=6 dirty cells go back to HBM as bytes;
-//   B2 finished envs (autoreset) get a fresh board: one wave per env rewrites
-//      its G bytes in LDS and HBM;
-//   C  every thread encodes 16 output bytes per iteration from the LDS tile
-//      (v_perm_b32 as an 8-entry byte LUT) and stores them with 16-byte stores.
-// HBM traffic per env-step: read G, write 2G (codes) — the algorithmic minimum.
+// Data layout.  Everything is env-major: grid[N][G] int8, obs[N][2][...],
+// one uint4 of hot state words per env.  A 256-thread workgroup owns a tile of E consecutive
+// envs, cut into per-env 16-byte chunks (CPE = ceil(G/16) per env, the last one possibly
+// short) so a chunk never spans envs; chunk i of the tile sits in LDS slot i.
+//
+// k_tile, one launch = one Game.step for every env + both players' observations:
+//   1  all threads: chunk loads HBM -> registers -> LDS (6 loads in flight per thread).
+//      In the shadow of that load wave 0, ONE ENV PER LANE, does all the random-number
+//      work the step can need: the Philox block for actions / slide uniforms and,
+//      speculatively, the start of the game after next (both need only the counters);
+//   2  barrier; wave 0 plays the move against the LDS tile — reads its 2-4 cells, writes
+//      its <=6 cells, marks their chunks in an LDS bitmask — and leaves its results
+//      (new state words, done/winner/reward, restart words) in LDS records.  It issues
+//      no global store: under store back-pressure each one would stall the lone wave;
+//   3  barrier; waves 1-3 write the records out (one array each), then ALL threads
+//      stream: LDS chunk (or the fresh-board template + heads for a restarted env) ->
+//      v_perm byte LUT -> two coalesced 16-byte stores, plus a predicated write-back of
+//      the grid chunk when it is dirty or its env restarted.
+// HBM sees one coalesced read of the grid, one coalesced write of both observation
+// planes, ~4 dirty 16-byte chunks per env, and ~100 bytes of state/outputs per env.
+// A lone wave retires about one instruction per five cycles, so the serial section
+// between the barriers is LDS-only and ~200 instructions; everything heavier is off it.
 #include "tron_device.hpp"
 #include "../../include/tron_hip.h"
 
@@ -24,7 +35,9 @@ using namespace tron;
 
 namespace {
 
+constexpr int WAVE = 64;
 constexpr int BLOCK = 256;
+constexpr int DK = 6;            // 16-byte loads per thread in flight per batch
 
 struct StepOut {
     int8_t *done;
@@ -33,81 +46,146 @@ struct StepOut {
     unsigned long long *totals;
 };
 
-__device__ __forceinline__ int cell_index(int S, int r, int c) { return (r + 1) * S + (c + 1); }
+// Diagnostic build only (-DTRON_STAMPS): out.totals is then a stamp buffer [blocks][2][8] of
+// s_memrealtime ticks (100 MHz) for wave 0 and wave 1; never enabled in the shipped library.
+#ifdef TRON_STAMPS
+#define STAMP(slot)                                                                               \
+    do {                                                                                          \
+        if (out.totals && (tid == 0 || tid == 64))                                                \
+            out.totals[((size_t)blockIdx.x * 2 + (tid >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
 
-// ------------------------------------------------------------------ phase B --
-// One lane = one env.  g points at this env's G bytes in LDS.
-// Follows Game.next_frame + Game.step (game.py:149-277); see DESIGN.md §4 for
-// the rule list.  res.rinfo is the reset word for phase B2 (0 = no reset).
-struct LaneResult {
-    uint32_t rinfo;
-    int stepped, done, winner;
+struct __attribute__((packed, aligned(4))) U4A4 {   // 16 bytes at 4-byte alignment
+    uint32_t x, y, z, w;
 };
-__device__ inline LaneResult lane_step(const Params &P, unsigned char *g, int env, const int8_t *actions,
-                                     const float *uniforms, uint32_t flags, const StepOut &out)
+
+// ---- global access of one chunk: 16-byte ops when G % 4 == 0, bytes otherwise ----
+template <bool ALIGNED>
+__device__ __forceinline__ uint4 load_chunk(const int8_t *p)
+{
+    if (ALIGNED) {
+        const U4A4 v = *reinterpret_cast<const U4A4 *>(p);          // allocation is padded: over-read is safe
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w[j >> 2] |= (uint32_t)(uint8_t)p[j] << ((j & 3) * 8);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <bool ALIGNED>
+__device__ __forceinline__ void store_chunk(int8_t *p, int nb, const uint32_t w[4])
+{
+    if (ALIGNED) {
+        if (nb == 16) {
+            *reinterpret_cast<U4A4 *>(p) = U4A4{w[0], w[1], w[2], w[3]};
+        } else {
+            for (int j = 0; j < (nb >> 2); ++j) reinterpret_cast<uint32_t *>(p)[j] = w[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < nb) p[j] = (int8_t)(w[j >> 2] >> ((j & 3) * 8));
+    }
+}
+
+// one chunk (nb valid cells of one env starting at cell c) -> both players' observations
+template <int FMT, bool ALIGNED>
+__device__ __forceinline__ void store_chunk_obs(void *__restrict__ obs, size_t env, int G, uint32_t c, int nb,
+                                                const uint32_t w[4], float p4)
+{
+    if (FMT == TRON_OBS_CODES_I8) {
+        int8_t *o1 = reinterpret_cast<int8_t *>(obs) + env * 2u * G + c;
+        const uint32_t c1[4] = {codes4(w[0], false), codes4(w[1], false), codes4(w[2], false), codes4(w[3], false)};
+        const uint32_t c2[4] = {codes4(w[0], true), codes4(w[1], true), codes4(w[2], true), codes4(w[3], true)};
+        store_chunk<ALIGNED>(o1, nb, c1);
+        store_chunk<ALIGNED>(o1 + G, nb, c2);
+    } else if (FMT == TRON_OBS_PLANES3_F32 || FMT == TRON_OBS_PLANES4_F32) {
+        constexpr int CH = (FMT == TRON_OBS_PLANES3_F32) ? 3 : 4;
+        float *ob = reinterpret_cast<float *>(obs) + env * 2u * CH * G + c;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                float *dst = ob + (size_t)(p * CH + ch) * G;
+                const uint32_t bits = (ch < 3) ? plane_bits(ch, p != 0) : 0u;
+                if (ALIGNED) {                                       // G % 4 == 0: 16-byte aligned rows of 4 cells
+                    for (int j = 0; j < (nb >> 2); ++j)
+                        reinterpret_cast<float4 *>(dst)[j] =
+                            (ch == 3) ? make_float4(p4, p4, p4, p4)
+                                      : make_float4(plane_val(bits, w[j]), plane_val(bits, w[j] >> 8),
+                                                    plane_val(bits, w[j] >> 16), plane_val(bits, w[j] >> 24));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (j < nb) dst[j] = (ch == 3) ? p4 : plane_val(bits, w[j >> 2] >> ((j & 3) * 8));
+                }
+            }
+        }
+    }
+}
+
+// state words of one env, loaded ahead of the tile
+struct EnvRegs {
+    uint32_t pos, meta, eplen, tick;           // st4
+    uint32_t envp, episode, nstart, nenvp;     // rs4
+    uint32_t act;                              // a0 | a1 << 8 when the caller supplies actions
+    float u0, u1;                              // slide uniforms when the caller supplies them
+    double slide;
+};
+
+// result records left in LDS by the move (read by waves 1-3 and by the stream)
+enum { RES_STEPPED = 1u, RES_DONE = 2u, RES_STORE_ST = 4u, RES_RESET = 8u };
+
+// ------------------------------------------------------------------ the move --
+// One lane = one env, against its LDS copy g: Game.next_frame + Game.step (game.py:149-277).
+// LDS-only.  Leaves: rec_st (new st4), rec_out {flags | winner<<4, reward1, reward2, restart word}.
+// (A variant that pre-fetched the 2-4 target cells from HBM and ran the move in registers
+// was measured: shorter serial section, but +20 VGPRs cost a workgroup per CU and lost.)
+__device__ inline void lane_move(const Params &P, unsigned char *g, const EnvRegs &R, const int a[2], const float u[2],
+                                 uint32_t flags, uint32_t *dirty, uint32_t chunk0, uint4 &rec_st, uint4 &rec_out)
 {
     const int S = P.S, W = P.W;
-    const uint32_t pw = P.pos[env];
-    uint32_t m = P.meta[env];
-    int r[2] = {(int)(int8_t)(pw), (int)(int8_t)(pw >> 16)};
-    int c[2] = {(int)(int8_t)(pw >> 8), (int)(int8_t)(pw >> 24)};
+    uint32_t m = R.meta;
+    int r[2] = {(int)(int8_t)(R.pos), (int)(int8_t)(R.pos >> 16)};
+    int c[2] = {(int)(int8_t)(R.pos >> 8), (int)(int8_t)(R.pos >> 24)};
     bool done = (m & META_DONE) != 0;
     int winner = (int)((m >> 4) & 3u);
     float rw0 = 0.0f, rw1 = 0.0f;
-    int8_t *ggrid = P.grid + (size_t)env * P.G;
-    const bool stepped = !done;
+    uint32_t res = 0u;
+    rec_st = make_uint4(R.pos, R.meta, R.eplen, R.tick);
 
     if (!done) {
-        const uint32_t tick = P.tick[env];
-        const uint32_t eplen = P.eplen[env];
-        int a[2];
-        float u[2] = {0.0f, 0.0f};
+        res |= RES_STEPPED;
         const bool sliding = (P.mode != TRON_MODE_NONE);
-        if (!actions || (sliding && !uniforms)) {
-            uint32_t x[4];
-            philox4x32_10((uint32_t)env, tick, RNG_STEP, 0u, P.seed, P.stream, x);
-            a[0] = (int)(x[0] & 3u);
-            a[1] = (int)(x[1] & 3u);
-            u[0] = (float)(x[2] >> 8) * (1.0f / 16777216.0f);
-            u[1] = (float)(x[3] >> 8) * (1.0f / 16777216.0f);
-        }
-        if (actions) {
-            const uint16_t aw = reinterpret_cast<const uint16_t *>(actions)[env];
-            a[0] = (int)(aw & 3u);
-            a[1] = (int)((aw >> 8) & 3u);
-        }
-        if (sliding && uniforms) {
-            const float2 uu = reinterpret_cast<const float2 *>(uniforms)[env];
-            u[0] = uu.x;
-            u[1] = uu.y;
-        }
-
-        int dirty[6];
+        int cells[6];
         // game.py:155-156 — both heads turn into bodies before anyone moves
-        dirty[0] = cell_index(S, r[0], c[0]);
-        dirty[1] = cell_index(S, r[1], c[1]);
-        g[dirty[0]] = (unsigned char)TRON_P1_BODY;
-        g[dirty[1]] = (unsigned char)TRON_P2_BODY;
-        dirty[2] = dirty[0];
-        dirty[3] = dirty[1];
+        cells[0] = cell_index(S, r[0], c[0]);
+        cells[1] = cell_index(S, r[1], c[1]);
+        g[cells[0]] = (unsigned char)TRON_P1_BODY;
+        g[cells[1]] = (unsigned char)TRON_P2_BODY;
+        cells[2] = cells[0];
+        cells[3] = cells[1];
 
         // game.py:158-178 — advance (player.py:124-132), optional slide, player order
-        const uint32_t ep = P.envp[env];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int dr = (a[p] == 0) ? -1 : (a[p] == 2) ? 1 : 0;   // UP / DOWN
             const int dc = (a[p] == 1) ? 1 : (a[p] == 3) ? -1 : 0;   // RIGHT / LEFT
             int nr = r[p] + dr, nc = c[p] + dc;
             if (sliding) {
+                // the uniform is consulted only for an in-bounds EMPTY target (game.py:164-165)
                 if (nr >= 0 && nc >= 0 && nr < W && nc < W) {
                     const int idx = cell_index(S, nr, nc);
                     if (g[idx] == (unsigned char)TRON_EMPTY) {
                         const double rate = (P.mode == TRON_MODE_ICE)
-                                                ? P.slide[env]
-                                                : get_rate((int)(int8_t)(ep >> 16), (int)((ep >> (8 * p)) & 0xFFu));
+                                                ? R.slide
+                                                : get_rate((int)(int8_t)(R.envp >> 16), (int)((R.envp >> (8 * p)) & 0xFFu));
                         if ((double)u[p] <= rate) {                 // game.py:169
                             g[idx] = (unsigned char)(p == 0 ? TRON_P1_SLIDE : TRON_P2_SLIDE);
-                            dirty[2 + p] = idx;
+                            cells[2 + p] = idx;
                             nr += dr;
                             nc += dc;
                         }
@@ -118,7 +196,8 @@ __device__ inline LaneResult lane_step(const Params &P, unsigned char *g, int en
             c[p] = nc;
         }
 
-        // game.py:205-214 — collisions in player order; head written in every branch
+        // game.py:205-214 — collisions in player order; the head is written in every branch
+        // (an out-of-bounds head lands on the border WALL cell)
         uint32_t alive = m & 3u;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -127,10 +206,10 @@ __device__ inline LaneResult lane_step(const Params &P, unsigned char *g, int en
             if (oob || g[idx] != (unsigned char)TRON_EMPTY)
                 alive &= ~(1u << p);
             g[idx] = (unsigned char)(p == 0 ? TRON_P1_HEAD : TRON_P2_HEAD);
-            dirty[4 + p] = idx;
+            cells[4 + p] = idx;
         }
 
-        // game.py:264-275 — done / winner
+        // game.py:264-275 — done / winner (same cell => draw)
         const int n_alive = (int)(alive & 1u) + (int)((alive >> 1) & 1u);
         if (n_alive <= 1) {
             if (n_alive == 1 && (r[0] != r[1] || c[0] != c[1]))
@@ -140,7 +219,7 @@ __device__ inline LaneResult lane_step(const Params &P, unsigned char *g, int en
 
         // rewards: util.py:87-94 / DDQN.py:289-305 / DQN.py:224-241
         if (!done) {
-            rw0 = rw1 = P.r_index ? (float)eplen : P.r_step;
+            rw0 = rw1 = P.r_index ? (float)R.eplen : P.r_step;
         } else if (winner == 0) {
             rw0 = rw1 = P.r_draw;
         } else {
@@ -148,217 +227,211 @@ __device__ inline LaneResult lane_step(const Params &P, unsigned char *g, int en
             rw1 = (winner == 2) ? P.r_win : P.r_lose;
         }
 
-        m = alive | (done ? META_DONE : 0u) | ((uint32_t)winner << 4) | ((uint32_t)(a[0] + 1) << 8) |
-            ((uint32_t)(a[1] + 1) << 12);
-        P.tick[env] = tick + 1u;
-        P.eplen[env] = eplen + 1u;
-
-        const bool will_reset = done && (flags & TRON_STEP_AUTORESET);
-        if (!will_reset) {
-            // final values of the touched cells (order-free: duplicates store the same byte)
+        if (!(done && (flags & TRON_STEP_AUTORESET))) {
+            // the stream writes these chunks back to the grid
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
-                ggrid[dirty[k]] = (int8_t)g[dirty[k]];
-            P.pos[env] = (uint32_t)(uint8_t)r[0] | ((uint32_t)(uint8_t)c[0] << 8) |
-                         ((uint32_t)(uint8_t)r[1] << 16) | ((uint32_t)(uint8_t)c[1] << 24);
-            P.meta[env] = m;
+            for (int k = 0; k < 6; ++k) {
+                const uint32_t ci = chunk0 + (uint32_t)(cells[k] >> 4);
+                atomicOr(&dirty[ci >> 5], 1u << (ci & 31u));
+            }
         }
+        rec_st = make_uint4(pack_pos(r[0], c[0], r[1], c[1]),
+                            alive | (done ? META_DONE : 0u) | ((uint32_t)winner << 4) | ((uint32_t)(a[0] + 1) << 8) |
+                                ((uint32_t)(a[1] + 1) << 12),
+                            R.eplen + 1u, R.tick + 1u);
+        res |= RES_STORE_ST;
     }
+    if (done) res |= RES_DONE;
 
-    if (out.done) out.done[env] = (int8_t)done;
-    if (out.winner) out.winner[env] = (int8_t)winner;
-    if (out.reward) reinterpret_cast<float2 *>(out.reward)[env] = make_float2(rw0, rw1);
-
-    uint32_t rinfo = 0u;
+    uint32_t restart = 0u;
     if (done && (flags & TRON_STEP_AUTORESET)) {                    // ACKTR.py:307-310
-        const uint32_t epi = P.episode[env];
-        const NewGame ng = make_game(P, (uint32_t)env, epi);
-        P.pos[env] = (uint32_t)(uint8_t)ng.r1 | ((uint32_t)(uint8_t)ng.c1 << 8) |
-                     ((uint32_t)(uint8_t)ng.r2 << 16) | ((uint32_t)(uint8_t)ng.c2 << 24);
-        P.meta[env] = META_ALIVE0 | META_ALIVE1;
-        P.envp[env] = (uint32_t)ng.w0 | ((uint32_t)ng.w1 << 8) | ((uint32_t)(uint8_t)(int8_t)ng.degree << 16);
-        P.episode[env] = epi + 1u;
-        P.eplen[env] = 0u;
-        rinfo = 0x80000000u | (uint32_t)cell_index(S, ng.r1, ng.c1) | ((uint32_t)cell_index(S, ng.r2, ng.c2) << 14);
+        // the game being started was drawn at the previous restart (rs4.nstart / .nenvp)
+        rec_st = make_uint4(R.nstart, META_ALIVE0 | META_ALIVE1, 0u, rec_st.w);
+        res |= RES_STORE_ST | RES_RESET;
+        const int h1 = cell_index(S, (int)(int8_t)(R.nstart), (int)(int8_t)(R.nstart >> 8));
+        const int h2 = cell_index(S, (int)(int8_t)(R.nstart >> 16), (int)(int8_t)(R.nstart >> 24));
+        restart = 0x80000000u | (uint32_t)h1 | ((uint32_t)h2 << 14);
     }
-    return LaneResult{rinfo, (int)stepped, (int)done, winner};
+    rec_out = make_uint4(res | ((uint32_t)winner << 4), __float_as_uint(rw0), __float_as_uint(rw1), restart);
 }
 
 // ---------------------------------------------------------------- the kernel --
-template <int FMT, bool FAST, bool DO_STEP>
-__global__ __launch_bounds__(BLOCK) void k_step_encode(Params P, int E, const int8_t *__restrict__ actions,
-                                                       const float *__restrict__ uniforms, uint32_t flags,
-                                                       void *__restrict__ obs, StepOut out)
+template <int FMT, bool DO_STEP, bool ALIGNED>
+__global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, uint32_t cpe_magic,
+                                                const int8_t *__restrict__ actions,
+                                                const float *__restrict__ uniforms, uint32_t flags,
+                                                void *__restrict__ obs, StepOut out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int G = P.G;
-    const int tile_cap = (E * G + 15) & ~15;
-    unsigned char *tile = smem;
-    uint32_t *rinfo = reinterpret_cast<uint32_t *>(smem + tile_cap);   // [E]
-    float *plane4 = reinterpret_cast<float *>(rinfo + E);              // [E]
+    uint4 *tile = reinterpret_cast<uint4 *>(smem);                  // [E*cpe]
+    uint4 *tmpl = tile + (size_t)E * cpe;                           // [cpe] fresh board as chunks
+    uint4 *rec_st = tmpl + cpe;                                     // [64] new st4
+    uint4 *rec_out = rec_st + 64;                                   // [64] flags / rewards / restart word
+    uint4 *rec_rs = rec_out + 64;                                   // [64] new rs4 (restarted envs)
+    float *plane4 = reinterpret_cast<float *>(rec_rs + 64);         // [64]
+    uint32_t *dirty = reinterpret_cast<uint32_t *>(plane4 + 64);    // [ceil(E*cpe/32)] chunk bitmask
 
     const int tid = threadIdx.x;
     const int e0 = blockIdx.x * E;
     const int ne = min(E, P.N - e0);
-    const size_t gbase = (size_t)e0 * G;
-    const int nbytes = ne * G;
+    const int env = e0 + tid;
+    const bool mine = tid < ne;
+    const uint32_t nchunks = (uint32_t)ne * cpe;
+    const int8_t *gtile = P.grid + (size_t)e0 * G;
+    const bool sliding = (P.mode != TRON_MODE_NONE);
+    const bool autoreset = (flags & TRON_STEP_AUTORESET) != 0u;
+    const bool w0 = DO_STEP && tid < WAVE;
 
-    // ---- A: tile HBM -> LDS (the grid allocation is padded, over-read is safe)
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(P.grid + gbase);
-        uint4 *dst = reinterpret_cast<uint4 *>(tile);
-        const int nch = (nbytes + 15) >> 4;
-        for (int i = tid; i < nch; i += 4 * BLOCK) {
-            uint4 v0, v1, v2, v3;
-            const int i1 = i + BLOCK, i2 = i + 2 * BLOCK, i3 = i + 3 * BLOCK;
-            v0 = src[i];
-            if (i1 < nch) v1 = src[i1];
-            if (i2 < nch) v2 = src[i2];
-            if (i3 < nch) v3 = src[i3];
-            dst[i] = v0;
-            if (i1 < nch) dst[i1] = v1;
-            if (i2 < nch) dst[i2] = v2;
-            if (i3 < nch) dst[i3] = v3;
+    STAMP(0);
+    // ---- 1: state words first (their latency hides under the tile load), then the tile
+    EnvRegs R{};
+    if (w0 && mine) {
+        const uint4 st = P.st4[env];
+        R.pos = st.x; R.meta = st.y; R.eplen = st.z; R.tick = st.w;
+        if (autoreset || sliding) {
+            const uint4 rs = P.rs4[env];
+            R.envp = rs.x; R.episode = rs.y; R.nstart = rs.z; R.nenvp = rs.w;
+        }
+        if (actions) R.act = reinterpret_cast<const uint16_t *>(actions)[env];
+        if (sliding) {
+            if (uniforms) {
+                const float2 uu = reinterpret_cast<const float2 *>(uniforms)[env];
+                R.u0 = uu.x;
+                R.u1 = uu.y;
+            }
+            R.slide = P.slide[env];
         }
     }
-    if (FMT == TRON_OBS_PLANES4_F32 && tid < ne)
-        plane4[tid] = (float)degree_slide(P.slide[e0 + tid]);           // game.py:124-132
+    if (FMT == TRON_OBS_PLANES4_F32 && mine) plane4[tid] = (float)degree_slide(P.slide[env]);   // game.py:124-132
+    if (DO_STEP && autoreset)
+        for (uint32_t d = (uint32_t)tid; d < cpe * 16u; d += BLOCK)
+            reinterpret_cast<int8_t *>(tmpl)[d] = (d < (uint32_t)G) ? P.fresh[d] : (int8_t)0;
+
+    int a[2] = {0, 0};
+    float u[2] = {R.u0, R.u1};
+    for (uint32_t base = 0; base < nchunks; base += DK * BLOCK) {
+        uint4 v[DK];
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+            const uint32_t i = base + (uint32_t)tid + (uint32_t)k * BLOCK;
+            const uint32_t le = __umulhi(i, cpe_magic);
+            const uint32_t c = (i - le * cpe) * 16u;
+            if (i < nchunks) v[k] = load_chunk<ALIGNED>(gtile + (size_t)le * G + c);
+        }
+        if (base == 0u && w0) {
+            // the random-number work, in the shadow of the tile load (it needs the counters only)
+            for (uint32_t d = (uint32_t)tid; d < (nchunks + 31u) / 32u; d += WAVE) dirty[d] = 0u;
+            if (mine) {
+                const bool have_actions = actions != nullptr, have_uniforms = uniforms != nullptr;
+                if (!have_actions || (sliding && !have_uniforms)) {
+                    uint32_t x[4];
+                    philox4x32_10((uint32_t)env, R.tick, RNG_STEP, 0u, P.seed, P.stream, x);
+                    a[0] = (int)(x[0] & 3u);
+                    a[1] = (int)(x[1] & 3u);
+                    if (!have_uniforms) {
+                        u[0] = (float)(x[2] >> 8) * (1.0f / 16777216.0f);
+                        u[1] = (float)(x[3] >> 8) * (1.0f / 16777216.0f);
+                    }
+                }
+                if (have_actions) {
+                    a[0] = (int)(R.act & 3u);
+                    a[1] = (int)((R.act >> 8) & 3u);
+                }
+                if (autoreset) {       // speculative: stored only if this env restarts in this launch
+                    const NewGame ng = make_game(P.seed, P.stream, P.W, P.fair, (uint32_t)env, R.episode + 1u);
+                    rec_rs[tid] = make_uint4(R.nenvp, R.episode + 1u, pack_pos(ng.r1, ng.c1, ng.r2, ng.c2),
+                                             pack_envp(ng.w0, ng.w1, ng.degree));
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+            const uint32_t i = base + (uint32_t)tid + (uint32_t)k * BLOCK;
+            if (i < nchunks) tile[i] = v[k];
+        }
+    }
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
 
     if (DO_STEP) {
-        // ---- B: one env per lane (wave 0 covers E <= 64 envs)
-        if (tid < E) {
-            LaneResult lr{0u, 0, 0, 0};
-            if (tid < ne)
-                lr = lane_step(P, tile + tid * G, e0 + tid, actions, uniforms, flags, out);
-            rinfo[tid] = lr.rinfo;
-            if (out.totals) {
-                // {env_steps, p1_wins, p2_wins, draws}: one atomic per counter per workgroup
-                const int wn = (lr.stepped && lr.done) ? lr.winner : -1;
-                const unsigned long long bs = __ballot(lr.stepped != 0);
-                const unsigned long long b1 = __ballot(wn == 1), b2 = __ballot(wn == 2), b0 = __ballot(wn == 0);
-                if (tid == 0) {
-                    if (bs) atomicAdd(&out.totals[0], (unsigned long long)__popcll(bs));
-                    if (b1) atomicAdd(&out.totals[1], (unsigned long long)__popcll(b1));
-                    if (b2) atomicAdd(&out.totals[2], (unsigned long long)__popcll(b2));
-                    if (b0) atomicAdd(&out.totals[3], (unsigned long long)__popcll(b0));
-                }
-            }
+        // ---- 2: the move, wave 0, one env per lane, LDS only
+        if (w0) {
+            uint4 rs = make_uint4(0u, 0u, 0u, 0u), ro = make_uint4(0u, 0u, 0u, 0u);
+            if (mine)
+                lane_move(P, reinterpret_cast<unsigned char *>(tile + (size_t)tid * cpe), R, a, u, flags, dirty,
+                          (uint32_t)tid * cpe, rs, ro);
+            rec_st[tid] = rs;
+            rec_out[tid] = ro;
         }
+        STAMP(3);
         __syncthreads();
+        STAMP(4);
 
-        // ---- B2: fresh boards for finished envs, one wave per env
-        if (flags & TRON_STEP_AUTORESET) {
-            const int wave = tid >> 6, lane = tid & 63;
-            for (int e = wave; e < ne; e += BLOCK / 64) {
-                const uint32_t ri = rinfo[e];
-                if (!(ri >> 31)) continue;                               // wave-uniform
-                const int h1 = (int)(ri & 0x3FFFu), h2 = (int)((ri >> 14) & 0x3FFFu);
-                if (FAST) {
-                    const int D = G >> 2;
-                    const uint32_t *fresh32 = reinterpret_cast<const uint32_t *>(P.fresh);
-                    uint32_t *t32 = reinterpret_cast<uint32_t *>(tile) + e * D;
-                    uint32_t *g32 = reinterpret_cast<uint32_t *>(P.grid + gbase) + (size_t)e * D;
-                    for (int d = lane; d < D; d += 64) {
-                        uint32_t v = fresh32[d];
-                        if ((h1 >> 2) == d) v |= (uint32_t)TRON_P1_HEAD << ((h1 & 3) * 8);   // EMPTY is 0
-                        if ((h2 >> 2) == d) v |= (uint32_t)TRON_P2_HEAD << ((h2 & 3) * 8);
-                        t32[d] = v;
-                        g32[d] = v;
-                    }
-                } else {
-                    unsigned char *t8 = tile + e * G;
-                    int8_t *g8 = P.grid + gbase + (size_t)e * G;
-                    for (int i = lane; i < G; i += 64) {
-                        int8_t v = P.fresh[i];
-                        if (i == h1) v = TRON_P1_HEAD;
-                        if (i == h2) v = TRON_P2_HEAD;
-                        t8[i] = (unsigned char)v;
-                        g8[i] = v;
-                    }
-                }
+        // ---- 3a: waves 1-3 write the records out, one kind of array each (lane = env)
+        const int wave = tid >> 6, lane = tid & 63;
+        if (wave >= 1 && lane < ne) {
+            const uint4 ro = rec_out[lane];
+            const int genv = e0 + lane;
+            if (wave == 1) {
+                if (ro.x & RES_STORE_ST) P.st4[genv] = rec_st[lane];
+                if (ro.x & RES_RESET) P.rs4[genv] = rec_rs[lane];
+            } else if (wave == 2) {
+                if (out.done) out.done[genv] = (int8_t)((ro.x & RES_DONE) != 0u);
+                if (out.winner) out.winner[genv] = (int8_t)((ro.x >> 4) & 3u);
+            } else {
+                if (out.reward)
+                    reinterpret_cast<float2 *>(out.reward)[genv] = make_float2(__uint_as_float(ro.y), __uint_as_float(ro.z));
             }
-            __syncthreads();
         }
+#ifndef TRON_STAMPS
+        if (out.totals && wave == 3) {
+            // {env_steps, p1_wins, p2_wins, draws}: one atomic per counter per workgroup
+            const uint32_t f = lane < ne ? rec_out[lane].x : 0u;
+            const int wn = ((f & RES_STEPPED) && (f & RES_DONE)) ? (int)((f >> 4) & 3u) : -1;
+            const unsigned long long bs = __ballot((f & RES_STEPPED) != 0u);
+            const unsigned long long b1 = __ballot(wn == 1), b2 = __ballot(wn == 2), b0 = __ballot(wn == 0);
+            if (lane == 0) {
+                if (bs) atomicAdd(&out.totals[0], (unsigned long long)__popcll(bs));
+                if (b1) atomicAdd(&out.totals[1], (unsigned long long)__popcll(b1));
+                if (b2) atomicAdd(&out.totals[2], (unsigned long long)__popcll(b2));
+                if (b0) atomicAdd(&out.totals[3], (unsigned long long)__popcll(b0));
+            }
+        }
+#endif
     }
 
-    // ---- C: encode from the LDS tile
-    if (FMT == TRON_OBS_CODES_I8) {
-        if (FAST) {
-            const uint32_t D = (uint32_t)G >> 2;
-            const uint32_t *tile32 = reinterpret_cast<const uint32_t *>(tile);
-            const uint32_t total = (uint32_t)ne * 2u * D;                  // output dwords
-            uint32_t *o32 = reinterpret_cast<uint32_t *>(obs) + (size_t)e0 * 2u * D;
-            for (uint32_t od = (uint32_t)tid * 4u; od < total; od += 4u * BLOCK) {
-                uint32_t q = __umulhi(od, P.d_magic);                      // plane = od / D
-                uint32_t cd = od - q * D;
-                uint32_t rr[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t t = (od + j < total) ? tile32[(q >> 1) * D + cd] : 0u;
-                    rr[j] = codes4(t, (q & 1u) != 0u);
-                    if (++cd == D) { cd = 0u; ++q; }
-                }
-                if (od + 4u <= total) {
-                    *reinterpret_cast<uint4 *>(o32 + od) = make_uint4(rr[0], rr[1], rr[2], rr[3]);
-                } else {
-                    for (uint32_t j = 0; od + j < total; ++j) o32[od + j] = rr[j];
-                }
-            }
-        } else {
-            const uint32_t total = (uint32_t)ne * 2u * (uint32_t)G;        // output bytes
-            int8_t *o8 = reinterpret_cast<int8_t *>(obs) + (size_t)e0 * 2u * G;
-            for (uint32_t ob = (uint32_t)tid * 16u; ob < total; ob += 16u * BLOCK) {
-                uint32_t q = ob / (uint32_t)G, cc = ob - q * (uint32_t)G;
-                uint32_t rr[4] = {0u, 0u, 0u, 0u};
-                for (uint32_t j = 0; j < 16u && ob + j < total; ++j) {
-                    const int t = (int)(int8_t)tile[(q >> 1) * (uint32_t)G + cc];
-                    rr[j >> 2] |= (uint32_t)(uint8_t)code1(t, (q & 1u) != 0u) << ((j & 3u) * 8u);
-                    if (++cc == (uint32_t)G) { cc = 0u; ++q; }
-                }
-                if (ob + 16u <= total) {
-                    *reinterpret_cast<uint4 *>(o8 + ob) = make_uint4(rr[0], rr[1], rr[2], rr[3]);
-                } else {
-                    for (uint32_t j = 0; ob + j < total; ++j) o8[ob + j] = (int8_t)(rr[j >> 2] >> ((j & 3u) * 8u));
-                }
+    // ---- 3b: the stream
+    for (uint32_t i = (uint32_t)tid; i < nchunks; i += BLOCK) {
+        const uint32_t le = __umulhi(i, cpe_magic);
+        const uint32_t k = i - le * cpe;
+        const uint32_t c = k * 16u;
+        const int nb = min(16, G - (int)c);                               // valid cells in this chunk
+        uint4 t = tile[i];
+        bool wb = false;
+        if (DO_STEP) {
+            const uint32_t ri = rec_out[le].w;
+            if (ri >> 31) {                                                // restarted env: fresh board + heads
+                t = tmpl[k];
+                const uint32_t d1 = (ri & 0x3FFFu) - c, d2 = ((ri >> 14) & 0x3FFFu) - c;
+                const uint32_t v1 = (uint32_t)TRON_P1_HEAD << ((d1 & 3u) * 8u);   // EMPTY is 0: OR the head in
+                const uint32_t v2 = (uint32_t)TRON_P2_HEAD << ((d2 & 3u) * 8u);   // game.py:90-91
+                t.x |= (d1 < 4u ? v1 : 0u) | (d2 < 4u ? v2 : 0u);
+                t.y |= (d1 - 4u < 4u ? v1 : 0u) | (d2 - 4u < 4u ? v2 : 0u);
+                t.z |= (d1 - 8u < 4u ? v1 : 0u) | (d2 - 8u < 4u ? v2 : 0u);
+                t.w |= (d1 - 12u < 4u ? v1 : 0u) | (d2 - 12u < 4u ? v2 : 0u);
+                wb = true;
+            } else {
+                wb = ((dirty[i >> 5] >> (i & 31u)) & 1u) != 0u;
             }
         }
-    } else if (FMT == TRON_OBS_PLANES3_F32 || FMT == TRON_OBS_PLANES4_F32) {
-        constexpr uint32_t CH = (FMT == TRON_OBS_PLANES3_F32) ? 3u : 4u;
-        if (FAST) {
-            const uint32_t D = (uint32_t)G >> 2;
-            const uint32_t *tile32 = reinterpret_cast<const uint32_t *>(tile);
-            const uint32_t total = (uint32_t)ne * 2u * CH * D;             // output float4s
-            float4 *o4 = reinterpret_cast<float4 *>(obs) + (size_t)e0 * 2u * CH * D;
-            for (uint32_t i = (uint32_t)tid; i < total; i += BLOCK) {
-                const uint32_t pl = __umulhi(i, P.d_magic);                // plane = i / D
-                const uint32_t cd = i - pl * D;
-                const uint32_t q = pl / CH, ch = pl - q * CH;
-                const uint32_t e = q >> 1;
-                float4 v;
-                if (ch == 3u) {
-                    const float f = plane4[e];
-                    v = make_float4(f, f, f, f);
-                } else {
-                    const uint32_t t = tile32[e * D + cd];
-                    const uint32_t bits = plane_bits((int)ch, (q & 1u) != 0u);
-                    v = make_float4(plane_val(bits, t), plane_val(bits, t >> 8), plane_val(bits, t >> 16),
-                                    plane_val(bits, t >> 24));
-                }
-                o4[i] = v;
-            }
-        } else {
-            const uint32_t total = (uint32_t)ne * 2u * CH * (uint32_t)G;   // output floats
-            float *o = reinterpret_cast<float *>(obs) + (size_t)e0 * 2u * CH * G;
-            for (uint32_t i = (uint32_t)tid; i < total; i += BLOCK) {
-                const uint32_t pl = i / (uint32_t)G, cc = i - pl * (uint32_t)G;
-                const uint32_t q = pl / CH, ch = pl - q * CH;
-                const uint32_t e = q >> 1;
-                o[i] = (ch == 3u) ? plane4[e]
-                                  : plane_val(plane_bits((int)ch, (q & 1u) != 0u), (uint32_t)tile[e * (uint32_t)G + cc]);
-            }
-        }
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+        if (wb) store_chunk<ALIGNED>(P.grid + (size_t)(e0 + le) * G + c, nb, w);
+        store_chunk_obs<FMT, ALIGNED>(obs, (size_t)(e0 + le), G, c, nb, w,
+                                      (FMT == TRON_OBS_PLANES4_F32) ? plane4[le] : 0.0f);
     }
+    STAMP(7);
 }
 
 // ------------------------------------------------------------- small kernels --
@@ -371,7 +444,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(Params P, const int8_t *__restr
     const int lane = threadIdx.x & 63;
     if (env >= P.N) return;
     if (mask && !mask[env]) return;
-    const uint32_t epi = P.episode[env];
+    const uint32_t epi = P.rs4[env].y;
     NewGame ng;
     if (start) {
         ng.r1 = start[4 * env]; ng.c1 = start[4 * env + 1]; ng.r2 = start[4 * env + 2]; ng.c2 = start[4 * env + 3];
@@ -381,7 +454,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(Params P, const int8_t *__restr
         ng.w1 = randint_u32(x[1], 40, 101);
         ng.degree = randint_u32(x[2], -30, 30);                          // game.py:87
     } else {
-        ng = make_game(P, (uint32_t)env, epi);
+        ng = make_game(P.seed, P.stream, P.W, P.fair, (uint32_t)env, epi);
     }
     if (weight) { ng.w0 = weight[2 * env]; ng.w1 = weight[2 * env + 1]; }
     if (degree) ng.degree = degree[env];
@@ -394,13 +467,11 @@ __global__ __launch_bounds__(BLOCK) void k_reset(Params P, const int8_t *__restr
         g[i] = v;
     }
     if (lane == 0) {
-        P.pos[env] = (uint32_t)(uint8_t)ng.r1 | ((uint32_t)(uint8_t)ng.c1 << 8) | ((uint32_t)(uint8_t)ng.r2 << 16) |
-                     ((uint32_t)(uint8_t)ng.c2 << 24);
-        P.meta[env] = META_ALIVE0 | META_ALIVE1;
-        P.envp[env] = (uint32_t)(uint8_t)ng.w0 | ((uint32_t)(uint8_t)ng.w1 << 8) |
-                      ((uint32_t)(uint8_t)(int8_t)ng.degree << 16);
-        P.episode[env] = epi + 1u;
-        P.eplen[env] = 0u;
+        const uint32_t tick = P.st4[env].w;
+        P.st4[env] = make_uint4(pack_pos(ng.r1, ng.c1, ng.r2, ng.c2), META_ALIVE0 | META_ALIVE1, 0u, tick);
+        const NewGame nx = make_game(P.seed, P.stream, P.W, P.fair, (uint32_t)env, epi + 1u);   // the next autoreset's game
+        P.rs4[env] = make_uint4(pack_envp(ng.w0, ng.w1, ng.degree), epi + 1u, pack_pos(nx.r1, nx.c1, nx.r2, nx.c2),
+                                pack_envp(nx.w0, nx.w1, nx.degree));
     }
 }
 
@@ -432,7 +503,8 @@ __global__ void k_get_state(Params P, int8_t *pos, int8_t *alive, int8_t *dir, i
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.N) return;
-    const uint32_t pw = P.pos[i], m = P.meta[i], ep = P.envp[i];
+    const uint4 st = P.st4[i], rs = P.rs4[i];
+    const uint32_t pw = st.x, m = st.y, ep = rs.x;
     if (pos) reinterpret_cast<uint32_t *>(pos)[i] = pw;
     if (alive) { alive[2 * i] = (int8_t)(m & 1u); alive[2 * i + 1] = (int8_t)((m >> 1) & 1u); }
     if (dir) { dir[2 * i] = (int8_t)((m >> 8) & 7u); dir[2 * i + 1] = (int8_t)((m >> 12) & 7u); }
@@ -441,7 +513,7 @@ __global__ void k_get_state(Params P, int8_t *pos, int8_t *alive, int8_t *dir, i
     if (weight) { weight[2 * i] = (int16_t)(ep & 0xFFu); weight[2 * i + 1] = (int16_t)((ep >> 8) & 0xFFu); }
     if (degree) degree[i] = (int16_t)(int8_t)(ep >> 16);
     if (slide) slide[i] = P.slide[i];
-    if (counters) { counters[3 * i] = P.tick[i]; counters[3 * i + 1] = P.episode[i]; counters[3 * i + 2] = P.eplen[i]; }
+    if (counters) { counters[3 * i] = st.w; counters[3 * i + 1] = rs.y; counters[3 * i + 2] = st.z; }
 }
 
 // Map.state_for_player on arbitrary tile images (map.py:67-84)
@@ -480,10 +552,11 @@ __global__ void k_pop_up(const int8_t *__restrict__ codes, size_t n, int cells, 
 struct tron_env {
     Params P;
     int device;
-    int E;          // envs per workgroup tile
-    size_t smem;    // dynamic LDS bytes
-    bool fast;      // G % 4 == 0
-    void *blob;     // one allocation behind all state arrays
+    int E;                    // envs per workgroup tile
+    uint32_t cpe, cpe_magic;  // 16-byte chunks per env, ceil(2^32 / cpe)
+    size_t smem;              // dynamic LDS bytes
+    bool aligned;             // G % 4 == 0: 16-byte global accesses
+    void *blob;               // one allocation behind all state arrays
 };
 
 namespace {
@@ -495,11 +568,11 @@ inline int launch_status()
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
-template <int FMT, bool FAST, bool DO_STEP>
+template <int FMT, bool DO_STEP, bool ALIGNED>
 int launch_one(tron_env *h, const int8_t *actions, const float *uniforms, uint32_t flags, void *obs, StepOut out,
                hipStream_t st)
 {
-    auto kern = k_step_encode<FMT, FAST, DO_STEP>;
+    auto kern = k_tile<FMT, DO_STEP, ALIGNED>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -508,7 +581,8 @@ int launch_one(tron_env *h, const int8_t *actions, const float *uniforms, uint32
         attr_done = true;
     }
     const int blocks = (h->P.N + h->E - 1) / h->E;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), h->smem, st, h->P, h->E, actions, uniforms, flags, obs, out);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), h->smem, st, h->P, h->E, h->cpe, h->cpe_magic, actions,
+                       uniforms, flags, obs, out);
     return launch_status();
 }
 
@@ -518,8 +592,8 @@ int launch_fmt(tron_env *h, int fmt, const int8_t *a, const float *u, uint32_t f
 {
 #define TRON_CASE(F)                                                                          \
     case F:                                                                                   \
-        return h->fast ? launch_one<F, true, DO_STEP>(h, a, u, flags, obs, out, st)           \
-                       : launch_one<F, false, DO_STEP>(h, a, u, flags, obs, out, st);
+        return h->aligned ? launch_one<F, DO_STEP, true>(h, a, u, flags, obs, out, st)        \
+                          : launch_one<F, DO_STEP, false>(h, a, u, flags, obs, out, st);
     switch (fmt) {
         TRON_CASE(TRON_OBS_NONE)
         TRON_CASE(TRON_OBS_CODES_I8)
@@ -573,25 +647,25 @@ int tron_create(int32_t n_envs, int32_t W, int32_t mode, int32_t fair, uint32_t 
     P.seed = seed; P.stream = rng_stream;
     P.r_step = -1.0f; P.r_win = 100.0f; P.r_lose = -100.0f; P.r_draw = 0.0f; P.r_index = 0;   // DDQN.py:289-305
     h->device = dev;
-    h->fast = (P.G % 4) == 0;
-    const uint32_t D = h->fast ? (uint32_t)P.G / 4u : (uint32_t)P.G;
-    P.d_magic = (uint32_t)((0x100000000ull + D - 1) / D);
+    h->aligned = (P.G % 4) == 0;
+    h->cpe = ((uint32_t)P.G + 15u) / 16u;
+    h->cpe_magic = (uint32_t)((0x100000000ull + h->cpe - 1) / h->cpe);   // exact i / cpe for i < 2^32 / cpe
 
-    // tile size: E % 16 == 0 keeps every tile span 16-byte aligned for any G
-    int E = (64 * P.G <= 48 * 1024) ? 64 : (32 * P.G <= 64 * 1024) ? 32 : 16;
+    // tile size: keep the LDS tile near 24 KB so ~6 workgroups share a CU
+    int E = (int)((24u * 1024u) / (h->cpe * 16u));
+    E = E >= 64 ? 64 : E >= 32 ? 32 : E >= 16 ? 16 : E >= 8 ? 8 : 4;
     if (const char *s = getenv("TRON_TILE_ENVS")) {
         const int v = atoi(s);
-        if ((v == 16 || v == 32 || v == 64) && (size_t)v * P.G + 8u * v + 16 <= 160u * 1024) E = v;
+        if (v >= 1 && v <= 64 && ((size_t)v + 1u) * h->cpe * 16u + 8192u <= 160u * 1024u) E = v;
     }
     h->E = E;
-    h->smem = (((size_t)E * P.G + 15) & ~(size_t)15) + 8u * (size_t)E;
+    h->smem = ((size_t)E + 1u) * h->cpe * 16u + 3u * 64u * 16u + 64u * 4u + 4u * (((size_t)E * h->cpe + 31u) / 32u + 1u);
 
-    // one blob: grid (padded for 16-byte over-read) + SoA words + fresh template
+    // one blob: grid (padded for 16-byte over-read) + state words + fresh template
     const size_t N = (size_t)n_envs;
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_grid = 0, o_pos = align(o_grid + N * P.G + 64), o_meta = align(o_pos + 4 * N),
-                 o_envp = align(o_meta + 4 * N), o_slide = align(o_envp + 4 * N), o_tick = align(o_slide + 8 * N),
-                 o_epi = align(o_tick + 4 * N), o_len = align(o_epi + 4 * N), o_fresh = align(o_len + 4 * N),
+    const size_t o_grid = 0, o_st4 = align(o_grid + N * P.G + 64), o_rs4 = align(o_st4 + 16 * N),
+                 o_slide = align(o_rs4 + 16 * N), o_fresh = align(o_slide + 8 * N),
                  total = align(o_fresh + (size_t)P.G + 16);
     char *blob = nullptr;
     if (hipMalloc(reinterpret_cast<void **>(&blob), total) != hipSuccess) {
@@ -601,13 +675,9 @@ int tron_create(int32_t n_envs, int32_t W, int32_t mode, int32_t fair, uint32_t 
     }
     h->blob = blob;
     P.grid = reinterpret_cast<int8_t *>(blob + o_grid);
-    P.pos = reinterpret_cast<uint32_t *>(blob + o_pos);
-    P.meta = reinterpret_cast<uint32_t *>(blob + o_meta);
-    P.envp = reinterpret_cast<uint32_t *>(blob + o_envp);
+    P.st4 = reinterpret_cast<uint4 *>(blob + o_st4);
+    P.rs4 = reinterpret_cast<uint4 *>(blob + o_rs4);
     P.slide = reinterpret_cast<double *>(blob + o_slide);
-    P.tick = reinterpret_cast<uint32_t *>(blob + o_tick);
-    P.episode = reinterpret_cast<uint32_t *>(blob + o_epi);
-    P.eplen = reinterpret_cast<uint32_t *>(blob + o_len);
     P.fresh = reinterpret_cast<const int8_t *>(blob + o_fresh);
     if (hipMemsetAsync(blob, 0, total, nullptr) != hipSuccess) { (void)hipGetLastError(); }
     hipLaunchKernelGGL(k_fresh, dim3((P.G + 255) / 256), dim3(256), 0, nullptr, const_cast<int8_t *>(P.fresh), P.S);

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libtron_hip.so")
+LIB_PATH = os.environ.get("TRON_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libtron_hip.so")
 
 OK = 0
 MODE = {None: 0, "none": 0, "ice": 1, "temper": 2}                 # tron/game.py:86,163
