@@ -1,0 +1,230 @@
+"""Double-DQN learner — the reference's DDQN.py (Agent :34-165, ReplayBuffer :167-203,
+train :206-346) with the replay memory resident in HBM and a batched trainer on VecTron.
+
+Two ways in:
+  * drop-in: `Agent()`, `.action(obs)`, `.step(s, a, r, s2, done)`, `.learn`, `.soft_update`,
+    `ReplayBuffer(action_size, buffer_size, batch_size)` with the reference's signatures;
+  * batched: `train(n_envs=..., width=...)` — N self-play envs stepped by one kernel launch,
+    2N transitions pushed per step, learn steps sampled from the device ring, gradients
+    all-reduced over RCCL when launched with torch.distributed.run (one rank per GPU).
+"""
+import os
+import random
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from config import *            # noqa: F401,F403
+from config import BATCH_SIZE, GAMMA, MAP_WIDTH
+from Net.DQNNet import Net
+
+# DDQN.py:18-31
+EPSILON_START = 1
+ESPILON_END = 0.003
+DECAY_RATE = 0.999
+TAU = 0.001
+MEM_CAPACITY = int(1e5)
+UPDATE_EVERY = 4
+GAME_CYCLE = 20
+DISPLAY_CYCLE = GAME_CYCLE
+folderName = 'survivor'
+
+
+def planes_to_codes(planes):
+    """pop_up planes [n, >=3, S, S] (wall, my, enemy) -> int8 observation codes [n, S, S]
+    (inverse of util.pop_up, util.py:18-27): how float states handed to the drop-in
+    ReplayBuffer.add are packed for the int8 ring."""
+    wall, my, en = planes[:, 0], planes[:, 1], planes[:, 2]
+    codes = torch.ones_like(wall, dtype=torch.int8)
+    codes = torch.where(wall > 0.5, torch.full_like(codes, -1), codes)
+    codes = torch.where(my > 5, torch.full_like(codes, 10), torch.where(my > 0.5, torch.full_like(codes, -2), codes))
+    codes = torch.where(en > 5, torch.full_like(codes, -10), torch.where(en > 0.5, torch.full_like(codes, -3), codes))
+    return codes
+
+
+class ReplayBuffer:
+    """DDQN.ReplayBuffer (DDQN.py:167-203) on a device ring (tron.vec.DeviceReplay)."""
+
+    def __init__(self, action_size, buffer_size, batch_size, width=MAP_WIDTH, channels=4, plane4=0.0, seed=None,
+                 rank=0):
+        from tron.vec import DeviceReplay
+        self.action_size = action_size
+        self.batch_size = batch_size
+        self.channels = channels
+        self.plane4 = plane4
+        self.side = width + 2
+        self.memory = DeviceReplay(buffer_size, self.side * self.side,
+                                   seed=random.getrandbits(32) if seed is None else seed, rank=rank)
+
+    def add(self, state, action, reward, next_state, done):
+        """One transition in the reference's types: float plane tensors (1,C,S,S), int, number, bool."""
+        dev = self.memory.device
+        s = planes_to_codes(torch.as_tensor(state, device=dev).reshape(1, -1, self.side, self.side))
+        s2 = planes_to_codes(torch.as_tensor(next_state, device=dev).reshape(1, -1, self.side, self.side))
+        self.memory.add(s, torch.tensor([int(action)], dtype=torch.int8, device=dev),
+                        torch.tensor([float(reward)], dtype=torch.float32, device=dev), s2,
+                        torch.tensor([int(bool(done))], dtype=torch.int8, device=dev))
+
+    def add_batch(self, codes, actions, rewards, next_codes, dones):
+        self.memory.add(codes, actions, rewards, next_codes, dones)
+
+    def sample(self):                              # DDQN.py:191-200
+        return self.memory.sample(self.batch_size, self.channels, self.plane4, side=self.side)
+
+    def __len__(self):
+        return len(self.memory)
+
+
+def average_gradients(model, group=None):
+    """One flattened RCCL all-reduce of the whole gradient per learn step (2.0 MB at 12x12:
+    latency-bound on xGMI, so a single bucket).  No-op without torch.distributed."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+class Agent():
+    def __init__(self, width=MAP_WIDTH, in_channels=4, device=None, buffer_size=MEM_CAPACITY, batch_size=BATCH_SIZE,
+                 seed=None, rank=0, make_memory=True):
+        self.device = torch.device(device if device is not None else ('cuda' if torch.cuda.is_available() else 'cpu'))
+        self.qnetwork_local = Net(in_channels, width).to(self.device)            # DDQN.py:45-46
+        self.qnetwork_target = Net(in_channels, width).to(self.device)
+        self.action_size = 4
+        self.steps = 0
+        self.optimizer = optim.Adam(self.qnetwork_local.parameters())            # DDQN.py:52
+        self.epsilon = 0
+        self.totalloss = 0
+        self.batch_size = batch_size
+        self.memory = (ReplayBuffer(4, buffer_size, batch_size, width, in_channels, seed=seed, rank=rank)
+                       if make_memory else None)
+        self.t_step = 0
+        for name, net in (('local_ai.bak', self.qnetwork_local), ('target_ai.bak', self.qnetwork_target)):
+            path = 'ais/' + folderName + '/' + name                              # DDQN.py:61-64
+            if os.path.isfile(path):
+                net.load_state_dict(torch.load(path, map_location=self.device, weights_only=True))
+
+    def get_loss(self):                            # DDQN.py:66-71
+        out_loss = self.totalloss / max(self.steps, 1)
+        self.totalloss = 0
+        self.steps = 0
+        return out_loss
+
+    def step(self, state, action, reward, next_step, done):                      # DDQN.py:73-88
+        self.memory.add(state, action, reward, next_step, done)
+        self.t_step = (self.t_step + 1) % UPDATE_EVERY
+        if self.t_step == 0 and len(self.memory) > self.batch_size:
+            self.steps += 1
+            self.learn(self.memory.sample(), GAMMA)
+
+    def action(self, game_map):                    # DDQN.py:90-110
+        self.qnetwork_local.eval()
+        with torch.no_grad():
+            action_values = self.qnetwork_local(game_map.to(self.device))
+        self.qnetwork_local.train()
+        if random.random() > self.epsilon:
+            return int(np.argmax(action_values.cpu().data.numpy()))
+        return int(random.choice(np.arange(self.action_size)))
+
+    def act_batch(self, obs, epsilon):
+        """Batched epsilon-greedy on the device: obs [B,C,S,S] -> int8 actions [B]."""
+        self.qnetwork_local.eval()
+        with torch.no_grad():
+            greedy = self.qnetwork_local(obs).argmax(1)
+        self.qnetwork_local.train()
+        rnd = torch.randint(0, self.action_size, greedy.shape, device=greedy.device)
+        explore = torch.rand(greedy.shape, device=greedy.device) <= epsilon
+        return torch.where(explore, rnd, greedy).to(torch.int8)
+
+    def targets(self, rewards, next_state, dones, gamma):
+        """Double-DQN labels (DDQN.py:129-142): a* = argmax Q_local(s'), y = r + g Q_target(s', a*)(1-done)."""
+        self.qnetwork_local.eval()
+        with torch.no_grad():
+            actions_q_local = self.qnetwork_local(next_state).detach().max(1)[1].unsqueeze(1).long()
+            labels_next = self.qnetwork_target(next_state).gather(1, actions_q_local)
+        self.qnetwork_local.train()
+        return rewards + (gamma * labels_next * (1 - dones))
+
+    def learn(self, experiences, gamma):           # DDQN.py:115-151
+        states, actions, rewards, next_state, dones = experiences
+        criterion = torch.nn.MSELoss()
+        self.qnetwork_local.train()
+        self.qnetwork_target.eval()
+        predicted_targets = self.qnetwork_local(states).gather(1, actions)
+        labels = self.targets(rewards, next_state, dones, gamma)
+        loss = criterion(predicted_targets, labels)
+        self.totalloss += loss.detach()
+        self.optimizer.zero_grad()
+        loss.backward()
+        average_gradients(self.qnetwork_local)     # RCCL over xGMI when run one-rank-per-GPU
+        self.optimizer.step()
+        self.soft_update(self.qnetwork_local, self.qnetwork_target, TAU)
+        return loss.detach()
+
+    def soft_update(self, local_model, target_model, tau):                       # DDQN.py:153-165
+        with torch.no_grad():
+            for target_param, local_param in zip(target_model.parameters(), local_model.parameters()):
+                target_param.data.copy_(tau * local_param.data + (1 - tau) * target_param.data)
+
+
+def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BATCH_SIZE, capacity=1 << 20,
+          in_channels=3, seed=0x5EED, log_every=50, save_path=None):
+    """Batched self-play DDQN: the loop of DDQN.py:225-346 with N envs per launch.
+    Honours the reference's cadence as defaults (App. A #12): one learn step per 2 env-steps
+    (UPDATE_EVERY=4 counted in per-player `brain.step` calls), epsilon x0.999 per 20 finished
+    games, target net saved.  Returns a dict of counters."""
+    import time
+    import torch.distributed as dist
+    from tron.vec import VecTron, pop_up_planes
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    torch.manual_seed(seed)                        # same initial weights on every rank
+    brain = Agent(width, in_channels, buffer_size=capacity, batch_size=batch_size, seed=seed, rank=rank,
+                  make_memory=True)
+    env = VecTron(n_envs, width, mode=None, seed=seed, rank=rank, obs_format="codes", reward="ddqn")
+    S = width + 2
+    codes = env.reset().reshape(2 * n_envs, S, S).clone()
+    epsilon, games, learn_steps, transitions = float(EPSILON_START), 0, 0, 0
+    t0 = time.perf_counter()
+    for it in range(steps):
+        planes = pop_up_planes(codes)                                             # [2N,3,S,S] for the CNN
+        actions = brain.act_batch(planes, epsilon).reshape(n_envs, 2)
+        obs, reward, done, _ = env.step(actions, autoreset=True)
+        next_codes = obs.reshape(2 * n_envs, S, S)
+        brain.memory.add_batch(codes, actions.reshape(-1), reward.reshape(-1), next_codes,
+                               done.repeat_interleave(2))
+        transitions += 2 * n_envs
+        codes = next_codes.clone()
+        finished = int(done.sum())
+        games += finished
+        if it % learn_every == learn_every - 1 and len(brain.memory) > batch_size:
+            brain.steps += 1
+            brain.learn(brain.memory.sample(), GAMMA)
+            learn_steps += 1
+        for _ in range(games // GAME_CYCLE - (games - finished) // GAME_CYCLE):   # DDQN.py:313-315
+            if epsilon * DECAY_RATE > ESPILON_END:
+                epsilon *= DECAY_RATE
+        if log_every and rank == 0 and it % log_every == log_every - 1:
+            print(f"step {it + 1}: games {games} eps {epsilon:.4f} loss {float(brain.get_loss()):.4f}", flush=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if save_path and rank == 0:
+        torch.save(brain.qnetwork_target.state_dict(), save_path)                 # DDQN.py:326 saves the TARGET net
+    return dict(env_steps=n_envs * steps * world, transitions_pushed=transitions * world,
+                transitions_learned=learn_steps * batch_size * world, learn_steps=learn_steps, games=games * world,
+                seconds=dt, env_steps_per_s=n_envs * steps * world / dt,
+                learned_transitions_per_s=learn_steps * batch_size * world / dt, brain=brain)
+
+
+if __name__ == "__main__":
+    out = train()
+    print({k: v for k, v in out.items() if k != "brain"})

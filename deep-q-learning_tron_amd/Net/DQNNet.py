@@ -1,0 +1,65 @@
+"""The reference's DQN network (Net/DQNNet.py:6-66) on PyTorch-ROCm, with its two defects
+fixed: `mish` is defined here, and the input channel count and the
+board side are parameters, so fc1 is sized from the grid instead of hard-wired to 64*3*3.
+Parameter names/shapes are the reference's (22 tensors, 501 924 parameters at 4 channels,
+12x12), so `torch.save(state_dict)` .bak files interchange.
+
+The convolutions stay on MIOpen/rocBLAS: at 12x12..26x26 they are memory/launch bound, not
+MFMA bound (BASELINE.json north_star)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from config import MAP_WIDTH
+
+
+def conv7_side(side):
+    """Spatial side after avgpool(k3,s2,p1) then conv7(k7,s2,p3) (DQNNet.py:20,22)."""
+    pooled = (side + 2 - 3) // 2 + 1
+    return (pooled + 6 - 7) // 2 + 1
+
+
+class Net(nn.Module):
+    def __init__(self, in_channels=4, width=MAP_WIDTH):
+        super(Net, self).__init__()
+        self.in_channels = in_channels
+        self.side = width + 2
+        self.conv1 = nn.Conv2d(in_channels, 32, 3, padding=1)        # DQNNet.py:10
+        self.conv2 = nn.Conv2d(32, 32, 3, padding=1)
+        self.conv3 = nn.Conv2d(32, 32, 3, padding=1)
+        self.conv4 = nn.Conv2d(32, 64, 3, padding=1)
+        self.conv5 = nn.Conv2d(64, 64, 3, padding=1)
+        self.conv6 = nn.Conv2d(64, 64, 3, padding=1)
+        self.pool = nn.AvgPool2d(kernel_size=3, padding=1, stride=2)
+        self.conv7 = nn.Conv2d(64, 64, 7, padding=3, stride=2)
+        self.flat = 64 * conv7_side(self.side) ** 2                   # 576 at 12x12 (DQNNet.py:24,55)
+        self.fc1 = nn.Linear(self.flat, 256)
+        self.fc2 = nn.Linear(256, 128)
+        self.actor1 = nn.Linear(128, 64)
+        self.actor2 = nn.Linear(64, 4)
+        self.dropout = nn.Dropout(p=0.2)
+        self.activation = self.mish
+
+    @staticmethod
+    def mish(x):                                  # ACNet.py:56-57: x * tanh(softplus(x))
+        return x * torch.tanh(F.softplus(x))
+
+    def forward(self, x):                         # DQNNet.py:33-63
+        x = x.to(self.conv1.weight.device)
+        x = self.activation(self.conv1(x))
+        idx = x
+        x = self.activation(self.conv2(x))
+        x = self.activation(self.conv3(x) + idx)
+        x = self.activation(self.conv4(x))
+        idx = x
+        x = self.activation(self.conv5(x))
+        x = self.activation(self.conv6(x) + idx)
+        x = self.pool(x)
+        x = self.activation(self.conv7(x))
+        x = x.reshape(-1, self.flat)
+        x = self.dropout(self.activation(self.fc1(x)))
+        x = self.dropout(self.activation(self.fc2(x)))
+        return self.actor2(self.activation(self.actor1(x)))
+
+    def act(self, x, env_prob=None):              # DQNNet.py:64-66 (env_prob accepted for Game.main_loop)
+        return torch.argmax(self(x), dim=1)

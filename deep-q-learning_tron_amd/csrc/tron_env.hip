@@ -489,6 +489,16 @@ __global__ void k_fill_f64(double *dst, double v, const double *src, int n)
     if (i < n) dst[i] = src ? src[i] : v;
 }
 
+__global__ void k_set_wd(Params P, const int16_t *weight, const int16_t *degree)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.N) return;
+    uint32_t ep = P.rs4[i].x;
+    if (weight) ep = (ep & 0xFFFF0000u) | (uint32_t)(uint8_t)weight[2 * i] | ((uint32_t)(uint8_t)weight[2 * i + 1] << 8);
+    if (degree) ep = (ep & 0xFF00FFFFu) | ((uint32_t)(uint8_t)(int8_t)degree[i] << 16);
+    P.rs4[i].x = ep;
+}
+
 __global__ void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16, const int8_t *src8,
                          int8_t *dst8, size_t nbytes)
 {
@@ -723,6 +733,13 @@ int tron_set_slide(tron_handle h, double slide, const double *slide_dev, void *s
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
     hipLaunchKernelGGL(k_fill_f64, dim3((h->P.N + 255) / 256), dim3(256), 0, S_(stream), h->P.slide, slide, slide_dev,
                        h->P.N);
+    return launch_status();
+}
+
+int tron_set_weight_degree(tron_handle h, const int16_t *weight, const int16_t *degree, void *stream)
+{
+    if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_set_wd, dim3((h->P.N + 255) / 256), dim3(256), 0, S_(stream), h->P, weight, degree);
     return launch_status();
 }
 

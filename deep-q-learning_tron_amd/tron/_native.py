@@ -27,6 +27,7 @@ SIGNATURES = {
     "tron_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "tron_set_reward": (C.c_int, [_vp, _f32, _f32, _f32, _f32, _i32]),
     "tron_set_slide": (C.c_int, [_vp, _f64, _vp, _vp]),
+    "tron_set_weight_degree": (C.c_int, [_vp, _vp, _vp, _vp]),
     "tron_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "tron_step_encode": (C.c_int, [_vp, _vp, _vp, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "tron_step": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),

@@ -1,0 +1,42 @@
+"""Env helpers — same surface as the reference's tron/util.py: pop_up, prob_map, make_game,
+get_reward (util.py:11-94).  pop_up runs on the GPU (tron_pop_up); make_game draws its start
+positions on the device with the reference's rule (P1-only redraw on a clash, "fair" window)."""
+import numpy as np
+import torch
+
+from config import *          # noqa: F401,F403  (the reference star-imports config here too)
+from .game import *           # noqa: F401,F403
+from .game import Game, PositionPlayer
+from .player import ACPlayer, KeyboardPlayer  # noqa: F401
+from .vec import pop_up_planes
+
+
+def pop_up(map):
+    """(S, S) observation codes -> (3, S, S) float64 planes (wall, my, enemy); heads carry 10
+    (util.py:11-37)."""
+    codes = torch.as_tensor(np.ascontiguousarray(map)).to(torch.int8).cuda()
+    return pop_up_planes(codes[None])[0].cpu().numpy().astype(np.float64)
+
+
+def prob_map(x, width=None, height=None):         # util.py:38-45; size defaults to config like the reference
+    import config
+    return np.full(((width or config.MAP_WIDTH) + 2, (height or config.MAP_HEIGHT) + 2), float(x))
+
+
+def make_game(p1, p2, mode=None, gamemode=None, slide_pram=None, width=None):
+    """util.py:46-84.  p1/p2 False selected the Minimax opponent in the reference — out of scope."""
+    import config
+    if not (p1 and p2):
+        raise NotImplementedError("MinimaxPlayer opponents are out of scope (SURVEY.md §2); pass p1=p2=True")
+    w = width or config.MAP_WIDTH
+    pps = [PositionPlayer(1, ACPlayer(), [0, 0]), PositionPlayer(2, ACPlayer(), [0, 0])]
+    return Game(w, w, pps, gamemode, slide_pram, _fair_start=(mode == "fair"))
+
+
+def get_reward(game, constants):                  # util.py:87-94
+    if game.winner is None:
+        return 0, 0
+    elif game.winner == 1:
+        return constants[0], constants[1]
+    else:
+        return constants[1], constants[0]

@@ -88,6 +88,14 @@ class VecTron:
             else:
                 nat.check(self._lib.tron_set_slide(self._h, float(slide), None, nat.stream_ptr()), "tron_set_slide")
 
+    def set_weight_degree(self, weight=None, degree=None):
+        """Assign Game.weight / Game.degree (game.py:83,87): int16 [N,2] / [N]."""
+        w = self._dev_arg(weight, torch.int16, (self.N, 2))
+        d = self._dev_arg(degree, torch.int16, (self.N,))
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_set_weight_degree(self._h, nat.ptr(w), nat.ptr(d), nat.stream_ptr()),
+                      "tron_set_weight_degree")
+
     # -- reset / step / encode --------------------------------------------
     def reset(self, mask=None, start_pos=None, weight=None, degree=None):
         """make_game for the masked envs (all when mask is None); returns the observation."""

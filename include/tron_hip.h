@@ -78,6 +78,10 @@ int tron_set_reward(tron_handle h, float step, float win, float lose, float draw
  * sweeps it); NULL => broadcast `slide`.                                     */
 int tron_set_slide(tron_handle h, double slide, const double *slide_dev, void *stream);
 
+/* Assign Game.weight / Game.degree (game.py:83,87) of the envs after construction, as user
+ * code may (`game.weight = [...]`).  weight int16[N][2] / degree int16[N]; either may be NULL. */
+int tron_set_weight_degree(tron_handle h, const int16_t *weight, const int16_t *degree, void *stream);
+
 /* --- reset -------------------------------------------------------------------
  * Replaces: util.make_game (util.py:46-84) + Game.__init__ (game.py:71-91).
  * env_mask  int8[N] or NULL (= all): which envs to (re)start.

@@ -342,7 +342,72 @@ def gen_reward():
     print("reward: done")
 
 
+# --------------------------------------------------------------------------
+# G-net: Q-values of the reference DQNNet.Net and one full DDQN Agent.learn() step
+# --------------------------------------------------------------------------
+def gen_net():
+    import collections
+    import json
+    import torch
+    sys.path.insert(0, OUT)
+    from netgen import det_state_dict
+    # torch.utils.tensorboard is imported by DDQN.py only for logging; tensorboard is absent here
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = type("SummaryWriter", (), {"__init__": lambda self, *a, **k: None,
+                                                  "add_scalar": lambda self, *a, **k: None})
+    sys.modules["torch.utils.tensorboard"] = tb
+    import Net.DQNNet as RD
+    import Net.ACNet as RA
+    RD.Net.mish = RA.Net.mish                 # DQNNet.Net never defines mish (DQNNet.py:31)
+    import DDQN as RDD
+
+    torch.manual_seed(0)
+    net = RD.Net()
+    shapes = collections.OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    net.load_state_dict(det_state_dict(shapes, salt=0))
+    net.eval()
+    enc = np.load(os.path.join(OUT, "encode.npz"))
+    planes = enc["planes_10"].astype(np.float32)                  # [32, 2, 3, 12, 12]
+    x3 = planes[:8, 0]
+    x = np.concatenate([x3, np.full((8, 1, 12, 12), 5.0, np.float32)], axis=1)    # + prob_map plane (slide .15)
+    with torch.no_grad():
+        q = net(torch.from_numpy(x)).numpy()
+
+    # one real Agent.learn() with dropout switched off (p = 0) so train mode is deterministic
+    agent = RDD.Agent()
+    agent.qnetwork_local.load_state_dict(det_state_dict(shapes, salt=1))
+    agent.qnetwork_target.load_state_dict(det_state_dict(shapes, salt=2))
+    agent.qnetwork_local.dropout.p = 0.0
+    agent.qnetwork_target.dropout.p = 0.0
+    B = 16
+    s = np.concatenate([planes[:B, 0], np.full((B, 1, 12, 12), 5.0, np.float32)], axis=1)
+    s2 = np.concatenate([planes[B:2 * B, 1], np.full((B, 1, 12, 12), 5.0, np.float32)], axis=1)
+    rs = np.random.RandomState(3)
+    a = rs.randint(0, 4, size=(B, 1)).astype(np.int64)
+    r = rs.choice([-1.0, 100.0, -100.0, 0.0], size=(B, 1)).astype(np.float32)
+    d = (rs.rand(B, 1) < 0.3).astype(np.float32)
+    exp = tuple(torch.from_numpy(t) for t in (s, a, r, s2, d))
+    with torch.no_grad():
+        q_local_before = agent.qnetwork_local.eval()(exp[0]).numpy()
+    agent.learn(exp, RDD.GAMMA)
+    loss = float(agent.totalloss)
+    after_local = {k: v.detach().numpy().copy() for k, v in agent.qnetwork_local.state_dict().items()}
+    after_target = {k: v.detach().numpy().copy() for k, v in agent.qnetwork_target.state_dict().items()}
+    probe = ["conv1.weight", "conv4.bias", "conv7.weight", "fc1.weight", "actor2.weight", "actor2.bias"]
+    out = dict(shapes_json=np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
+               x=x, q=q, ls=s, la=a, lr=r, ls2=s2, ld=d, loss=np.float64(loss), gamma=np.float64(RDD.GAMMA),
+               tau=np.float64(RDD.TAU), q_local_before=q_local_before)
+    for k in probe:
+        out["local_" + k] = after_local[k].reshape(-1)[:512]
+        out["target_" + k] = after_target[k].reshape(-1)[:512]
+    np.savez_compressed(os.path.join(OUT, "net.npz"), **out)
+    print("net: Q", q.shape, "loss", loss, "params", sum(int(np.prod(v)) for v in shapes.values()))
+
+
 def main():
+    if "--net-only" in sys.argv:
+        gen_net()
+        return
     gen_step_exhaustive()
     gen_episodes("episodes_none_4", 4, 300, 101, None, p_safe=0.6, keep_steps=True)
     gen_episodes("episodes_none_10", 10, 200, 102, None, p_safe=0.85, keep_steps=True)
@@ -359,6 +424,7 @@ def main():
     gen_encode()
     gen_reset()
     gen_reward()
+    gen_net()
 
 
 if __name__ == "__main__":

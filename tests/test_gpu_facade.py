@@ -1,0 +1,189 @@
+"""GPU tests of the reference-compatible host surface (Game / Map / pop_up / make_game /
+Agent / ReplayBuffer) and of the device replay memory — all of it runs through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def test_game_facade_replays_reference_episodes():
+    """BASELINE config 1 shape: a single 10x10 game driven through Game.step, checked against
+    the episodes recorded from the reference's Game.step (positions, alive, done, winner, grid,
+    both observations, history directions)."""
+    from tron.game import Game, PositionPlayer
+    from tron.player import ACPlayer, Direction
+    g = load_golden("episodes_none_10")
+    off = g["ep_off"]
+    for e in range(12):
+        s = g["starts"][e]
+        game = Game(10, 10, [PositionPlayer(1, ACPlayer(), [int(s[0]), int(s[1])]),
+                             PositionPlayer(2, ACPlayer(), [int(s[2]), int(s[3])])])
+        assert game.winner is None and not game.done and len(game.history) == 1
+        assert game.map()[int(s[0]), int(s[1])].value == 2 and game.map()[int(s[2]), int(s[3])].value == 4
+        for t in range(off[e], off[e + 1]):
+            a = g["actions"][t]
+            n1, n2, done = game.step(int(a[0]), int(a[1]))
+            assert n1.dtype == np.int64 and n1.shape == (12, 12)
+            assert np.array_equal(n1, g["step_obs1"][t]) and np.array_equal(n2, g["step_obs2"][t])
+            assert np.array_equal(game.history[-1].map.array(), g["step_grid"][t])
+            assert [*game.pps[0].position, *game.pps[1].position] == list(g["pos"][t])
+            assert [int(game.pps[0].alive), int(game.pps[1].alive)] == list(g["alive"][t])
+            assert done == bool(g["done"][t])
+            assert game.history[-2].player_one_direction == Direction(int(a[0]) + 1)
+        assert game.done and (0 if game.winner is None else game.winner) == int(g["winner"][e])
+        with pytest.raises(RuntimeError):
+            game.step(0, 0)
+
+
+def test_map_and_pop_up_facade():
+    from tron.map import Map, Tile
+    from tron.util import pop_up, prob_map, get_reward
+    e = load_golden("encode")
+    for k in range(4):
+        m = Map.from_codes(10, e["raw_10"][k])
+        for p in (1, 2):
+            codes = m.state_for_player(p)
+            assert codes.dtype == np.int64 and np.array_equal(codes, e["codes_10"][k, p - 1])
+            planes = pop_up(codes)
+            assert planes.dtype == np.float64 and np.array_equal(planes, e["planes_10"][k, p - 1])
+    m = Map(4, 4, Tile.EMPTY, Tile.WALL)
+    assert m[0, 0] is Tile.EMPTY and m.array()[0, 0] == -1
+    m[1, 2] = Tile.PLAYER_TWO_slide
+    assert m[1, 2] is Tile.PLAYER_TWO_slide and m.clone()[1, 2] is Tile.PLAYER_TWO_slide
+    assert m.color(Tile.PLAYER_ONE_HEAD, 1) == 10 and m.color(Tile.PLAYER_ONE_HEAD, 2) == -10
+    assert m.color(Tile.EMPTY, 1) == 1 and m.color(Tile.PLAYER_TWO_slide, 1) == -3
+    assert np.array_equal(prob_map(3.0), e["util_prob_map_3"])
+    r = load_golden("reward")["get_reward"]
+
+    class G:
+        winner = None
+    for ci, w, win, lose, r1, r2 in r:
+        G.winner = None if w == 0 else int(w)
+        assert get_reward(G, [win, lose]) == (r1, r2)
+
+
+def test_game_env_scalars_and_setters():
+    from tron.util import make_game
+    e = load_golden("encode")
+    game = make_game(True, True, gamemode="temper")
+    assert 40 <= game.weight[0] <= 101 and 40 <= game.weight[1] <= 101 and -30 <= game.degree <= 30
+    assert game.pps[0].position != game.pps[1].position
+    assert all(0 <= v < 10 for pp in game.pps for v in pp.position)
+    game.weight = [55, 99]
+    game.degree = -7
+    game.slide = 0.15
+    st = game._env.state()
+    assert st["weight"][0].tolist() == [55, 99] and int(st["degree"][0]) == -7
+    assert game.get_multy(0) == list(e["multy0"]) and game.get_multy(1) == list(e["multy1"])
+    assert np.array_equal(game.prob_map(), e["prob_map_015"]) and np.array_equal(game.degree_map(), e["degree_map_m7"])
+    i, j = list(e["rate_degrees"]).index(-7), list(e["rate_weights"]).index(55)
+    assert game.get_rate(0) == e["rate"][i, j] and game.get_rate() == e["rate_none"][i]
+    fair = make_game(True, True, mode="fair", gamemode="ice", slide_pram=0.3)
+    assert fair.slide == 0.3 and fair.mode == "ice"
+    with pytest.raises(NotImplementedError):
+        make_game(False, True)
+
+
+def test_main_loop_with_stub_model_and_ai_action():
+    """Game.main_loop(model, pop) with a random-action stub (the pygame-free CPU loop of
+    BASELINE config 1) terminates with a consistent winner; Ai.action returns a Direction."""
+    import random
+    from tron.util import make_game, pop_up
+    from tron.player import Direction
+    import DQN
+
+    class Stub:
+        def act(self, x, env=None):
+            assert x.shape == (1, 3, 12, 12)
+            return torch.tensor([random.randrange(4)])
+
+    for _ in range(5):
+        game = make_game(True, True)
+        game.main_loop(Stub(), pop_up)
+        alive = [pp.alive for pp in game.pps]
+        assert game.done and sum(alive) <= 1
+        if game.winner is not None:
+            assert alive[game.winner - 1] and game.pps[0].position != game.pps[1].position
+    game = make_game(True, True)
+    ai = DQN.Ai(epsilon=0.5)
+    assert isinstance(ai.action(game.map(), 1), Direction)
+
+
+def test_device_replay_ring_and_sampling():
+    from tron.vec import DeviceReplay, pop_up_planes
+    cells, cap = 144, 1000
+    rb = DeviceReplay(cap, cells, seed=11)
+    rs = np.random.RandomState(0)
+    vals = np.array([1, -1, -2, -3, 10, -10], np.int8)
+    host = dict(s=np.zeros((cap, cells), np.int8), s2=np.zeros((cap, cells), np.int8), a=np.zeros(cap, np.int8),
+                r=np.zeros(cap, np.float32), d=np.zeros(cap, np.int8))
+    head = size = 0
+    for n in (300, 450, 400, 77):                                   # wraps the ring twice
+        s, s2 = vals[rs.randint(0, 6, (n, cells))], vals[rs.randint(0, 6, (n, cells))]
+        a, r, d = rs.randint(0, 4, n).astype(np.int8), rs.randn(n).astype(np.float32), (rs.rand(n) < .3).astype(np.int8)
+        rb.add(*(torch.from_numpy(x).cuda() for x in (s, a, r, s2, d)))
+        idx = (head + np.arange(n)) % cap
+        host["s"][idx], host["s2"][idx], host["a"][idx], host["r"][idx], host["d"][idx] = s, s2, a, r, d
+        head, size = (head + n) % cap, min(size + n, cap)
+        assert len(rb) == size
+    counts = np.zeros(cap)
+    for _ in range(200):
+        st, a, r, s2, d = rb.sample(64, channels=4, plane4=5.0, side=12)
+        idx = rb.last_indices(64).cpu().numpy()
+        assert len(set(idx.tolist())) == 64 and idx.min() >= 0 and idx.max() < size      # random.sample: distinct
+        counts[idx] += 1
+        exp = pop_up_planes(torch.from_numpy(host["s"][idx].reshape(64, 12, 12)).cuda())
+        assert torch.equal(st[:, :3], exp) and torch.all(st[:, 3] == 5.0)
+        exp2 = pop_up_planes(torch.from_numpy(host["s2"][idx].reshape(64, 12, 12)).cuda())
+        assert torch.equal(s2[:, :3], exp2)
+        assert np.array_equal(a.cpu().numpy().ravel(), host["a"][idx].astype(np.int64))
+        assert np.array_equal(r.cpu().numpy().ravel(), host["r"][idx])
+        assert np.array_equal(d.cpu().numpy().ravel(), host["d"][idx].astype(np.float32))
+    # uniformity: 12800 draws over 1000 slots, expected 12.8 each; chi-square far from pathological
+    chi2 = ((counts - 12.8) ** 2 / 12.8).sum()
+    assert 800 < chi2 < 1250, chi2
+    from tron import _native as nat
+    with pytest.raises(nat.TronNativeError):                         # random.sample raises when k > len(memory)
+        rb.sample(2048, channels=3, side=12)
+    rb2 = DeviceReplay(4096, cells, seed=12)
+    s = torch.from_numpy(vals[rs.randint(0, 6, (3000, cells))]).cuda()
+    z = torch.zeros(3000, device="cuda")
+    rb2.add(s, z.to(torch.int8), z, s, z.to(torch.int8))
+    big = rb2.sample(2048, channels=3, side=12)                      # > 1024: slots drawn with replacement
+    assert big[0].shape == (2048, 3, 12, 12)
+    idx = rb2.last_indices(2048)
+    assert int(idx.min()) >= 0 and int(idx.max()) < 3000
+    assert torch.equal(big[0], pop_up_planes(s[idx].reshape(2048, 12, 12)))
+
+
+def test_dropin_agent_and_batched_trainer():
+    import DDQN
+    torch.manual_seed(0)
+    agent = DDQN.Agent(10, 4, buffer_size=4096, batch_size=32, seed=5)
+    from tron.util import make_game, pop_up
+    game = make_game(True, True)
+
+    def obs(p):
+        planes = np.concatenate([pop_up(game.map().state_for_player(p)), game.prob_map()[None]], 0)
+        return torch.from_numpy(planes[None]).float()
+    agent.epsilon = 1.0
+    s1 = obs(1)
+    a1 = agent.action(s1)
+    assert a1 in (0, 1, 2, 3)
+    for k in range(140):                                             # learn() fires once len > batch and every 4th call
+        agent.step(s1, k % 4, -1.0, s1, k % 7 == 0)
+    assert len(agent.memory) == 140 and agent.steps >= 20
+    assert torch.isfinite(agent.get_loss())
+    out = DDQN.train(n_envs=512, width=10, steps=12, learn_every=2, batch_size=64, capacity=1 << 14, log_every=0)
+    assert out["env_steps"] == 512 * 12 and out["transitions_pushed"] == 2 * 512 * 12
+    assert out["learn_steps"] == 6 and out["games"] > 0
+    assert len(out["brain"].memory) == min(2 * 512 * 12, 1 << 14)
