@@ -49,7 +49,7 @@ def pmc_traffic(envs, width, obs, mode):
         return None, None
     summ = json.load(open(files[-1]))
     for name, k in summ["kernels"].items():
-        if "k_tile<1, true, true>" in name:
+        if "k_obs<true>" in name:
             return k["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
     return None, None
 
@@ -107,14 +107,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step = env.step_fn(autoreset=True)             # ctypes arguments bound once: the loop is launch-only
     for _ in range(args.warmup):
-        env.step(autoreset=True)
+        step()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
     ev0.record()                                   # same stream the kernels are launched on
     for _ in range(args.steps):
-        env.step(autoreset=True)
+        step()
     ev1.record()
     barrier()
     wall = time.perf_counter() - t0
@@ -155,7 +156,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if hbm_bytes is None else hbm_bytes / (kern_ms * 1e-3) / 1e9,
                          "traffic_bytes_per_launch": hbm_bytes, "traffic_source": hbm_src,
-                         "kernel": "k_tile<CODES_I8, step, 16B>", "kernel_ms": kern_ms,
+                         "kernel": "k_obs<step> (observation-is-state, int8 codes)", "kernel_ms": kern_ms,
                          "alg_bytes_per_env_step": b_alg, "alg_bytes_per_launch": b_alg * args.envs},
         }
         if world == 1 and not args.no_cpu_baseline:

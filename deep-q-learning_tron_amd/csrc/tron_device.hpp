@@ -26,6 +26,8 @@ struct Params {
                                //   episode = games started (RNG counter)
                                //   nstart / nenvp = pos / envp of the NEXT game (make_game at `episode`)
     double *slide;             // [N] game.py:88
+    int8_t *obs_state;         // observation-is-state mode (mode None): caller-attached [N][2][G] code planes
+                               //   whose player-1 plane IS the board; `grid` is then unused
     const int8_t *fresh;       // [G] empty board with WALL border (map.py:45-48)
 };
 
@@ -180,6 +182,33 @@ __device__ __forceinline__ uint32_t codes4(uint32_t tiles, bool player_is_2)
     return player_is_2 ? __builtin_amdgcn_perm(CODE_HI_P2, CODE_LO_P2, sel)
                        : __builtin_amdgcn_perm(CODE_HI_P1, CODE_LO_P1, sel);
 }
+// player-2 codes from player-1 codes: bodies -2 <-> -3, heads 10 <-> -10, EMPTY 1 and WALL -1 stay
+// (map.py:67-81).  The six codes have distinct low nibbles (1, F, E, D, A, 6), so this is a
+// 16-entry byte LUT: two v_perm halves selected by bit 3.
+constexpr uint32_t SWAP_LO = pack4(0, 1, 0, 0) | 0u, SWAP_LO_HI = pack4(0, 0, 10, 0);     // idx 0-3 | 4-7 (6 -> 10)
+constexpr uint32_t SWAP_HI_LO = pack4(0, 0, -10, 0), SWAP_HI_HI = pack4(0, -2, -3, -1);   // idx 8-11 (A -> -10) | 12-15 (D->-2, E->-3, F->-1)
+__device__ __forceinline__ uint32_t swap_codes4(uint32_t c)
+{
+    const uint32_t sel = c & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(SWAP_LO_HI, SWAP_LO, sel);       // low nibble 0..7
+    const uint32_t hi = __builtin_amdgcn_perm(SWAP_HI_HI, SWAP_HI_LO, sel);    // low nibble 8..15
+    const uint32_t m = ((c >> 3) & 0x01010101u) * 0xFFu;                       // 0xFF where bit 3 is set
+    return (hi & m) | (lo & ~m);
+}
+// Tile value (map.py:9-17) from a player-1 code, mode None (no slide tiles): low nibble LUT
+// 1->EMPTY 0, F->WALL -1, E->P1_BODY 1, D->P2_BODY 3, A->P1_HEAD 2, 6->P2_HEAD 4.
+__device__ __forceinline__ int8_t tile_of_code(int code)
+{
+    switch (code & 15) {
+    case 0x1: return 0;
+    case 0xF: return -1;
+    case 0xE: return 1;
+    case 0xD: return 3;
+    case 0xA: return 2;
+    default: return 4;
+    }
+}
+
 __device__ __forceinline__ int8_t code1(int tile, bool player_is_2)
 {
     const uint32_t sh = (uint32_t)(tile & 3) * 8u;

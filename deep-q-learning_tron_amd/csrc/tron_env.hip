@@ -141,9 +141,9 @@ enum { RES_STEPPED = 1u, RES_DONE = 2u, RES_STORE_ST = 4u, RES_RESET = 8u };
 
 // ------------------------------------------------------------------ the move --
 // One lane = one env, against its LDS copy g: Game.next_frame + Game.step (game.py:149-277).
-// LDS-only.  Leaves: rec_st (new st4), rec_out {flags | winner<<4, reward1, reward2, restart word}.
-// (A variant that pre-fetched the 2-4 target cells from HBM and ran the move in registers
-// was measured: shorter serial section, but +20 VGPRs cost a workgroup per CU and lost.)
+// LDS-only, one read round trip.  Leaves: rec_st (new st4), rec_out {flags | winner<<4, reward1,
+// reward2, restart word}.  (Pre-fetching the target cells from HBM before the barrier was
+// measured too: +20 VGPRs held across the tile load cost a workgroup per CU and lost.)
 __device__ inline void lane_move(const Params &P, unsigned char *g, const EnvRegs &R, const int a[2], const float u[2],
                                  uint32_t flags, uint32_t *dirty, uint32_t chunk0, uint4 &rec_st, uint4 &rec_out)
 {
@@ -160,36 +160,58 @@ __device__ inline void lane_move(const Params &P, unsigned char *g, const EnvReg
     if (!done) {
         res |= RES_STEPPED;
         const bool sliding = (P.mode != TRON_MODE_NONE);
-        int cells[6];
-        // game.py:155-156 — both heads turn into bodies before anyone moves
-        cells[0] = cell_index(S, r[0], c[0]);
-        cells[1] = cell_index(S, r[1], c[1]);
-        g[cells[0]] = (unsigned char)TRON_P1_BODY;
-        g[cells[1]] = (unsigned char)TRON_P2_BODY;
-        cells[2] = cells[0];
-        cells[3] = cells[1];
-
-        // game.py:158-178 — advance (player.py:124-132), optional slide, player order
+        // The <=4 cells the move can look at — first target n[p] and slide landing s[p] of each
+        // player (player.py:124-132, game.py:163-178) — are read from the LDS copy in ONE round
+        // trip; the write-then-read dependencies between the players are resolved in registers.
+        int dr[2], dc[2], n[2], sl[2], tn[2], ts[2];
+        bool inb[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const int dr = (a[p] == 0) ? -1 : (a[p] == 2) ? 1 : 0;   // UP / DOWN
-            const int dc = (a[p] == 1) ? 1 : (a[p] == 3) ? -1 : 0;   // RIGHT / LEFT
-            int nr = r[p] + dr, nc = c[p] + dc;
-            if (sliding) {
-                // the uniform is consulted only for an in-bounds EMPTY target (game.py:164-165)
-                if (nr >= 0 && nc >= 0 && nr < W && nc < W) {
-                    const int idx = cell_index(S, nr, nc);
-                    if (g[idx] == (unsigned char)TRON_EMPTY) {
-                        const double rate = (P.mode == TRON_MODE_ICE)
-                                                ? R.slide
-                                                : get_rate((int)(int8_t)(R.envp >> 16), (int)((R.envp >> (8 * p)) & 0xFFu));
-                        if ((double)u[p] <= rate) {                 // game.py:169
-                            g[idx] = (unsigned char)(p == 0 ? TRON_P1_SLIDE : TRON_P2_SLIDE);
-                            cells[2 + p] = idx;
-                            nr += dr;
-                            nc += dc;
-                        }
-                    }
+            dr[p] = (a[p] == 0) ? -1 : (a[p] == 2) ? 1 : 0;   // UP / DOWN
+            dc[p] = (a[p] == 1) ? 1 : (a[p] == 3) ? -1 : 0;   // RIGHT / LEFT
+            const int nr = r[p] + dr[p], nc = c[p] + dc[p];
+            inb[p] = nr >= 0 && nc >= 0 && nr < W && nc < W;
+            n[p] = cell_index(S, nr, nc);
+            sl[p] = inb[p] ? cell_index(S, nr + dr[p], nc + dc[p]) : n[p];
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            tn[p] = (int)(int8_t)g[n[p]];
+            ts[p] = sliding ? (int)(int8_t)g[sl[p]] : (int)TRON_WALL;
+        }
+        // cells written so far, in program order; a read sees the latest write to that cell
+        int cells[6], vals[6];
+        cells[0] = cell_index(S, r[0], c[0]); vals[0] = TRON_P1_BODY;     // game.py:155-156: heads -> bodies first
+        cells[1] = cell_index(S, r[1], c[1]); vals[1] = TRON_P2_BODY;
+#pragma unroll
+        for (int k = 2; k < 6; ++k) { cells[k] = cells[k & 1]; vals[k] = vals[k & 1]; }
+        auto tile_at = [&](int idx, int before, int upto) {
+            int v = before;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (k < upto && cells[k] == idx) v = vals[k];
+            return v;
+        };
+
+        // game.py:158-178 — advance, optional slide, player order
+        int f[2], tf[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f[p] = n[p];
+            tf[p] = tn[p];
+            int nr = r[p] + dr[p], nc = c[p] + dc[p];
+            // the uniform is consulted only for an in-bounds EMPTY target (game.py:164-165)
+            if (sliding && inb[p] && tile_at(n[p], tn[p], 2 + p) == TRON_EMPTY) {
+                const double rate = (P.mode == TRON_MODE_ICE)
+                                        ? R.slide
+                                        : get_rate((int)(int8_t)(R.envp >> 16), (int)((R.envp >> (8 * p)) & 0xFFu));
+                if ((double)u[p] <= rate) {                             // game.py:169
+                    cells[2 + p] = n[p];
+                    vals[2 + p] = (p == 0) ? TRON_P1_SLIDE : TRON_P2_SLIDE;
+                    f[p] = sl[p];
+                    tf[p] = ts[p];
+                    nr += dr[p];
+                    nc += dc[p];
                 }
             }
             r[p] = nr;
@@ -201,13 +223,15 @@ __device__ inline void lane_move(const Params &P, unsigned char *g, const EnvReg
         uint32_t alive = m & 3u;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const int idx = cell_index(S, r[p], c[p]);
             const bool oob = r[p] < 0 || c[p] < 0 || r[p] >= W || c[p] >= W;
-            if (oob || g[idx] != (unsigned char)TRON_EMPTY)
+            if (oob || tile_at(f[p], tf[p], 4 + p) != TRON_EMPTY)
                 alive &= ~(1u << p);
-            g[idx] = (unsigned char)(p == 0 ? TRON_P1_HEAD : TRON_P2_HEAD);
-            cells[4 + p] = idx;
+            cells[4 + p] = f[p];
+            vals[4 + p] = (p == 0) ? TRON_P1_HEAD : TRON_P2_HEAD;
         }
+        // the writes, in program order (same-lane LDS writes keep their order); fire and forget
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g[cells[k]] = (unsigned char)vals[k];
 
         // game.py:264-275 — done / winner (same cell => draw)
         const int n_alive = (int)(alive & 1u) + (int)((alive >> 1) & 1u);
@@ -266,11 +290,11 @@ __global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, u
     const int G = P.G;
     uint4 *tile = reinterpret_cast<uint4 *>(smem);                  // [E*cpe]
     uint4 *tmpl = tile + (size_t)E * cpe;                           // [cpe] fresh board as chunks
-    uint4 *rec_st = tmpl + cpe;                                     // [64] new st4
-    uint4 *rec_out = rec_st + 64;                                   // [64] flags / rewards / restart word
-    uint4 *rec_rs = rec_out + 64;                                   // [64] new rs4 (restarted envs)
-    float *plane4 = reinterpret_cast<float *>(rec_rs + 64);         // [64]
-    uint32_t *dirty = reinterpret_cast<uint32_t *>(plane4 + 64);    // [ceil(E*cpe/32)] chunk bitmask
+    uint4 *rec_st = tmpl + cpe;                                     // [E] new st4
+    uint4 *rec_out = rec_st + E;                                    // [E] flags / rewards / restart word
+    uint4 *rec_rs = rec_out + E;                                    // [E] new rs4 (restarted envs)
+    float *plane4 = reinterpret_cast<float *>(rec_rs + E);          // [E]
+    uint32_t *dirty = reinterpret_cast<uint32_t *>(plane4 + E);     // [ceil(E*cpe/32)] chunk bitmask
 
     const int tid = threadIdx.x;
     const int e0 = blockIdx.x * E;
@@ -362,8 +386,10 @@ __global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, u
             if (mine)
                 lane_move(P, reinterpret_cast<unsigned char *>(tile + (size_t)tid * cpe), R, a, u, flags, dirty,
                           (uint32_t)tid * cpe, rs, ro);
-            rec_st[tid] = rs;
-            rec_out[tid] = ro;
+            if (tid < E) {
+                rec_st[tid] = rs;
+                rec_out[tid] = ro;
+            }
         }
         STAMP(3);
         __syncthreads();
@@ -432,6 +458,285 @@ __global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, u
                                       (FMT == TRON_OBS_PLANES4_F32) ? plane4[le] : 0.0f);
     }
     STAMP(7);
+}
+
+// ------------------------------------------------- observation-is-state kernel --
+// Mode None, int8 code observations, even board side.  There are no slide tiles in this mode,
+// so the player-1 code plane (map.py:67-81) is a lossless image of the board.  The caller
+// attaches its [N][2][G] observation buffer once (tron_attach_obs_state) and that buffer IS the
+// env state: a step reads the player-1 plane (G bytes per env) and rewrites both planes (2G) —
+// exactly the algorithmic traffic, no dirty-chunk write-back, no rewrite of restarted boards.
+// Same three phases as k_tile; differences: the tile holds player-1 codes, the move works in
+// code space (EMPTY is 1; bodies -2 / -3; heads 10 / -10), the player-2 plane is the
+// swap_codes4 LUT of the player-1 plane, and wave 1 draws the speculative next start so it runs
+// beside wave 0's action Philox instead of after it.
+__device__ inline void lane_move_codes(const Params &P, unsigned char *g, const EnvRegs &R, const int a[2],
+                                       uint32_t flags, uint4 &rec_st, uint4 &rec_out)
+{
+    const int S = P.S, W = P.W;
+    uint32_t m = R.meta;
+    int r[2] = {(int)(int8_t)(R.pos), (int)(int8_t)(R.pos >> 16)};
+    int c[2] = {(int)(int8_t)(R.pos >> 8), (int)(int8_t)(R.pos >> 24)};
+    bool done = (m & META_DONE) != 0;
+    int winner = (int)((m >> 4) & 3u);
+    float rw0 = 0.0f, rw1 = 0.0f;
+    uint32_t res = 0u;
+    rec_st = make_uint4(R.pos, R.meta, R.eplen, R.tick);
+
+    if (!done) {
+        res |= RES_STEPPED;
+        constexpr int C_EMPTY = 1, C_P1_BODY = -2, C_P2_BODY = -3, C_P1_HEAD = 10, C_P2_HEAD = -10;
+        int old[2], f[2], tf[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            old[p] = cell_index(S, r[p], c[p]);
+            r[p] += (a[p] == 0) ? -1 : (a[p] == 2) ? 1 : 0;          // UP / DOWN   (player.py:124-132)
+            c[p] += (a[p] == 1) ? 1 : (a[p] == 3) ? -1 : 0;          // RIGHT / LEFT
+            f[p] = cell_index(S, r[p], c[p]);
+        }
+        tf[0] = (int)(int8_t)g[f[0]];                                  // one LDS round trip for both targets
+        tf[1] = (int)(int8_t)g[f[1]];
+        // game.py:155-156 — heads turn into bodies BEFORE anyone moves: a target that is either
+        // old head is a body by now
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (f[p] == old[0]) tf[p] = C_P1_BODY;
+            if (f[p] == old[1]) tf[p] = C_P2_BODY;
+        }
+        if (f[1] == f[0]) tf[1] = C_P1_HEAD;                           // game.py:205-214: P2 tests after P1's head is down
+        uint32_t alive = m & 3u;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const bool oob = r[p] < 0 || c[p] < 0 || r[p] >= W || c[p] >= W;
+            if (oob || tf[p] != C_EMPTY) alive &= ~(1u << p);
+        }
+        // writes in the reference's order: bodies, then P1's head, then P2's (an out-of-bounds
+        // head lands on the border WALL cell; a same-cell head-on leaves P2's head)
+        g[old[0]] = (unsigned char)C_P1_BODY;
+        g[old[1]] = (unsigned char)C_P2_BODY;
+        g[f[0]] = (unsigned char)C_P1_HEAD;
+        g[f[1]] = (unsigned char)C_P2_HEAD;
+
+        // game.py:264-275 — done / winner (same cell => draw)
+        const int n_alive = (int)(alive & 1u) + (int)((alive >> 1) & 1u);
+        if (n_alive <= 1) {
+            if (n_alive == 1 && (r[0] != r[1] || c[0] != c[1]))
+                winner = (alive & 1u) ? 1 : 2;
+            done = true;
+        }
+        // rewards: util.py:87-94 / DDQN.py:289-305 / DQN.py:224-241
+        if (!done) {
+            rw0 = rw1 = P.r_index ? (float)R.eplen : P.r_step;
+        } else if (winner == 0) {
+            rw0 = rw1 = P.r_draw;
+        } else {
+            rw0 = (winner == 1) ? P.r_win : P.r_lose;
+            rw1 = (winner == 2) ? P.r_win : P.r_lose;
+        }
+        rec_st = make_uint4(pack_pos(r[0], c[0], r[1], c[1]),
+                            alive | (done ? META_DONE : 0u) | ((uint32_t)winner << 4) | ((uint32_t)(a[0] + 1) << 8) |
+                                ((uint32_t)(a[1] + 1) << 12),
+                            R.eplen + 1u, R.tick + 1u);
+        res |= RES_STORE_ST;
+    }
+    if (done) res |= RES_DONE;
+
+    uint32_t restart = 0u;
+    if (done && (flags & TRON_STEP_AUTORESET)) {                      // ACKTR.py:307-310
+        rec_st = make_uint4(R.nstart, META_ALIVE0 | META_ALIVE1, 0u, rec_st.w);
+        res |= RES_STORE_ST | RES_RESET;
+        const int h1 = cell_index(S, (int)(int8_t)(R.nstart), (int)(int8_t)(R.nstart >> 8));
+        const int h2 = cell_index(S, (int)(int8_t)(R.nstart >> 16), (int)(int8_t)(R.nstart >> 24));
+        restart = 0x80000000u | (uint32_t)h1 | ((uint32_t)h2 << 14);
+    }
+    rec_out = make_uint4(res | ((uint32_t)winner << 4), __float_as_uint(rw0), __float_as_uint(rw1), restart);
+}
+
+template <bool DO_STEP>
+__global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, uint32_t cpe_magic,
+                                               const int8_t *__restrict__ actions, uint32_t flags, StepOut out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int G = P.G;
+    uint4 *tile = reinterpret_cast<uint4 *>(smem);                  // [E*cpe] player-1 codes
+    uint4 *tmpl = tile + (size_t)E * cpe;                           // [cpe] fresh board as player-1 codes
+    uint4 *rec_st = tmpl + cpe;                                     // [E]
+    uint4 *rec_out = rec_st + E;                                    // [E]
+    uint4 *rec_rs = rec_out + E;                                    // [E] new rs4 (restarted envs)
+    uint4 *rs_in = rec_rs + E;                                      // [E] rs4 as loaded by wave 1
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int e0 = blockIdx.x * E;
+    const int ne = min(E, P.N - e0);
+    const uint32_t nchunks = (uint32_t)ne * cpe;
+    int8_t *otile = P.obs_state + (size_t)e0 * 2u * G;              // this tile's [ne][2][G] planes
+    const bool autoreset = (flags & TRON_STEP_AUTORESET) != 0u;
+    const bool mine = lane < ne;
+    const int env = e0 + lane;
+
+    // ---- 1: state words (wave 0: st4, wave 1: rs4), then the tile
+    EnvRegs R{};
+    uint4 rs = make_uint4(0u, 0u, 0u, 0u);
+    if (DO_STEP && mine) {
+        if (wave == 0) {
+            const uint4 st = P.st4[env];
+            R.pos = st.x; R.meta = st.y; R.eplen = st.z; R.tick = st.w;
+            if (actions) R.act = reinterpret_cast<const uint16_t *>(actions)[env];
+        } else if (wave == 1 && autoreset) {
+            rs = P.rs4[env];
+        }
+    }
+    if (DO_STEP && autoreset)
+        for (uint32_t d = (uint32_t)tid; d < cpe * 16u; d += BLOCK)
+            reinterpret_cast<int8_t *>(tmpl)[d] = (d < (uint32_t)G) ? (P.fresh[d] == TRON_EMPTY ? (int8_t)1 : (int8_t)-1) : (int8_t)0;
+
+    int a[2] = {0, 0};
+    for (uint32_t base = 0; base < nchunks; base += DK * BLOCK) {
+        uint4 v[DK];
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+            const uint32_t i = base + (uint32_t)tid + (uint32_t)k * BLOCK;
+            const uint32_t le = __umulhi(i, cpe_magic);
+            const uint32_t c = (i - le * cpe) * 16u;
+            if (i < nchunks) v[k] = load_chunk<true>(otile + (size_t)le * 2u * G + c);   // player-1 plane
+        }
+        if (base == 0u && DO_STEP && mine) {
+            // random-number work in the shadow of the tile load: wave 0 the actions, wave 1 the next start
+            if (wave == 0) {
+                if (!actions) {
+                    uint32_t x[4];
+                    philox4x32_10((uint32_t)env, R.tick, RNG_STEP, 0u, P.seed, P.stream, x);
+                    a[0] = (int)(x[0] & 3u);
+                    a[1] = (int)(x[1] & 3u);
+                } else {
+                    a[0] = (int)(R.act & 3u);
+                    a[1] = (int)((R.act >> 8) & 3u);
+                }
+            } else if (wave == 1 && autoreset) {
+                rs_in[lane] = rs;
+                const NewGame ng = make_game(P.seed, P.stream, P.W, P.fair, (uint32_t)env, rs.y + 1u);
+                rec_rs[lane] = make_uint4(rs.w, rs.y + 1u, pack_pos(ng.r1, ng.c1, ng.r2, ng.c2),
+                                          pack_envp(ng.w0, ng.w1, ng.degree));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+            const uint32_t i = base + (uint32_t)tid + (uint32_t)k * BLOCK;
+            if (i < nchunks) tile[i] = v[k];
+        }
+    }
+    __syncthreads();
+
+    if (DO_STEP) {
+        // ---- 2: the move, wave 0, one env per lane, LDS only
+        if (wave == 0) {
+            uint4 rst = make_uint4(0u, 0u, 0u, 0u), ro = make_uint4(0u, 0u, 0u, 0u);
+            if (mine) {
+                if (autoreset) R.nstart = rs_in[lane].z;
+                lane_move_codes(P, reinterpret_cast<unsigned char *>(tile + (size_t)lane * cpe), R, a, flags, rst, ro);
+            }
+            if (lane < E) {
+                rec_st[lane] = rst;
+                rec_out[lane] = ro;
+            }
+        }
+        __syncthreads();
+
+        // ---- 3a: waves 1-3 write the records out (lane = env)
+        if (wave >= 1 && mine) {
+            const uint4 ro = rec_out[lane];
+            if (wave == 1) {
+                if (ro.x & RES_STORE_ST) P.st4[env] = rec_st[lane];
+                if (ro.x & RES_RESET) P.rs4[env] = rec_rs[lane];
+            } else if (wave == 2) {
+                if (out.done) out.done[env] = (int8_t)((ro.x & RES_DONE) != 0u);
+                if (out.winner) out.winner[env] = (int8_t)((ro.x >> 4) & 3u);
+            } else {
+                if (out.reward)
+                    reinterpret_cast<float2 *>(out.reward)[env] = make_float2(__uint_as_float(ro.y), __uint_as_float(ro.z));
+            }
+        }
+        if (out.totals && wave == 3) {
+            const uint32_t f = mine ? rec_out[lane].x : 0u;
+            const int wn = ((f & RES_STEPPED) && (f & RES_DONE)) ? (int)((f >> 4) & 3u) : -1;
+            const unsigned long long bs = __ballot((f & RES_STEPPED) != 0u);
+            const unsigned long long b1 = __ballot(wn == 1), b2 = __ballot(wn == 2), b0 = __ballot(wn == 0);
+            if (lane == 0) {
+                if (bs) atomicAdd(&out.totals[0], (unsigned long long)__popcll(bs));
+                if (b1) atomicAdd(&out.totals[1], (unsigned long long)__popcll(b1));
+                if (b2) atomicAdd(&out.totals[2], (unsigned long long)__popcll(b2));
+                if (b0) atomicAdd(&out.totals[3], (unsigned long long)__popcll(b0));
+            }
+        }
+    } else {
+        return;                                                        // nothing to re-encode: the planes are the state
+    }
+
+    // ---- 3b: the stream: both planes of every chunk
+    for (uint32_t i = (uint32_t)tid; i < nchunks; i += BLOCK) {
+        const uint32_t le = __umulhi(i, cpe_magic);
+        const uint32_t k = i - le * cpe;
+        const uint32_t c = k * 16u;
+        const int nb = min(16, G - (int)c);
+        uint4 t = tile[i];
+        const uint32_t ri = rec_out[le].w;
+        if (ri >> 31) {                                                // restarted env: fresh board + heads
+            t = tmpl[k];
+            const uint32_t d1 = (ri & 0x3FFFu) - c, d2 = ((ri >> 14) & 0x3FFFu) - c;
+            // the head cells are EMPTY (code 1) in the template: XOR turns 1 into 10 / -10 (game.py:90-91)
+            const uint32_t v1 = (uint32_t)(0x01 ^ 0x0A) << ((d1 & 3u) * 8u), v2 = (uint32_t)(0x01 ^ 0xF6) << ((d2 & 3u) * 8u);
+            t.x ^= (d1 < 4u ? v1 : 0u) ^ (d2 < 4u ? v2 : 0u);
+            t.y ^= (d1 - 4u < 4u ? v1 : 0u) ^ (d2 - 4u < 4u ? v2 : 0u);
+            t.z ^= (d1 - 8u < 4u ? v1 : 0u) ^ (d2 - 8u < 4u ? v2 : 0u);
+            t.w ^= (d1 - 12u < 4u ? v1 : 0u) ^ (d2 - 12u < 4u ? v2 : 0u);
+        }
+        const uint32_t w1[4] = {t.x, t.y, t.z, t.w};
+        const uint32_t w2[4] = {swap_codes4(t.x), swap_codes4(t.y), swap_codes4(t.z), swap_codes4(t.w)};
+        int8_t *o1 = otile + (size_t)le * 2u * G + c;
+        store_chunk<true>(o1, nb, w1);
+        store_chunk<true>(o1 + G, nb, w2);
+    }
+}
+
+// observation-is-state helpers: board images / other formats from the attached planes
+__global__ void k_obs_to_grid(Params P, int8_t *__restrict__ grid_out)
+{
+    const size_t total = (size_t)P.N * P.G;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t e = i / (size_t)P.G, cidx = i - e * (size_t)P.G;
+        grid_out[i] = tile_of_code(P.obs_state[e * 2u * P.G + cidx]);
+    }
+}
+__global__ void k_obs_reset(Params P, const int8_t *__restrict__ mask)
+{
+    // after k_reset wrote P.grid for the masked envs: re-derive their two planes from it
+    const int env = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (env >= P.N) return;
+    if (mask && !mask[env]) return;
+    const int8_t *g = P.grid + (size_t)env * P.G;
+    int8_t *o = P.obs_state + (size_t)env * 2u * P.G;
+    for (int i = lane; i < P.G; i += 64) {
+        o[i] = code1(g[i], false);
+        o[P.G + i] = code1(g[i], true);
+    }
+}
+// planes (util.pop_up [+ prob_map plane]) of every env from the attached code planes
+__global__ void k_obs_planes(Params P, int channels, float *__restrict__ out)
+{
+    const size_t cells = (size_t)P.G, total = (size_t)P.N * 2u * cells;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t k = i / cells, cidx = i - k * cells;          // k = env*2 + player
+        const int v = P.obs_state[i];
+        float *o = out + k * (size_t)channels * cells + cidx;
+        o[0] = (v == -1) ? 1.0f : 0.0f;
+        o[cells] = (v == -2) ? 1.0f : (v == 10) ? 10.0f : 0.0f;
+        o[2 * cells] = (v == -3) ? 1.0f : (v == -10) ? 10.0f : 0.0f;
+        if (channels == 4) o[3 * cells] = (float)degree_slide(P.slide[k >> 1]);
+    }
 }
 
 // ------------------------------------------------------------- small kernels --
@@ -615,6 +920,30 @@ int launch_fmt(tron_env *h, int fmt, const int8_t *a, const float *u, uint32_t f
 #undef TRON_CASE
 }
 
+template <bool DO_STEP>
+int launch_obs(tron_env *h, const int8_t *actions, uint32_t flags, StepOut out, hipStream_t st)
+{
+    auto kern = k_obs<DO_STEP>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        attr_done = true;
+    }
+    const int blocks = (h->P.N + h->E - 1) / h->E;
+    const size_t smem = ((size_t)h->E + 1u) * h->cpe * 16u + 4u * (size_t)h->E * 16u;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, h->P, h->E, h->cpe, h->cpe_magic, actions, flags, out);
+    return launch_status();
+}
+
+inline int obs_planes(tron_env *h, int fmt, void *obs, hipStream_t st)
+{
+    const int ch = (fmt == TRON_OBS_PLANES3_F32) ? 3 : 4;
+    hipLaunchKernelGGL(k_obs_planes, dim3(4096), dim3(256), 0, st, h->P, ch, reinterpret_cast<float *>(obs));
+    return launch_status();
+}
+
 inline bool bad_handle(tron_handle h)
 {
     if (!h) return true;
@@ -669,7 +998,7 @@ int tron_create(int32_t n_envs, int32_t W, int32_t mode, int32_t fair, uint32_t 
         if (v >= 1 && v <= 64 && ((size_t)v + 1u) * h->cpe * 16u + 8192u <= 160u * 1024u) E = v;
     }
     h->E = E;
-    h->smem = ((size_t)E + 1u) * h->cpe * 16u + 3u * 64u * 16u + 64u * 4u + 4u * (((size_t)E * h->cpe + 31u) / 32u + 1u);
+    h->smem = ((size_t)E + 1u) * h->cpe * 16u + 3u * (size_t)E * 16u + (size_t)E * 4u + 4u * (((size_t)E * h->cpe + 31u) / 32u + 1u) + 16u;
 
     // one blob: grid (padded for 16-byte over-read) + state words + fresh template
     const size_t N = (size_t)n_envs;
@@ -688,6 +1017,7 @@ int tron_create(int32_t n_envs, int32_t W, int32_t mode, int32_t fair, uint32_t 
     P.st4 = reinterpret_cast<uint4 *>(blob + o_st4);
     P.rs4 = reinterpret_cast<uint4 *>(blob + o_rs4);
     P.slide = reinterpret_cast<double *>(blob + o_slide);
+    P.obs_state = nullptr;
     P.fresh = reinterpret_cast<const int8_t *>(blob + o_fresh);
     if (hipMemsetAsync(blob, 0, total, nullptr) != hipSuccess) { (void)hipGetLastError(); }
     hipLaunchKernelGGL(k_fresh, dim3((P.G + 255) / 256), dim3(256), 0, nullptr, const_cast<int8_t *>(P.fresh), P.S);
@@ -750,6 +1080,21 @@ int tron_reset(tron_handle h, const int8_t *env_mask, const int8_t *start_pos, c
     const int per = BLOCK / 64;
     hipLaunchKernelGGL(k_reset, dim3((h->P.N + per - 1) / per), dim3(BLOCK), 0, S_(stream), h->P, env_mask, start_pos,
                        weight, degree);
+    if (h->P.obs_state)     // observation-is-state: the masked envs' planes are re-derived from their fresh boards
+        hipLaunchKernelGGL(k_obs_reset, dim3((h->P.N + per - 1) / per), dim3(BLOCK), 0, S_(stream), h->P, env_mask);
+    return launch_status();
+}
+
+int tron_attach_obs_state(tron_handle h, int8_t *obs_codes, void *stream)
+{
+    if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
+    if (!obs_codes || (reinterpret_cast<uintptr_t>(obs_codes) & 15u)) return TRON_ERR_BAD_ARG;
+    if (h->P.mode != TRON_MODE_NONE || !h->aligned) return TRON_ERR_UNSUPPORTED;   // slide tiles are not codable
+    if (h->P.obs_state) return TRON_ERR_BAD_ARG;                                      // already attached
+    h->P.obs_state = obs_codes;
+    const int per = BLOCK / 64;     // derive the planes from the boards as they are now
+    hipLaunchKernelGGL(k_obs_reset, dim3((h->P.N + per - 1) / per), dim3(BLOCK), 0, S_(stream), h->P,
+                       (const int8_t *)nullptr);
     return launch_status();
 }
 
@@ -760,6 +1105,13 @@ int tron_step_encode(tron_handle h, const int8_t *actions, const float *uniforms
     if ((obs_fmt != TRON_OBS_NONE) != (obs != nullptr)) return TRON_ERR_BAD_ARG;
     if (flags & ~TRON_STEP_AUTORESET) return TRON_ERR_BAD_ARG;
     StepOut out{out_done, out_winner, out_reward, nullptr};
+    if (h->P.obs_state) {
+        if (obs_fmt == TRON_OBS_CODES_I8 && obs != h->P.obs_state) return TRON_ERR_BAD_ARG;   // the attached buffer is the output
+        if (obs_fmt < TRON_OBS_NONE || obs_fmt > TRON_OBS_PLANES4_F32) return TRON_ERR_BAD_ARG;
+        const int rc = launch_obs<true>(h, actions, flags, out, S_(stream));
+        if (rc != TRON_OK || obs_fmt == TRON_OBS_NONE || obs_fmt == TRON_OBS_CODES_I8) return rc;
+        return obs_planes(h, obs_fmt, obs, S_(stream));
+    }
     return launch_fmt<true>(h, obs_fmt, actions, uniforms, flags, obs, out, S_(stream));
 }
 
@@ -775,6 +1127,19 @@ int tron_encode(tron_handle h, int32_t obs_fmt, void *obs, void *stream)
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
     if (obs_fmt == TRON_OBS_NONE || !obs) return TRON_ERR_BAD_ARG;
     StepOut out{nullptr, nullptr, nullptr, nullptr};
+    if (h->P.obs_state) {
+        if (obs_fmt == TRON_OBS_CODES_I8) {
+            if (obs == h->P.obs_state) return TRON_OK;            // the attached planes are always current
+            const size_t nbytes = (size_t)h->P.N * 2u * h->P.G;
+            if (reinterpret_cast<uintptr_t>(obs) & 15u) return TRON_ERR_BAD_ARG;
+            hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, S_(stream), reinterpret_cast<const uint4 *>(h->P.obs_state),
+                               reinterpret_cast<uint4 *>(obs), nbytes / 16, h->P.obs_state, reinterpret_cast<int8_t *>(obs),
+                               nbytes);
+            return launch_status();
+        }
+        if (obs_fmt != TRON_OBS_PLANES3_F32 && obs_fmt != TRON_OBS_PLANES4_F32) return TRON_ERR_BAD_ARG;
+        return obs_planes(h, obs_fmt, obs, S_(stream));
+    }
     return launch_fmt<false>(h, obs_fmt, nullptr, nullptr, 0u, obs, out, S_(stream));
 }
 
@@ -782,6 +1147,10 @@ int tron_get_grid(tron_handle h, int8_t *grid_out, void *stream)
 {
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
     if (!grid_out) return TRON_ERR_BAD_ARG;
+    if (h->P.obs_state) {
+        hipLaunchKernelGGL(k_obs_to_grid, dim3(2048), dim3(256), 0, S_(stream), h->P, grid_out);
+        return launch_status();
+    }
     const size_t nbytes = (size_t)h->P.N * h->P.G;
     const bool aligned = (reinterpret_cast<uintptr_t>(grid_out) & 15u) == 0;
     const size_t n16 = aligned ? nbytes / 16 : 0;
@@ -806,10 +1175,15 @@ int tron_rollout_random(tron_handle h, int32_t k_steps, int32_t obs_fmt, void *o
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
     if (k_steps < 0 || (obs_fmt != TRON_OBS_NONE) != (obs != nullptr)) return TRON_ERR_BAD_ARG;
     StepOut out{nullptr, nullptr, nullptr, totals};
+    if (h->P.obs_state && obs_fmt == TRON_OBS_CODES_I8 && obs != h->P.obs_state) return TRON_ERR_BAD_ARG;
     for (int k = 0; k < k_steps; ++k) {
-        const int rc = launch_fmt<true>(h, obs_fmt, nullptr, nullptr, TRON_STEP_AUTORESET, obs, out, S_(stream));
+        const int rc = h->P.obs_state ? launch_obs<true>(h, nullptr, TRON_STEP_AUTORESET, out, S_(stream))
+                                      : launch_fmt<true>(h, obs_fmt, nullptr, nullptr, TRON_STEP_AUTORESET, obs, out,
+                                                         S_(stream));
         if (rc != TRON_OK) return rc;
     }
+    if (h->P.obs_state && (obs_fmt == TRON_OBS_PLANES3_F32 || obs_fmt == TRON_OBS_PLANES4_F32) && k_steps > 0)
+        return obs_planes(h, obs_fmt, obs, S_(stream));
     return TRON_OK;
 }
 

@@ -1,0 +1,77 @@
+"""Batched evaluation — the rating sweep of the reference's play.py (play.py:72-98) on VecTron.
+
+The reference plays 13 x 10 000 "fair"/"ice" games one after another, sweeping `slide_pram`
+from 0 to 0.36 in steps of 0.03, and prints player 1's win rate per value.  Here every game of
+every slide value is one env of a single batch (the slide probability is a per-env quantity on
+the device), stepped until all are finished.  The pygame menu / window of play.py:22-45,100-107
+is out of scope."""
+import argparse
+
+import torch
+
+from tron.vec import VecTron, pop_up_planes
+
+
+def model_actions(model, planes, prob_plane, env_vec):
+    """model.act on a batch, in the two calling conventions of Game.main_loop (game.py:296-304)."""
+    with torch.no_grad():
+        if getattr(model, "wants_prob_plane", False):
+            a = model.act(torch.cat([planes, prob_plane], 1))
+        else:
+            a = model.act(planes, env_vec)
+    return torch.as_tensor(a).reshape(-1).to(torch.int8)
+
+
+def rating(model, model2=None, n_games=10000, slides=None, width=10, gamemode="ice", fair=True, seed=0x5EED,
+           max_steps=None, verbose=True):
+    """Returns a list of dicts {slide, p1_win, p2_win, draw, p1_rate} (play.py:76-98)."""
+    model2 = model2 or model
+    slides = [0.03 * i for i in range(13)] if slides is None else list(slides)     # play.py:74,98
+    n = n_games * len(slides)
+    S = width + 2
+    env = VecTron(n, width, mode=gamemode, fair=fair, seed=seed, obs_format="codes", reward="ddqn")
+    slide_t = torch.tensor(slides, dtype=torch.float64, device=env.device).repeat_interleave(n_games)
+    env.set_slide(slide_t)
+    obs = env.reset()
+    st = env.state()
+    # what main_loop feeds beside the planes: get_multy(0) to player 1, [get_rate()] to player 2
+    degree = st["degree"].to(torch.float32)
+    env1 = torch.stack([degree, st["weight"][:, 0].to(torch.float32)], 1)
+    env2 = (-((degree - 30) * 0.6) / 100).unsqueeze(1)
+    prob_plane = ((-slide_t * 100) * (10 / 6) + 30).to(torch.float32).view(n, 1, 1, 1).expand(n, 1, S, S)
+    for _ in range(max_steps or width * width):
+        planes = pop_up_planes(obs.reshape(2 * n, S, S)).view(n, 2, 3, S, S)
+        a1 = model_actions(model, planes[:, 0], prob_plane, env1)
+        a2 = model_actions(model2, planes[:, 1], prob_plane, env2)
+        obs, _, done, _ = env.step(torch.stack([a1, a2], 1), autoreset=False)
+        if bool(done.all()):
+            break
+    winner = env.state()["winner"].view(len(slides), n_games)
+    out = []
+    for i, s in enumerate(slides):
+        p1, p2 = int((winner[i] == 1).sum()), int((winner[i] == 2).sum())
+        out.append(dict(slide=s, p1_win=p1, p2_win=p2, draw=n_games - p1 - p2, p1_rate=p1 / max(p1 + p2, 1)))
+        if verbose:
+            print("Player 1:{} \nPlayer 2:{}\np1's win rating {}\nprob={}".format(p1, p2, out[-1]["p1_rate"], s))
+    env.close()
+    return out
+
+
+def main(args):
+    from Net.DQNNet import Net
+    from config import MAP_WIDTH
+    nets = []
+    for path in (args.p1, args.p2):
+        net = Net(3, MAP_WIDTH).to("cuda").eval()
+        if path:
+            net.load_state_dict(torch.load(path, map_location="cuda", weights_only=True))
+        nets.append(net)
+    rating(nets[0], nets[1], n_games=args.games)
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--p1', required=False, help='state_dict (.bak) of player 1\'s DQN net')
+    parser.add_argument('--p2', required=False, help='state_dict (.bak) of player 2\'s DQN net')
+    parser.add_argument('--games', type=int, default=10000)
+    main(parser.parse_args())

@@ -29,6 +29,7 @@ SIGNATURES = {
     "tron_set_slide": (C.c_int, [_vp, _f64, _vp, _vp]),
     "tron_set_weight_degree": (C.c_int, [_vp, _vp, _vp, _vp]),
     "tron_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "tron_attach_obs_state": (C.c_int, [_vp, _vp, _vp]),
     "tron_step_encode": (C.c_int, [_vp, _vp, _vp, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "tron_step": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "tron_encode": (C.c_int, [_vp, _i32, _vp, _vp]),

@@ -21,7 +21,7 @@ REWARDS = {
 
 class VecTron:
     def __init__(self, n_envs, width=10, mode=None, fair=False, seed=0x5EED, rank=0, device=None,
-                 obs_format="codes", reward="ddqn", slide=None):
+                 obs_format="codes", reward="ddqn", slide=None, obs_is_state=True):
         if not torch.cuda.is_available():
             raise nat.TronNativeError("VecTron needs a HIP device (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -45,6 +45,14 @@ class VecTron:
         self.done = torch.zeros(self.N, dtype=torch.int8, device=dev)
         self.winner = torch.zeros(self.N, dtype=torch.int8, device=dev)
         self.reward = torch.zeros(self.N, 2, dtype=torch.float32, device=dev)
+        # mode None + int8 codes + even side: let self.obs BE the env state (tron_attach_obs_state);
+        # it is then read-only for the caller — clone what must outlive the next step
+        self.obs_is_state = bool(obs_is_state and mode in (None, "none") and self._fmt == nat.OBS_CODES_I8
+                                 and self.W % 2 == 0)
+        if self.obs_is_state:
+            with torch.cuda.device(self.device):
+                nat.check(self._lib.tron_attach_obs_state(self._h, nat.ptr(self.obs), nat.stream_ptr()),
+                          "tron_attach_obs_state")
 
     # -- plumbing ---------------------------------------------------------
     def _alloc_obs(self, fmt):
@@ -121,6 +129,20 @@ class VecTron:
                                                  nat.ptr(self.obs), nat.ptr(self.done), nat.ptr(self.winner),
                                                  nat.ptr(self.reward), nat.stream_ptr()), "tron_step_encode")
         return self.obs, self.reward, self.done, self.winner
+
+    def step_fn(self, autoreset=True):
+        """A zero-argument callable that launches one random-action step (Philox actions) with all
+        ctypes arguments bound once — for launch loops where Python argument handling per call
+        would otherwise dominate a ~25 us kernel.  Same outputs as step()."""
+        fn = self._lib.tron_step_encode
+        args = (self._h, None, None, nat.STEP_AUTORESET if autoreset else 0, self._fmt, nat.ptr(self.obs),
+                nat.ptr(self.done), nat.ptr(self.winner), nat.ptr(self.reward), nat.stream_ptr())
+
+        def launch():
+            rc = fn(*args)
+            if rc:
+                nat.check(rc, "tron_step_encode")
+        return launch
 
     def encode(self, obs_format=None, out=None):
         fmt = self._fmt if obs_format is None else nat.OBS[obs_format]

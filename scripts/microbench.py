@@ -47,11 +47,11 @@ def main():
             os.environ["TRON_TILE_ENVS"] = str(e)
             env = VecTron(a.envs, a.width, seed=0x5EED, obs_format=a.obs)
             env.reset()
-            full = timeit(lambda: env.step(autoreset=True), a.iters)
+            full = timeit(env.step_fn(autoreset=True), a.iters)
             enc = timeit(lambda: env.encode(), a.iters)
             env2 = VecTron(a.envs, a.width, seed=0x5EED, obs_format=None)
             env2.reset()
-            st = timeit(lambda: env2.step(autoreset=True), a.iters)
+            st = timeit(env2.step_fn(autoreset=True), a.iters)
             tbs = balg * a.envs / (full * 1e-6) / 1e12
             print(f"{nw:>3} {e:>3} {full:9.2f} {tbs:6.2f} {tbs/8:6.3f} {enc:8.2f} {st:8.2f}", flush=True)
             env.close()

@@ -18,7 +18,7 @@ def main(fetch_dir, write_dir, stats_csv, out_json, note):
     stats = {r["Name"]: r for r in csv.DictReader(open(stats_csv))}
     out = {"note": note, "kernels": {}}
     for k in sorted(set(f) | set(w)):
-        if "k_tile" not in k:
+        if "k_tile" not in k and "k_obs" not in k:
             continue
         fb = f.get(k, 0.0) * 1024 * 2      # gfx950 correction
         wb = w.get(k, 0.0) * 1024

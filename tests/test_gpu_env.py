@@ -117,8 +117,11 @@ def _compare_state(env, ref, tag):
 
 
 CASES = [
-    # N,   W,  mode,     fair,  autoreset, reward
+    # N,   W,  mode,     fair,  autoreset, reward      (mode None + even W runs the observation-is-state kernel)
     (64, 10, None, False, True, "ddqn"),
+    (64, 10, None, False, True, "grid"),          # same, forced onto the board-owning kernel (k_tile)
+    (70, 24, None, True, False, "grid"),
+    (200, 6, None, True, False, "acktr"),         # observation-is-state, no autoreset, masked resets
     (100, 10, "temper", False, True, "acktr"),     # tail tile (100 = 64 + 36)
     (37, 4, "ice", True, True, "dqn"),             # fair starts, step-index reward
     (130, 7, "ice", False, True, "ddqn"),          # odd W: generic (G % 4 != 0) path
@@ -132,8 +135,12 @@ CASES = [
 @pytest.mark.parametrize("N,W,mode,fair,autoreset,reward", CASES)
 def test_hip_vs_oracle_philox(T, N, W, mode, fair, autoreset, reward):
     tv, oracle = T
+    ois = reward != "grid"
+    reward = "ddqn" if reward == "grid" else reward
     table = {"ddqn": oracle.REWARD_DDQN, "dqn": oracle.REWARD_DQN, "acktr": oracle.REWARD_ACKTR}[reward]
-    env = tv.VecTron(N, W, mode=mode, fair=fair, seed=1234, rank=3, obs_format="codes", reward=reward, slide=0.3)
+    env = tv.VecTron(N, W, mode=mode, fair=fair, seed=1234, rank=3, obs_format="codes", reward=reward, slide=0.3,
+                     obs_is_state=ois)
+    assert env.obs_is_state == (ois and mode is None and W % 2 == 0)
     ref = oracle.VecOracle(N, W, mode=mode, seed=1234, stream=3, fair=fair, reward=table, slide=0.3)
     obs0 = env.reset()
     ref.reset_all()

@@ -187,3 +187,19 @@ def test_dropin_agent_and_batched_trainer():
     assert out["env_steps"] == 512 * 12 and out["transitions_pushed"] == 2 * 512 * 12
     assert out["learn_steps"] == 6 and out["games"] > 0
     assert len(out["brain"].memory) == min(2 * 512 * 12, 1 << 14)
+
+
+def test_batched_rating_sweep():
+    """play.py:72-98 as one batch: 3 slide values x 400 fair/ice games between two random policies."""
+    import play
+
+    class Rand:
+        def act(self, x, env=None):
+            return torch.randint(0, 4, (x.shape[0],), device=x.device)
+
+    torch.manual_seed(0)
+    res = play.rating(Rand(), Rand(), n_games=400, slides=[0.0, 0.18, 0.36], width=10, verbose=False)
+    assert [r["slide"] for r in res] == [0.0, 0.18, 0.36]
+    for r in res:
+        assert r["p1_win"] + r["p2_win"] + r["draw"] == 400
+        assert 0.3 < r["p1_rate"] < 0.7           # symmetric random play
