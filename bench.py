@@ -94,9 +94,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; TRON_DIST_BACKEND=gloo lets several ranks share a GPU to rehearse this path
+    backend = os.environ.get("TRON_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     env = VecTron(args.envs, args.width, mode=None if args.mode == "none" else args.mode, seed=0x5EED, rank=rank,
                   obs_format=args.obs)
