@@ -73,17 +73,58 @@ def cpu_baseline(width, budget_s=12.0):
                       f"{dt:.1f} s on 1 host core (oracle/libtron_oracle.so)"}
 
 
+def dqn_bench(args):
+    """DDQN.train on VecTron + device replay: env-steps/s with the policy in the loop and transitions/s
+    consumed by learn() (SURVEY.md §8(d) metric 2).  One rank per GPU; gradients all-reduced over RCCL."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    if world > 1:
+        dist.init_process_group(os.environ.get("TRON_DIST_BACKEND", "nccl"))
+    import DDQN
+    envs, width = args.envs, args.width
+    DDQN.train(n_envs=envs, width=width, steps=max(args.warmup, 4), learn_every=2, batch_size=args.batch,
+               capacity=1 << 20, log_every=0)                                  # warm-up (MIOpen find, allocator)
+    out = DDQN.train(n_envs=envs, width=width, steps=args.steps, learn_every=2, batch_size=args.batch,
+                     capacity=1 << 20, log_every=0)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "dqn-transitions/sec", "value": out["learned_transitions_per_s"], "unit": "transitions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "env_steps_per_s_with_policy": out["env_steps_per_s"],
+            "transitions_pushed_per_s": out["transitions_pushed"] / out["seconds"],
+            "config": {"workload": f"{envs} parallel {width}x{width} self-play envs per GPU, DDQN + target net, "
+                                   f"1M-slot HBM replay, learn batch {args.batch} every 2 env-steps, eps-greedy "
+                                   f"policy = the 7-conv CNN on f32 planes"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--envs", type=int, default=N_ENVS, help="envs per GPU")
-    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65536; --dqn: 4096)")
+    ap.add_argument("--width", type=int, default=None, help="board side (default 24; --dqn: 10)")
     ap.add_argument("--obs", default="codes", choices=["codes", "planes3", "planes4"])
     ap.add_argument("--mode", default="none", choices=["none", "ice", "temper"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dqn", action="store_true",
+                    help="secondary metric: DQN transitions/s of the batched DDQN trainer (BASELINE configs[1] by "
+                         "default: 4096 envs 10x10; use --envs/--width for others)")
+    ap.add_argument("--batch", type=int, default=4096, help="--dqn: learn batch")
     args = ap.parse_args()
+    if args.dqn:
+        args.envs = 4096 if args.envs is None else args.envs
+        args.width = 10 if args.width is None else args.width
+        return dqn_bench(args)
+    args.envs = N_ENVS if args.envs is None else args.envs
+    args.width = WIDTH if args.width is None else args.width
 
     import torch
     import torch.distributed as dist
