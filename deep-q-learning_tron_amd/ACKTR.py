@@ -1,0 +1,193 @@
+"""A2C / ACKTR trainer — the reference's ACKTR.py (RolloutStorage :24-69, Brain :72-159,
+train :162-437) with the env loop replaced by one VecTron launch per step.
+
+* `RolloutStorage`, `Brain(actor_critic, args, acktr)` keep the reference's methods and maths;
+  tensors live on the model's device instead of being shuffled through the host per step.
+* `train(...)` is the loop of ACKTR.py:263-375 for N parallel self-play envs (both players act
+  with the same network, two rollout storages, two updates per iteration), with the reference's
+  conventions: reward -1 per step and get_reward(constants) at the end of a game; on done the
+  env is replaced and the observation stored is the NEW game's (ACKTR.py:307-310); masks = 1 - done.
+"""
+import argparse
+import time
+
+import torch
+from torch import optim
+
+from config import *            # noqa: F401,F403
+import config
+from config import GAMMA, MAP_WIDTH, NUM_ADVANCED_STEP, NUM_PROCESSES
+from Net.ACNet import MapNet, Mulnet, TestNet  # noqa: F401
+from Net.kfac import KFACOptimizer
+
+folderName = 'save'
+
+
+class RolloutStorage(object):
+    """n-step rollout memory (ACKTR.py:24-69).  `env_dim` > 0 adds the per-step env vector
+    (`probs`) that the non-MapNet nets take."""
+
+    def __init__(self, num_steps, num_processes, channels=3, width=MAP_WIDTH, env_dim=2, device="cpu"):
+        S = width + 2
+        self.num_steps = num_steps
+        self.observations = torch.zeros(num_steps + 1, num_processes, channels, S, S, device=device)
+        self.masks = torch.ones(num_steps + 1, num_processes, 1, device=device)
+        self.rewards = torch.zeros(num_steps, num_processes, 1, device=device)
+        self.actions = torch.zeros(num_steps, num_processes, 1, device=device).long()
+        self.probs = torch.zeros(num_steps, num_processes, env_dim, device=device).float() if env_dim else None
+        self.returns = torch.zeros(num_steps + 1, num_processes, 1, device=device)
+        self.index = 0
+
+    def insert(self, current_obs, action, reward, mask, probs=None):
+        self.observations[self.index + 1].copy_(current_obs)
+        self.masks[self.index + 1].copy_(mask)
+        self.rewards[self.index].copy_(reward)
+        self.actions[self.index].copy_(action)
+        if probs is not None:
+            self.probs[self.index].copy_(probs)
+        self.index = (self.index + 1) % self.num_steps
+
+    def after_update(self):
+        self.observations[0].copy_(self.observations[-1])
+        self.masks[0].copy_(self.masks[-1])
+
+    def compute_returns(self, next_value):
+        """Discounted n-step returns, newest first (ACKTR.py:60-69)."""
+        self.returns[-1] = next_value
+        for ad_step in reversed(range(self.rewards.size(0))):
+            self.returns[ad_step] = self.returns[ad_step + 1] * GAMMA * self.masks[ad_step + 1] + self.rewards[ad_step]
+
+
+class Brain(object):
+    def __init__(self, actor_critic, args=None, acktr=False, device=None):
+        self.device = torch.device(device if device is not None else config.device)
+        self.actor_critic = actor_critic.to(self.device)
+        self.acktr = acktr
+        p = getattr(args, "p", None)
+        v = getattr(args, "v", None)
+        self.policy_loss_coef = config.policy_loss_coef if p is None else float(p)
+        self.value_loss_coef = config.value_loss_coef if v is None else float(v)
+        if acktr:
+            self.optimizer = KFACOptimizer(self.actor_critic)
+        else:
+            self.optimizer = optim.RMSprop(self.actor_critic.parameters(), config.lr, eps=config.eps,
+                                           alpha=config.alpha)
+
+    def update(self, rollouts):
+        """One update from a full rollout (ACKTR.py:88-159)."""
+        num_steps, num_processes = rollouts.rewards.size(0), rollouts.rewards.size(1)
+        obs_shape = rollouts.observations.shape[2:]
+        self.optimizer.zero_grad()
+        obs = rollouts.observations[:-1].reshape(-1, *obs_shape).to(self.device).detach()
+        acts = rollouts.actions.view(-1, 1).to(self.device).detach()
+        if rollouts.probs is None:
+            values, action_log_probs, entropy = self.actor_critic.evaluate_actions(obs, acts)
+        else:
+            values, action_log_probs, entropy = self.actor_critic.evaluate_actions(
+                obs, acts, rollouts.probs.view(-1, rollouts.probs.size(-1)).to(self.device).detach())
+        values = values.view(num_steps, num_processes, 1)
+        action_log_probs = action_log_probs.view(num_steps, num_processes, 1)
+        advantages = rollouts.returns[:-1].to(self.device).detach() - values
+        value_loss = advantages.pow(2).mean()
+        radvantages = advantages.detach().mean()
+        action_gain = (action_log_probs * advantages.detach()).mean()
+
+        if self.acktr and self.optimizer.steps % self.optimizer.Ts == 0:
+            # sampled Fisher (Martens 2014): statistics of the gradients of these two losses
+            self.actor_critic.zero_grad()
+            pg_fisher_loss = -action_log_probs.mean()
+            value_noise = torch.randn(values.size(), device=values.device)
+            sample_values = values + value_noise
+            vf_fisher_loss = -(values - sample_values.detach()).pow(2).mean()
+            fisher_loss = pg_fisher_loss + vf_fisher_loss
+            self.optimizer.acc_stats = True
+            fisher_loss.backward(retain_graph=True)
+            self.optimizer.acc_stats = False
+
+        # the reference's loss reads the coefficients from config, not from the Brain (ACKTR.py:147-148)
+        total_loss = (value_loss * config.value_loss_coef - action_gain * config.policy_loss_coef
+                      - entropy * config.entropy_coef)
+        total_loss.backward()
+        self.optimizer.step()
+        return total_loss, value_loss, action_gain, entropy, action_log_probs.mean(), radvantages
+
+
+def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterations=100, acktr=True,
+          num_steps=NUM_ADVANCED_STEP, gamemode=None, seed=0x5EED, log_every=0, save_path=None, args=None):
+    """Batched self-play ACKTR/A2C on VecTron.  Returns counters and the Brain."""
+    from tron.vec import VecTron
+    gamemode = config.GAME_MODE if gamemode is None else gamemode
+    constants = {"1": config.reward_cons1, "2": config.reward_cons2, "3": config.reward_cons3}[str(reward)]
+    torch.manual_seed(seed)
+    is_map = (model == "map")
+    net = MapNet(width) if is_map else Mulnet(width)
+    brain = Brain(net, args, acktr=acktr, device="cuda")
+    dev = brain.device
+    env = VecTron(n_envs, width, mode=gamemode, seed=seed, obs_format="planes4" if is_map else "planes3",
+                  reward=dict(step=-1.0, win=float(constants[0]), lose=float(constants[1]), draw=0.0, step_is_index=0))
+    ch = 4 if is_map else 3
+    rollouts = [RolloutStorage(num_steps, n_envs, ch, width, 0 if is_map else 2, dev) for _ in range(2)]
+
+    def env_vectors():
+        st = env.state()
+        deg = st["degree"].to(torch.float32)
+        return [torch.stack([deg, st["weight"][:, p].to(torch.float32)], 1) for p in range(2)]   # get_multy(p)
+
+    obs = env.reset()
+    for p in range(2):
+        rollouts[p].observations[0].copy_(obs[:, p])
+    probs = env_vectors()
+    games, t0 = 0, time.perf_counter()
+    stats = None
+    for it in range(iterations):
+        for step in range(num_steps):
+            if not is_map:
+                probs = env_vectors()
+            with torch.no_grad():
+                acts = [net.act(rollouts[p].observations[step]) if is_map
+                        else net.act(rollouts[p].observations[step], probs[p]) for p in range(2)]
+            actions = torch.cat(acts, 1).to(torch.int8)
+            obs, reward, done, _ = env.step(actions, autoreset=True)
+            masks = (1 - done.to(torch.float32)).unsqueeze(1)
+            games += int(done.sum())
+            for p in range(2):
+                rollouts[p].insert(obs[:, p], acts[p], reward[:, p:p + 1], masks, None if is_map else probs[p])
+        with torch.no_grad():
+            nxt = [net.get_value(rollouts[p].observations[-1]) if is_map
+                   else net.get_value(rollouts[p].observations[-1], probs[p]) for p in range(2)]
+        for p in range(2):
+            rollouts[p].compute_returns(nxt[p])
+        stats = brain.update(rollouts[0])
+        brain.update(rollouts[1])
+        for p in range(2):
+            rollouts[p].after_update()
+        if log_every and it % log_every == log_every - 1:
+            print(f"iter {it + 1}: games {games} loss {float(stats[0]):.4f} value {float(stats[1]):.4f} "
+                  f"entropy {float(stats[3]):.4f}", flush=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if save_path:
+        torch.save(brain.actor_critic.state_dict(), save_path)          # ACKTR.py:399
+    return dict(iterations=iterations, env_steps=iterations * num_steps * n_envs, games=games, seconds=dt,
+                env_steps_per_s=iterations * num_steps * n_envs / dt, updates=2 * iterations, brain=brain,
+                last_stats=None if stats is None else [float(s) for s in stats])
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('-m', required=False, help='model structure: map | mul', default="mul")
+    parser.add_argument('-r', required=False, help='reward condition number', default="3")
+    parser.add_argument('-p', required=False, help='policy coefficient', default="0.7")
+    parser.add_argument('-v', required=False, help='value coefficient', default="0.9")
+    parser.add_argument('-u', required=False, help='unique string', default='multi_test')
+    parser.add_argument('--envs', type=int, default=NUM_PROCESSES)
+    parser.add_argument('--width', type=int, default=MAP_WIDTH)
+    parser.add_argument('--iterations', type=int, default=1000)
+    a = parser.parse_args()
+    out = train(a.envs, a.width, a.m, a.r, a.iterations, log_every=20, args=a,
+                save_path=f"{folderName}/ACKTR_player{a.m}{a.u}.bak" if a.u else None)
+    print({k: v for k, v in out.items() if k != "brain"})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,200 @@
+"""Actor-critic networks of the reference's ACKTR path (Net/ACNet.py:6-397) on PyTorch-ROCm.
+
+Same class names, attribute names and parameter shapes (so `.bak` state_dicts interchange, also
+after KFACOptimizer has split the biases), same forward maths.  Differences, all deliberate:
+the shared 7-conv trunk is written once; the board side is a parameter (fc1 is sized from it,
+DQNNet.conv7_side) instead of the hard-wired 12x12; nothing calls `.cuda()` — tensors follow the
+module's device (ACNet.py:94,164,233,300 pin the reference to a GPU).
+
+  MapNet  (ACNet.py:335-397)  4 input planes (pop_up + prob_map), no env vector
+  TestNet (ACNet.py:59-126)   3 planes, env scalar concatenated before the heads (129 wide)
+  Net3    (ACNet.py:128-196)  3 planes, fc1 output gated by tanh(fc_env(scalar))
+  Net4    (ACNet.py:198-263)  3 planes, env scalar concatenated before fc2 (257 wide)
+  Mulnet  (ACNet.py:265-333)  3 planes, fc1 output gated by tanh(fc_env([degree, weight]))
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from config import MAP_WIDTH
+from Net.DQNNet import conv7_side
+
+
+class Net(nn.Module):
+    """Policy/value interface shared by all nets (ACNet.py:6-57)."""
+
+    wants_prob_plane = False        # MapNet: Game.main_loop feeds pop_up + prob_map (game.py:297)
+
+    def act(self, x, env_prob=None):
+        """Sample an action from softmax(actor logits) (ACNet.py:14-26)."""
+        value, actor_output = self(x, env_prob) if env_prob is not None else self(x)
+        return F.softmax(actor_output, dim=1).multinomial(num_samples=1)
+
+    def deterministic_act(self, x, env_prob=None):          # ACNet.py:28-31
+        value, actor_output = self(x, env_prob) if env_prob is not None else self(x)
+        return torch.argmax(actor_output, dim=1)
+
+    def get_value(self, x, env_prob=None):                  # ACNet.py:33-39
+        value, actor_output = self(x, env_prob) if env_prob is not None else self(x)
+        return value
+
+    def evaluate_actions(self, x, actions, env_prob=None):
+        """(value, log pi(a|s), mean entropy) for a batch (ACNet.py:41-54)."""
+        value, actor_output = self(x, env_prob) if env_prob is not None else self(x)
+        log_probs = F.log_softmax(actor_output, dim=1)
+        action_log_probs = log_probs.gather(1, actions.detach())
+        probs = F.softmax(actor_output, dim=1)
+        entropy = -(log_probs * probs).sum(-1).mean()
+        return value, action_log_probs, entropy
+
+    @staticmethod
+    def mish(x):                                            # ACNet.py:56-57
+        return x * torch.tanh(F.softplus(x))
+
+    # ---- the trunk every net shares (e.g. ACNet.py:97-116) -------------------------------
+    def _build_trunk(self, in_channels, width):
+        self.side = width + 2
+        self.conv1 = nn.Conv2d(in_channels, 32, 3, padding=1)
+        self.conv2 = nn.Conv2d(32, 32, 3, padding=1)
+        self.conv3 = nn.Conv2d(32, 32, 3, padding=1)
+        self.conv4 = nn.Conv2d(32, 64, 3, padding=1)
+        self.conv5 = nn.Conv2d(64, 64, 3, padding=1)
+        self.conv6 = nn.Conv2d(64, 64, 3, padding=1)
+        self.pool = nn.AvgPool2d(kernel_size=3, padding=1, stride=2)
+        self.conv7 = nn.Conv2d(64, 64, 7, padding=3, stride=2)
+        self.flat = 64 * conv7_side(self.side) ** 2
+        self.fc1 = nn.Linear(self.flat, 256)
+
+    def _trunk(self, x):
+        """conv1..conv7 + fc1 with dropout; returns the [B, 256] feature."""
+        a = self.activation
+        x = a(self.conv1(x))
+        idx = x
+        x = a(self.conv2(x))
+        x = a(self.conv3(x) + idx)
+        x = a(self.conv4(x))
+        idx = x
+        x = a(self.conv5(x))
+        x = a(self.conv6(x) + idx)
+        x = self.pool(x)
+        x = a(self.conv7(x))
+        x = x.reshape(-1, self.flat)
+        return self.dropout(a(self.fc1(x)))
+
+    def _heads(self, x):
+        a = self.activation
+        actor_output = self.actor2(a(self.actor1(x)))
+        critic_output = self.critic3(a(self.critic2(a(self.critic1(x)))))
+        return critic_output, actor_output
+
+    def _device(self):
+        return self.conv1.module.weight.device if hasattr(self.conv1, "module") else self.conv1.weight.device
+
+
+def _finish(net):
+    net.dropout = nn.Dropout(p=0.2)
+    net.activation = net.mish
+
+
+class TestNet(Net):
+    def __init__(self, width=MAP_WIDTH):
+        super(TestNet, self).__init__()
+        self._build_trunk(3, width)
+        self.fc2 = nn.Linear(256, 128)
+        self.actor1 = nn.Linear(129, 64)
+        self.actor2 = nn.Linear(64, 4)
+        self.critic1 = nn.Linear(129, 64)
+        self.critic2 = nn.Linear(64, 16)
+        self.critic3 = nn.Linear(16, 1)
+        _finish(self)
+
+    def forward(self, x, env_prob):
+        dev = self._device()
+        env_prob = env_prob.unsqueeze(1).detach().to(dev)
+        x = self._trunk(x.to(dev))
+        x = self.dropout(self.activation(self.fc2(x)))
+        return self._heads(torch.cat([x, env_prob], 1))
+
+
+class Net3(Net):
+    def __init__(self, width=MAP_WIDTH):
+        super(Net3, self).__init__()
+        self._build_trunk(3, width)
+        self.fc_env = nn.Linear(1, 256)
+        self.fc2 = nn.Linear(256, 128)
+        self.actor1 = nn.Linear(128, 32)
+        self.actor2 = nn.Linear(32, 4)
+        self.critic1 = nn.Linear(128, 32)
+        self.critic2 = nn.Linear(32, 8)
+        self.critic3 = nn.Linear(8, 1)
+        _finish(self)
+
+    def forward(self, x, env_prob):
+        dev = self._device()
+        env_prob = env_prob.unsqueeze(1).to(dev)
+        x = self._trunk(x.to(dev))
+        x = x.mul(torch.tanh(self.fc_env(env_prob)))
+        x = self.dropout(self.activation(self.fc2(x)))
+        return self._heads(x)
+
+
+class Net4(Net):
+    def __init__(self, width=MAP_WIDTH):
+        super(Net4, self).__init__()
+        self._build_trunk(3, width)
+        self.fc2 = nn.Linear(257, 128)
+        self.actor1 = nn.Linear(128, 64)
+        self.actor2 = nn.Linear(64, 4)
+        self.critic1 = nn.Linear(128, 64)
+        self.critic2 = nn.Linear(64, 16)
+        self.critic3 = nn.Linear(16, 1)
+        _finish(self)
+
+    def forward(self, x, env_prob):
+        dev = self._device()
+        env_prob = env_prob.unsqueeze(1).detach().to(dev)
+        x = self._trunk(x.to(dev))
+        x = self.dropout(self.activation(self.fc2(torch.cat([x, env_prob], 1))))
+        return self._heads(x)
+
+
+class Mulnet(Net):
+    def __init__(self, width=MAP_WIDTH):
+        super(Mulnet, self).__init__()
+        self._build_trunk(3, width)
+        self.fc_env = nn.Linear(2, 256)
+        self.fc2 = nn.Linear(256, 128)
+        self.actor1 = nn.Linear(128, 32)
+        self.actor2 = nn.Linear(32, 4)
+        self.critic1 = nn.Linear(128, 32)
+        self.critic2 = nn.Linear(32, 8)
+        self.critic3 = nn.Linear(8, 1)
+        _finish(self)
+
+    def forward(self, x, env_prob):
+        dev = self._device()
+        env_prob = env_prob.to(dev)
+        x = self._trunk(x.to(dev))
+        x = x.mul(torch.tanh(self.fc_env(env_prob)))
+        x = self.dropout(self.activation(self.fc2(x)))
+        return self._heads(x)
+
+
+class MapNet(Net):
+    wants_prob_plane = True
+
+    def __init__(self, width=MAP_WIDTH):
+        super(MapNet, self).__init__()
+        self._build_trunk(4, width)
+        self.fc2 = nn.Linear(256, 128)
+        self.actor1 = nn.Linear(128, 32)
+        self.actor2 = nn.Linear(32, 4)
+        self.critic1 = nn.Linear(128, 32)
+        self.critic2 = nn.Linear(32, 8)
+        self.critic3 = nn.Linear(8, 1)
+        _finish(self)
+
+    def forward(self, x):
+        x = self._trunk(x.to(self._device()))
+        x = self.dropout(self.activation(self.fc2(x)))
+        return self._heads(x)

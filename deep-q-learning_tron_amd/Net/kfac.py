@@ -1,0 +1,165 @@
+"""K-FAC natural-gradient optimiser for the ACKTR path — the algorithm of the reference's
+Net/kfac.py:99-254 (Kronecker-factored Fisher per layer, Martens & Grosse 2015; ACKTR, Wu et
+al. 2017), written for PyTorch-ROCm:
+
+* biases are split into `AddBias` layers so every factored module has exactly one parameter
+  (kfac.py:13-24,80-96) — this also fixes the checkpoint key layout `convK.module.weight`,
+  `convK.add_bias._bias`, which is kept;
+* per module, running Kronecker factors  A = E[a a^T]  (inputs, via a forward pre-hook) and
+  G = E[g g^T]  (output gradients of the sampled-Fisher loss, via a backward hook) with decay
+  0.99 (kfac.py:41-76,156-189).  Conv inputs are unfolded with `F.unfold` (one im2col kernel +
+  one GEMM on rocBLAS) — the fused `_extract_patches` the reference's TODO asks for
+  (kfac.py:9-12) — with the reference's normalisation by output positions;
+* every `Tf` steps the factors are eigendecomposed with `torch.linalg.eigh` (hipSOLVER on
+  ROCm; `torch.symeig`, kfac.py:220-223, no longer exists); eigenvalues <= 1e-6 are zeroed;
+* the update is  v = Q_g [ (Q_g^T grad Q_a) / (d_g d_a^T + damping) ] Q_a^T,  KL-clipped by
+  nu = min(1, sqrt(kl_clip / sum(v * grad * lr^2))), then applied by SGD with momentum 0.9 and
+  lr * (1 - momentum) (kfac.py:202-254).
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.optim as optim
+
+
+# the first conv's input needs no gradient; its hook still receives the output gradient, which is all we use
+warnings.filterwarnings("ignore", message="Full backward hook is firing when gradients are computed with respect to module outputs")
+
+
+class AddBias(nn.Module):
+    """A bias as its own layer; stored [C, 1] like the reference (kfac.py:13-24)."""
+
+    def __init__(self, bias):
+        super(AddBias, self).__init__()
+        self._bias = nn.Parameter(bias.unsqueeze(1))
+
+    def forward(self, x):
+        b = self._bias.t()
+        return x + (b.view(1, -1) if x.dim() == 2 else b.view(1, -1, 1, 1))
+
+
+class SplitBias(nn.Module):
+    """module (bias removed) followed by AddBias (kfac.py:80-96)."""
+
+    def __init__(self, module):
+        super(SplitBias, self).__init__()
+        self.module = module
+        self.add_bias = AddBias(module.bias.data)
+        self.module.bias = None
+
+    def forward(self, input):
+        return self.add_bias(self.module(input))
+
+
+def split_biases(model):
+    for name, child in model.named_children():
+        if getattr(child, "bias", None) is not None and not isinstance(child, AddBias):
+            model._modules[name] = SplitBias(child)
+        else:
+            split_biases(child)
+
+
+def cov_inputs(a, module):
+    """A-factor sample of one batch (kfac.py:41-58)."""
+    batch = a.size(0)
+    if isinstance(module, nn.Conv2d):
+        # im2col in batch chunks of <= ~256 MB so large rollouts (16 384 envs x 5 steps) stay bounded
+        oh = (a.size(2) + 2 * module.padding[0] - module.kernel_size[0]) // module.stride[0] + 1
+        ow = (a.size(3) + 2 * module.padding[1] - module.kernel_size[1]) // module.stride[1] + 1
+        d = a.size(1) * module.kernel_size[0] * module.kernel_size[1]
+        chunk = max(1, min(batch, (64 << 20) // max(d * oh * ow, 1)))
+        if chunk >= batch:
+            cols = F.unfold(a, module.kernel_size, padding=module.padding, stride=module.stride)   # [B, d, L]
+            rows = cols.transpose(1, 2).reshape(-1, d) / (oh * ow)
+            return rows.t() @ (rows / batch)
+        acc = torch.zeros(d, d, device=a.device, dtype=a.dtype)
+        for i in range(0, batch, chunk):
+            cols = F.unfold(a[i:i + chunk], module.kernel_size, padding=module.padding, stride=module.stride)
+            rows = cols.transpose(1, 2).reshape(-1, d) / (oh * ow)
+            acc.addmm_(rows.t(), rows / batch)
+        return acc
+    if isinstance(module, AddBias):
+        return torch.ones(1, 1, device=a.device, dtype=a.dtype)      # ones(B,1)^T ones(B,1) / B
+    return a.t() @ (a / batch)
+
+
+def cov_grads(g, module):
+    """G-factor sample of one batch (kfac.py:61-76)."""
+    batch = g.size(0)
+    if isinstance(module, nn.Conv2d):
+        oh, ow = g.size(2), g.size(3)
+        g = g.permute(0, 2, 3, 1).reshape(-1, g.size(1)) * (oh * ow)
+    elif isinstance(module, AddBias):
+        g = g.reshape(g.size(0), g.size(1), -1).sum(-1)
+    g_ = g * batch
+    return g_.t() @ (g_ / g.size(0))
+
+
+class KFACOptimizer(optim.Optimizer):
+    def __init__(self, model, lr=0.25, momentum=0.9, stat_decay=0.99, kl_clip=0.001, damping=1e-2, weight_decay=0,
+                 fast_cnn=False, Ts=1, Tf=10):
+        if fast_cnn:
+            raise NotImplementedError("fast_cnn factors are not used by the reference's trainer")
+        split_biases(model)
+        super(KFACOptimizer, self).__init__(model.parameters(), dict())
+        self.model = model
+        self.modules = [m for m in model.modules() if isinstance(m, (nn.Linear, nn.Conv2d, AddBias))]
+        for m in self.modules:
+            assert len(list(m.parameters(recurse=False))) == 1, "one parameter per factored module"
+            m.register_forward_pre_hook(self._save_input)
+            m.register_full_backward_hook(self._save_grad_output)
+        self.steps = 0
+        self.acc_stats = False
+        self.m_aa, self.m_gg = {}, {}
+        self.Q_a, self.Q_g, self.d_a, self.d_g = {}, {}, {}, {}
+        self.momentum, self.stat_decay, self.lr = momentum, stat_decay, lr
+        self.kl_clip, self.damping, self.weight_decay = kl_clip, damping, weight_decay
+        self.Ts, self.Tf = Ts, Tf
+        self.optim = optim.SGD(model.parameters(), lr=self.lr * (1 - self.momentum), momentum=self.momentum)
+
+    # ---- factor statistics -----------------------------------------------------------------
+    def _running(self, store, module, sample):
+        if self.steps == 0:
+            store[module] = sample.clone()
+        store[module].mul_(self.stat_decay).add_(sample, alpha=1 - self.stat_decay)      # kfac.py:79-83
+
+    def _save_input(self, module, inputs):
+        if torch.is_grad_enabled() and self.steps % self.Ts == 0:
+            with torch.no_grad():
+                self._running(self.m_aa, module, cov_inputs(inputs[0].detach(), module))
+
+    def _save_grad_output(self, module, grad_input, grad_output):
+        if self.acc_stats:
+            with torch.no_grad():
+                self._running(self.m_gg, module, cov_grads(grad_output[0].detach(), module))
+
+    # ---- the step -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self):
+        if self.weight_decay > 0:
+            for p in self.model.parameters():
+                p.grad.add_(p, alpha=self.weight_decay)
+        la = self.damping + self.weight_decay
+        updates = {}
+        for m in self.modules:
+            p = next(m.parameters(recurse=False))
+            if self.steps % self.Tf == 0:
+                self.d_a[m], self.Q_a[m] = torch.linalg.eigh(self.m_aa[m])
+                self.d_g[m], self.Q_g[m] = torch.linalg.eigh(self.m_gg[m])
+                self.d_a[m].mul_((self.d_a[m] > 1e-6).float())
+                self.d_g[m].mul_((self.d_g[m] > 1e-6).float())
+            grad = p.grad.reshape(p.grad.size(0), -1) if isinstance(m, nn.Conv2d) else p.grad
+            v1 = self.Q_g[m].t() @ grad @ self.Q_a[m]
+            v2 = v1 / (self.d_g[m].unsqueeze(1) * self.d_a[m].unsqueeze(0) + la)
+            updates[p] = (self.Q_g[m] @ v2 @ self.Q_a[m].t()).view_as(p.grad)
+        vg_sum = 0.0
+        for p in self.model.parameters():
+            vg_sum = vg_sum + (updates[p] * p.grad * self.lr * self.lr).sum()
+        nu = min(1.0, math.sqrt(self.kl_clip / float(vg_sum)))
+        for p in self.model.parameters():
+            p.grad.copy_(updates[p]).mul_(nu)
+        self.optim.step()
+        self.steps += 1

@@ -1,6 +1,12 @@
 """Constants of the reference's config.py (config.py:1-41), same names so `from config import *`
 keeps working.  Values are the reference's; grid size is a real parameter everywhere else."""
-import torch
+import os
+
+# MIOpen's default exhaustive "find" costs tens of seconds for every new (batch, shape) the CNN sees;
+# the trainers change batch sizes freely, so use the heuristic immediate mode unless the user chose one.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+import torch  # noqa: E402
 
 device = 'cuda' if torch.cuda.is_available() else 'cpu'   # config.py:3
 

@@ -404,9 +404,123 @@ def gen_net():
     print("net: Q", q.shape, "loss", loss, "params", sum(int(np.prod(v)) for v in shapes.values()))
 
 
+# --------------------------------------------------------------------------
+# G-acktr: actor-critic nets, RolloutStorage returns, A2C and ACKTR (KFAC) updates
+# --------------------------------------------------------------------------
+def gen_acktr():
+    """Harness patches (the reference's ACKTR path assumes a GPU and an old torch):
+    Tensor.cuda() is the identity here (ACNet.py:94,164,233,300 call it unconditionally),
+    torch.symeig (removed in torch 2) is served by torch.linalg.eigh (kfac.py:220-223),
+    torch.utils.tensorboard is a stub.  Nothing else is changed."""
+    import collections
+    import json
+    import warnings
+    import torch
+    warnings.filterwarnings("ignore")
+    sys.path.insert(0, OUT)
+    from netgen import det_state_dict
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.symeig = lambda A, eigenvectors=True: torch.linalg.eigh(A)
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = type("SummaryWriter", (), {"__init__": lambda self, *a, **k: None,
+                                                  "add_scalar": lambda self, *a, **k: None})
+    sys.modules["torch.utils.tensorboard"] = tb
+    import Net.ACNet as RA
+    import ACKTR as RK
+
+    enc = np.load(os.path.join(OUT, "encode.npz"))
+    planes = enc["planes_10"].astype(np.float32)                  # [32, 2, 3, 12, 12]
+    rs = np.random.RandomState(17)
+    out = {}
+    B = 6
+    x3 = planes[:B, 0]
+    x4 = np.concatenate([x3, np.full((B, 1, 12, 12), 5.0, np.float32)], 1)
+    env1 = rs.uniform(-0.3, 0.6, B).astype(np.float32)            # a rate-like scalar
+    env2 = np.stack([rs.randint(-30, 31, B), rs.randint(40, 102, B)], 1).astype(np.float32)   # get_multy
+    out.update(x3=x3, x4=x4, env1=env1, env2=env2)
+    shapes_all = {}
+    for name, cls, args in (("MapNet", RA.MapNet, (x4,)), ("TestNet", RA.TestNet, (x3, env1)),
+                            ("Net3", RA.Net3, (x3, env1)), ("Net4", RA.Net4, (x3, env1)),
+                            ("Mulnet", RA.Mulnet, (x3, env2))):
+        net = cls()
+        shapes = collections.OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+        shapes_all[name] = {k: list(v) for k, v in shapes.items()}
+        net.load_state_dict(det_state_dict(shapes, salt=3))
+        net.eval()
+        with torch.no_grad():
+            value, logits = net(*[torch.from_numpy(a) for a in args])
+            acts = torch.from_numpy(rs.randint(0, 4, (B, 1)).astype(np.int64))
+            v2, lp, ent = net.evaluate_actions(*([torch.from_numpy(args[0]), acts] +
+                                                 [torch.from_numpy(a) for a in args[1:]]))
+        out[name + "_value"] = value.numpy()
+        out[name + "_logits"] = logits.numpy()
+        out[name + "_acts"] = acts.numpy()
+        out[name + "_logp"] = lp.numpy()
+        out[name + "_entropy"] = np.float64(float(ent))
+    out["shapes_json"] = np.array(json.dumps(shapes_all))
+
+    # rollouts + updates, reference globals: 16 processes x 5 steps
+    T, N = RK.NUM_ADVANCED_STEP, RK.NUM_PROCESSES
+    idx = rs.randint(0, 32, size=(T + 1, N))
+    pl = rs.randint(0, 2, size=(T + 1, N))
+    obs3 = planes[idx, pl]                                        # [T+1, N, 3, 12, 12]
+    obs4 = np.concatenate([obs3, np.full((T + 1, N, 1, 12, 12), 5.0, np.float32)], 2)
+    actions = rs.randint(0, 4, size=(T, N, 1)).astype(np.int64)
+    rewards = rs.choice([-1.0, 20.0, -10.0, 0.0], size=(T, N, 1), p=[.7, .1, .1, .1]).astype(np.float32)
+    masks = (rs.rand(T + 1, N, 1) > 0.25).astype(np.float32)
+    probs = np.stack([rs.randint(-30, 31, (T, N)), rs.randint(40, 102, (T, N))], 2).astype(np.float32)
+    next_value = rs.randn(N, 1).astype(np.float32)
+    out.update(r_obs3=obs3, r_actions=actions, r_rewards=rewards, r_masks=masks, r_probs=probs, r_next=next_value)
+    probe = ["conv1.module.weight", "conv1.add_bias._bias", "conv7.module.weight", "fc1.module.weight",
+             "actor2.module.weight", "critic3.add_bias._bias"]
+
+    def fill(ro, obs, with_probs):
+        ro.observations.copy_(torch.from_numpy(obs))
+        ro.actions.copy_(torch.from_numpy(actions))
+        ro.rewards.copy_(torch.from_numpy(rewards))
+        ro.masks.copy_(torch.from_numpy(masks))
+        if with_probs:
+            ro.probs.copy_(torch.from_numpy(probs))
+        ro.compute_returns(torch.from_numpy(next_value))
+        return ro
+
+    args_ns = types.SimpleNamespace(p=None, v=None)
+    for tag, cls, obs, with_probs in (("map", RA.MapNet, obs4, False), ("mul", RA.Mulnet, obs3, True)):
+        RK.Nettype = cls if with_probs else RK.maptype            # the module global Brain.update branches on
+        for mode in ("a2c", "acktr"):
+            net = cls()
+            brain = RK.Brain(net, args_ns, acktr=(mode == "acktr"))
+            shapes = collections.OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+            net.load_state_dict(det_state_dict(shapes, salt=4))
+            net.dropout.p = 0.0                                   # deterministic train mode
+            ro = fill(RK.RolloutStorage(T, N), obs, with_probs)
+            if tag == "map" and mode == "a2c":
+                out["returns"] = ro.returns.numpy().copy()
+            for k in range(2 if mode == "acktr" else 1):
+                torch.manual_seed(1000 + k)                       # value_noise of the sampled Fisher
+                res = brain.update(ro)
+                out[f"{tag}_{mode}_stats{k}"] = np.array([float(t) for t in res], np.float64)
+                sd = net.state_dict()
+                for name in probe:
+                    key = name if name in sd else name.replace(".module.weight", ".weight").replace(".add_bias._bias", ".bias")
+                    out[f"{tag}_{mode}_u{k}_{name}"] = sd[key].detach().numpy().reshape(-1)[:384].copy()
+            if mode == "acktr":
+                opt = brain.optimizer
+                mods = dict(net.named_modules())
+                for mn in ("conv1.module", "conv7.module", "fc1.module", "actor2.add_bias"):
+                    out[f"{tag}_maa_{mn}"] = opt.m_aa[mods[mn]].numpy().reshape(-1)[:256].copy()
+                    out[f"{tag}_mgg_{mn}"] = opt.m_gg[mods[mn]].numpy().reshape(-1)[:256].copy()
+                out[f"{tag}_shapes_split"] = np.array(json.dumps({k: list(v) for k, v in shapes.items()}))
+    np.savez_compressed(os.path.join(OUT, "acktr.npz"), **out)
+    print("acktr: done;", {k: out[k].tolist() for k in out if k.endswith("stats0")})
+
+
 def main():
     if "--net-only" in sys.argv:
         gen_net()
+        return
+    if "--acktr-only" in sys.argv:
+        gen_acktr()
         return
     gen_step_exhaustive()
     gen_episodes("episodes_none_4", 4, 300, 101, None, p_safe=0.6, keep_steps=True)
@@ -425,6 +539,7 @@ def main():
     gen_reset()
     gen_reward()
     gen_net()
+    gen_acktr()
 
 
 if __name__ == "__main__":

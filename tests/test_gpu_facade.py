@@ -203,3 +203,14 @@ def test_batched_rating_sweep():
     for r in res:
         assert r["p1_win"] + r["p2_win"] + r["draw"] == 400
         assert 0.3 < r["p1_rate"] < 0.7           # symmetric random play
+
+
+def test_acktr_batched_trainer_runs():
+    """ACKTR.train on VecTron: MapNet (planes4 from the kernel) with K-FAC, and Mulnet with A2C."""
+    import ACKTR
+    out = ACKTR.train(n_envs=64, width=10, model="map", reward="1", iterations=3, acktr=True, seed=3)
+    assert out["env_steps"] == 3 * 5 * 64 and out["updates"] == 6 and out["games"] > 0
+    assert all(np.isfinite(out["last_stats"]))
+    assert out["brain"].optimizer.steps == 6
+    out = ACKTR.train(n_envs=48, width=6, model="mul", reward="3", iterations=2, acktr=False, gamemode="temper", seed=4)
+    assert out["env_steps"] == 2 * 5 * 48 and all(np.isfinite(out["last_stats"]))
