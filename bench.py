@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--obs", default="codes", choices=["codes", "planes3", "planes4"])
     ap.add_argument("--mode", default="none", choices=["none", "ice", "temper"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--incremental", action="store_true",
+                    help="secondary variant: in-place observation update (only touched cells and restarted boards "
+                         "are written); reported under its own label, not comparable with the default line")
     ap.add_argument("--dqn", action="store_true",
                     help="secondary metric: DQN transitions/s of the batched DDQN trainer (BASELINE configs[1] by "
                          "default: 4096 envs 10x10; use --envs/--width for others)")
@@ -146,7 +149,7 @@ def main():
             dist.init_process_group(backend)
 
     env = VecTron(args.envs, args.width, mode=None if args.mode == "none" else args.mode, seed=0x5EED, rank=rank,
-                  obs_format=args.obs)
+                  obs_format=args.obs, incremental=args.incremental)
     env.reset()
 
     def barrier():
@@ -181,8 +184,15 @@ def main():
             b_alg = g + 32 + 2 * (3 if args.obs == "planes3" else 4) * g * 4
         achieved = b_alg * args.envs / (kern_ms * 1e-3) / 1e9
         hbm_bytes, hbm_src = pmc_traffic(args.envs, args.width, args.obs, args.mode)
+        if args.incremental:
+            # bytes this variant needs per env-step: state words + outputs (~70 B), 2 cells read, 8 written,
+            # and both planes (2G) for the ~36 % of envs that restart under random play
+            g = (args.width + 2) ** 2
+            b_alg = 80 + int(0.36 * 2 * g)
+            achieved = b_alg * args.envs / (kern_ms * 1e-3) / 1e9
+            hbm_bytes = hbm_src = None
         out = {
-            "metric": "env-steps/sec",
+            "metric": "env-steps/sec" if not args.incremental else "env-steps/sec (incremental observation update)",
             "value": total_env_steps / wall,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -203,7 +213,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if hbm_bytes is None else hbm_bytes / (kern_ms * 1e-3) / 1e9,
                          "traffic_bytes_per_launch": hbm_bytes, "traffic_source": hbm_src,
-                         "kernel": "k_obs<step> (observation-is-state, int8 codes)", "kernel_ms": kern_ms,
+                         "kernel": ("k_inc (in-place update: touched cells + restarted boards only)" if args.incremental
+                                    else "k_obs<step> (observation-is-state, int8 codes)"), "kernel_ms": kern_ms,
                          "alg_bytes_per_env_step": b_alg, "alg_bytes_per_launch": b_alg * args.envs},
         }
         if world == 1 and not args.no_cpu_baseline:

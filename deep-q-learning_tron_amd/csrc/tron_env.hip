@@ -699,6 +699,181 @@ __global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, ui
     }
 }
 
+// ------------------------------------------------------------ incremental step --
+// Observation-is-state, TRON_STEP_INCREMENTAL: the attached planes already hold the previous
+// observation, and a move changes at most 4 cells per plane, so only those cells are written;
+// only boards that restart are rewritten in full.  No tile, no LDS staging: ONE ENV PER LANE
+// (wave 0 of each 64-env workgroup) reads its state words and two target cells, decides, and
+// stores 8 bytes; the four waves then share the rewrites of the restarting boards (coalesced
+// 16-byte stores from an LDS template).
+// HBM traffic per env-step is ~100 B + 2G per restart instead of 3G — this is a different
+// contract from "both planes written every step" and is reported under its own label.
+template <int DUMMY>
+__global__ __launch_bounds__(BLOCK) void k_inc(Params P, uint32_t cpe, const int8_t *__restrict__ actions,
+                                               uint32_t flags, StepOut out)
+{
+    // 256 threads per 64 envs: wave 0 decides (lane = env), wave 1 draws the speculative next start,
+    // then all four waves share the rewrites of the restarting boards.
+    __shared__ uint4 tmpl[640];                                   // fresh board as codes (same for both players)
+    __shared__ uint4 rec_rs[WAVE];                                // new rs4 of an env, should it restart
+    __shared__ uint32_t rec_nstart[WAVE];                         // its cached start positions (rs4.z)
+    __shared__ uint32_t rec_heads[WAVE];                          // restart word: 0x80000000 | head1 | head2 << 14
+    const int G = P.G, S = P.S, W = P.W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int env = blockIdx.x * WAVE + lane;
+    const bool mine = env < P.N;
+    const bool autoreset = (flags & TRON_STEP_AUTORESET) != 0u;
+
+    uint4 st = make_uint4(0u, META_DONE, 0u, 0u), rs = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t act = 0u;
+    if (mine && wave == 0) {
+        st = P.st4[env];
+        if (actions) act = reinterpret_cast<const uint16_t *>(actions)[env];
+    }
+    if (mine && wave == 1 && autoreset) rs = P.rs4[env];
+    if (autoreset)
+        for (uint32_t d = (uint32_t)tid; d < cpe * 16u; d += BLOCK)
+            reinterpret_cast<int8_t *>(tmpl)[d] = (d < (uint32_t)G) ? (P.fresh[d] == TRON_EMPTY ? (int8_t)1 : (int8_t)-1) : (int8_t)0;
+    if (wave == 1 && autoreset) {
+        rec_nstart[lane] = rs.z;
+        if (mine) {
+            const NewGame ng = make_game(P.seed, P.stream, W, P.fair, (uint32_t)env, rs.y + 1u);
+            rec_rs[lane] = make_uint4(rs.w, rs.y + 1u, pack_pos(ng.r1, ng.c1, ng.r2, ng.c2), pack_envp(ng.w0, ng.w1, ng.degree));
+        }
+    }
+
+    bool restart = false, done = false, stepped = false;
+    int winner = 0;
+    uint4 new_st = st;
+    if (wave == 0) {
+        int8_t *o1 = P.obs_state + (size_t)(mine ? env : 0) * 2u * G, *o2 = o1 + G;
+        uint32_t m = st.y;
+        int r[2] = {(int)(int8_t)(st.x), (int)(int8_t)(st.x >> 16)};
+        int c[2] = {(int)(int8_t)(st.x >> 8), (int)(int8_t)(st.x >> 24)};
+        done = (m & META_DONE) != 0;
+        stepped = mine && !done;
+        winner = (int)((m >> 4) & 3u);
+        float rw0 = 0.0f, rw1 = 0.0f;
+        if (stepped) {
+            int a[2];
+            if (!actions) {
+                uint32_t x[4];
+                philox4x32_10((uint32_t)env, st.w, RNG_STEP, 0u, P.seed, P.stream, x);
+                a[0] = (int)(x[0] & 3u);
+                a[1] = (int)(x[1] & 3u);
+            } else {
+                a[0] = (int)(act & 3u);
+                a[1] = (int)((act >> 8) & 3u);
+            }
+            int old[2], f[2], tf[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                old[p] = cell_index(S, r[p], c[p]);
+                r[p] += (a[p] == 0) ? -1 : (a[p] == 2) ? 1 : 0;          // player.py:124-132
+                c[p] += (a[p] == 1) ? 1 : (a[p] == 3) ? -1 : 0;
+                f[p] = cell_index(S, r[p], c[p]);
+            }
+            tf[0] = o1[f[0]];
+            tf[1] = o1[f[1]];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {                                // game.py:155-156: heads are bodies by now
+                if (f[p] == old[0]) tf[p] = -2;
+                if (f[p] == old[1]) tf[p] = -3;
+            }
+            if (f[1] == f[0]) tf[1] = 10;                                // game.py:205-214: P2 tests after P1's head is down
+            uint32_t alive = m & 3u;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const bool oob = r[p] < 0 || c[p] < 0 || r[p] >= W || c[p] >= W;
+                if (oob || tf[p] != 1) alive &= ~(1u << p);
+            }
+            const int n_alive = (int)(alive & 1u) + (int)((alive >> 1) & 1u);
+            if (n_alive <= 1) {                                          // game.py:264-275
+                if (n_alive == 1 && (r[0] != r[1] || c[0] != c[1])) winner = (alive & 1u) ? 1 : 2;
+                done = true;
+            }
+            if (!done) {
+                rw0 = rw1 = P.r_index ? (float)st.z : P.r_step;
+            } else if (winner == 0) {
+                rw0 = rw1 = P.r_draw;
+            } else {
+                rw0 = (winner == 1) ? P.r_win : P.r_lose;
+                rw1 = (winner == 2) ? P.r_win : P.r_lose;
+            }
+            new_st = make_uint4(pack_pos(r[0], c[0], r[1], c[1]),
+                                alive | (done ? META_DONE : 0u) | ((uint32_t)winner << 4) | ((uint32_t)(a[0] + 1) << 8) |
+                                    ((uint32_t)(a[1] + 1) << 12),
+                                st.z + 1u, st.w + 1u);
+            if (!(done && autoreset)) {
+                // the four cells, reference order: bodies, P1's head, P2's head — in both planes
+                o1[old[0]] = -2; o2[old[0]] = -3;
+                o1[old[1]] = -3; o2[old[1]] = -2;
+                o1[f[0]] = 10;   o2[f[0]] = -10;
+                o1[f[1]] = -10;  o2[f[1]] = 10;
+                P.st4[env] = new_st;
+            }
+        }
+        if (mine) {
+            if (out.done) out.done[env] = (int8_t)done;
+            if (out.winner) out.winner[env] = (int8_t)winner;
+            if (out.reward) reinterpret_cast<float2 *>(out.reward)[env] = make_float2(rw0, rw1);
+        }
+        if (out.totals) {
+            const int wn = (stepped && done) ? winner : -1;
+            const unsigned long long bs = __ballot(stepped);
+            const unsigned long long b1 = __ballot(wn == 1), b2 = __ballot(wn == 2), b0 = __ballot(wn == 0);
+            if (lane == 0) {
+                if (bs) atomicAdd(&out.totals[0], (unsigned long long)__popcll(bs));
+                if (b1) atomicAdd(&out.totals[1], (unsigned long long)__popcll(b1));
+                if (b2) atomicAdd(&out.totals[2], (unsigned long long)__popcll(b2));
+                if (b0) atomicAdd(&out.totals[3], (unsigned long long)__popcll(b0));
+            }
+        }
+        restart = mine && done && autoreset;
+    }
+    __syncthreads();                                                 // template, rec_rs, rec_nstart are in LDS
+    if (wave == 0) {
+        uint32_t hw = 0u;
+        if (restart) {                                               // ACKTR.py:307-310; start cached one restart ago
+            const uint32_t ns = rec_nstart[lane];
+            P.st4[env] = make_uint4(ns, META_ALIVE0 | META_ALIVE1, 0u, new_st.w);
+            P.rs4[env] = rec_rs[lane];
+            hw = 0x80000000u | (uint32_t)cell_index(S, (int)(int8_t)(ns), (int)(int8_t)(ns >> 8)) |
+                 ((uint32_t)cell_index(S, (int)(int8_t)(ns >> 16), (int)(int8_t)(ns >> 24)) << 14);
+        }
+        rec_heads[lane] = hw;
+    }
+    if (!autoreset) return;
+    __syncthreads();
+
+    // ---- restarting boards: both planes from the template, dealt round-robin to the four waves
+    const uint32_t my_hw = rec_heads[lane];
+    unsigned long long rmask = __ballot((my_hw >> 31) != 0u);
+    int nth = 0;
+    while (rmask) {
+        const int e = __ffsll((long long)rmask) - 1;
+        rmask &= rmask - 1;
+        if ((nth++ & 3) != wave) continue;
+        const uint32_t hw = rec_heads[e];
+        const uint32_t a1 = hw & 0x3FFFu, a2 = (hw >> 14) & 0x3FFFu;
+        int8_t *q = P.obs_state + (size_t)(blockIdx.x * WAVE + e) * 2u * G;
+        for (uint32_t j = (uint32_t)lane; j < 2u * cpe; j += WAVE) {      // chunk k of plane pl
+            const uint32_t pl = j >= cpe ? 1u : 0u, k = j - pl * cpe, cc = k * 16u;
+            uint4 t = tmpl[k];
+            const uint32_t d1 = a1 - cc, d2 = a2 - cc;
+            // template head cells are EMPTY (1): XOR to own head 10 / enemy head -10 per plane (game.py:90-91)
+            const uint32_t x1 = (uint32_t)(0x01 ^ (pl ? 0xF6 : 0x0A)) << ((d1 & 3u) * 8u);
+            const uint32_t x2 = (uint32_t)(0x01 ^ (pl ? 0x0A : 0xF6)) << ((d2 & 3u) * 8u);
+            t.x ^= (d1 < 4u ? x1 : 0u) ^ (d2 < 4u ? x2 : 0u);
+            t.y ^= (d1 - 4u < 4u ? x1 : 0u) ^ (d2 - 4u < 4u ? x2 : 0u);
+            t.z ^= (d1 - 8u < 4u ? x1 : 0u) ^ (d2 - 8u < 4u ? x2 : 0u);
+            t.w ^= (d1 - 12u < 4u ? x1 : 0u) ^ (d2 - 12u < 4u ? x2 : 0u);
+            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+            store_chunk<true>(q + (size_t)pl * G + cc, min(16, G - (int)cc), w);
+        }
+    }
+}
+
 // observation-is-state helpers: board images / other formats from the attached planes
 __global__ void k_obs_to_grid(Params P, int8_t *__restrict__ grid_out)
 {
@@ -1103,12 +1278,20 @@ int tron_step_encode(tron_handle h, const int8_t *actions, const float *uniforms
 {
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
     if ((obs_fmt != TRON_OBS_NONE) != (obs != nullptr)) return TRON_ERR_BAD_ARG;
-    if (flags & ~TRON_STEP_AUTORESET) return TRON_ERR_BAD_ARG;
+    if (flags & ~(TRON_STEP_AUTORESET | TRON_STEP_INCREMENTAL)) return TRON_ERR_BAD_ARG;
+    if ((flags & TRON_STEP_INCREMENTAL) && !h->P.obs_state) return TRON_ERR_UNSUPPORTED;
     StepOut out{out_done, out_winner, out_reward, nullptr};
     if (h->P.obs_state) {
         if (obs_fmt == TRON_OBS_CODES_I8 && obs != h->P.obs_state) return TRON_ERR_BAD_ARG;   // the attached buffer is the output
         if (obs_fmt < TRON_OBS_NONE || obs_fmt > TRON_OBS_PLANES4_F32) return TRON_ERR_BAD_ARG;
-        const int rc = launch_obs<true>(h, actions, flags, out, S_(stream));
+        int rc;
+        if (flags & TRON_STEP_INCREMENTAL) {
+            hipLaunchKernelGGL((k_inc<0>), dim3((h->P.N + WAVE - 1) / WAVE), dim3(BLOCK), 0, S_(stream), h->P, h->cpe,
+                               actions, flags, out);
+            rc = launch_status();
+        } else {
+            rc = launch_obs<true>(h, actions, flags, out, S_(stream));
+        }
         if (rc != TRON_OK || obs_fmt == TRON_OBS_NONE || obs_fmt == TRON_OBS_CODES_I8) return rc;
         return obs_planes(h, obs_fmt, obs, S_(stream));
     }

@@ -15,6 +15,7 @@ OBS_NONE, OBS_CODES_I8, OBS_PLANES3_F32, OBS_PLANES4_F32 = 0, 1, 2, 3
 OBS = {None: OBS_NONE, "none": OBS_NONE, "codes": OBS_CODES_I8, "planes3": OBS_PLANES3_F32,
        "planes4": OBS_PLANES4_F32}
 STEP_AUTORESET = 1
+STEP_INCREMENTAL = 2
 
 _vp, _i32, _i64, _u32, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_double
 

@@ -21,7 +21,7 @@ REWARDS = {
 
 class VecTron:
     def __init__(self, n_envs, width=10, mode=None, fair=False, seed=0x5EED, rank=0, device=None,
-                 obs_format="codes", reward="ddqn", slide=None, obs_is_state=True):
+                 obs_format="codes", reward="ddqn", slide=None, obs_is_state=True, incremental=False):
         if not torch.cuda.is_available():
             raise nat.TronNativeError("VecTron needs a HIP device (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -49,6 +49,9 @@ class VecTron:
         # it is then read-only for the caller — clone what must outlive the next step
         self.obs_is_state = bool(obs_is_state and mode in (None, "none") and self._fmt == nat.OBS_CODES_I8
                                  and self.W % 2 == 0)
+        # incremental=True (needs obs_is_state): steps write only the cells a move touches and the boards
+        # that restart, instead of rewriting both planes — same observations, far less traffic
+        self.incremental = bool(incremental and self.obs_is_state)
         if self.obs_is_state:
             with torch.cuda.device(self.device):
                 nat.check(self._lib.tron_attach_obs_state(self._h, nat.ptr(self.obs), nat.stream_ptr()),
@@ -123,7 +126,7 @@ class VecTron:
         the next call."""
         a = self._dev_arg(actions, torch.int8, (self.N, 2))
         u = self._dev_arg(uniforms, torch.float32, (self.N, 2))
-        flags = nat.STEP_AUTORESET if autoreset else 0
+        flags = (nat.STEP_AUTORESET if autoreset else 0) | (nat.STEP_INCREMENTAL if self.incremental else 0)
         with torch.cuda.device(self.device):
             nat.check(self._lib.tron_step_encode(self._h, nat.ptr(a), nat.ptr(u), flags, self._fmt,
                                                  nat.ptr(self.obs), nat.ptr(self.done), nat.ptr(self.winner),
@@ -135,7 +138,8 @@ class VecTron:
         ctypes arguments bound once — for launch loops where Python argument handling per call
         would otherwise dominate a ~25 us kernel.  Same outputs as step()."""
         fn = self._lib.tron_step_encode
-        args = (self._h, None, None, nat.STEP_AUTORESET if autoreset else 0, self._fmt, nat.ptr(self.obs),
+        flags = (nat.STEP_AUTORESET if autoreset else 0) | (nat.STEP_INCREMENTAL if self.incremental else 0)
+        args = (self._h, None, None, flags, self._fmt, nat.ptr(self.obs),
                 nat.ptr(self.done), nat.ptr(self.winner), nat.ptr(self.reward), nat.stream_ptr())
 
         def launch():

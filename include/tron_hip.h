@@ -54,6 +54,9 @@ enum {
 
 /* tron_step_encode flags */
 #define TRON_STEP_AUTORESET 1u /* ACKTR.py:294-314: finished env -> fresh make_game, obs = new game */
+#define TRON_STEP_INCREMENTAL 2u /* observation-is-state only: update the attached planes in place — write just
+                                  * the <=4 cells a move touches and the boards that restart, instead of
+                                  * rewriting both planes.  Same results, different traffic contract.       */
 
 typedef struct tron_env *tron_handle;
 

@@ -122,6 +122,9 @@ CASES = [
     (64, 10, None, False, True, "grid"),          # same, forced onto the board-owning kernel (k_tile)
     (70, 24, None, True, False, "grid"),
     (200, 6, None, True, False, "acktr"),         # observation-is-state, no autoreset, masked resets
+    (300, 10, None, False, True, "inc"),          # incremental in-place update (TRON_STEP_INCREMENTAL)
+    (77, 24, None, True, True, "inc"),
+    (150, 8, None, False, False, "inc"),
     (100, 10, "temper", False, True, "acktr"),     # tail tile (100 = 64 + 36)
     (37, 4, "ice", True, True, "dqn"),             # fair starts, step-index reward
     (130, 7, "ice", False, True, "ddqn"),          # odd W: generic (G % 4 != 0) path
@@ -136,11 +139,12 @@ CASES = [
 def test_hip_vs_oracle_philox(T, N, W, mode, fair, autoreset, reward):
     tv, oracle = T
     ois = reward != "grid"
-    reward = "ddqn" if reward == "grid" else reward
+    inc = reward == "inc"
+    reward = "ddqn" if reward in ("grid", "inc") else reward
     table = {"ddqn": oracle.REWARD_DDQN, "dqn": oracle.REWARD_DQN, "acktr": oracle.REWARD_ACKTR}[reward]
     env = tv.VecTron(N, W, mode=mode, fair=fair, seed=1234, rank=3, obs_format="codes", reward=reward, slide=0.3,
-                     obs_is_state=ois)
-    assert env.obs_is_state == (ois and mode is None and W % 2 == 0)
+                     obs_is_state=ois, incremental=inc)
+    assert env.obs_is_state == (ois and mode is None and W % 2 == 0) and env.incremental == inc
     ref = oracle.VecOracle(N, W, mode=mode, seed=1234, stream=3, fair=fair, reward=table, slide=0.3)
     obs0 = env.reset()
     ref.reset_all()
@@ -214,6 +218,23 @@ def test_step_without_obs_and_totals(T):
 
 
 # ----------------------------------------------------- full size: properties --
+def test_full_size_incremental_matches_full_rewrite(T):
+    """65 536 x 24x24: the in-place incremental step and the full-rewrite step stay identical."""
+    tv, _ = T
+    N, W = 65536, 24
+    a = tv.VecTron(N, W, seed=99, obs_format="codes")
+    b = tv.VecTron(N, W, seed=99, obs_format="codes", incremental=True)
+    a.reset()
+    b.reset()
+    for _ in range(12):
+        oa, ra, da, wa = a.step()
+        ob, rb, db, wb = b.step()
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(wa, wb)
+    sa, sb = a.state(), b.state()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    assert torch.equal(a.grid(), b.grid())
+
+
 def test_full_size_65536x24_properties(T):
     """BASELINE config 3 size.  Size-independent checks: (a) the first 2048 envs equal the
     oracle run on the same seed (Philox is keyed by env index, so a prefix is self-contained);
