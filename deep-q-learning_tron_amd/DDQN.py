@@ -176,8 +176,26 @@ class Agent():
                 target_param.data.copy_(tau * local_param.data + (1 - tau) * target_param.data)
 
 
+def save_checkpoint(path, brain, epsilon=0.0, counters=None):
+    """Everything needed to resume except the replay contents: both nets, Adam state, epsilon and
+    counters.  (The reference saves only the target net's state_dict, DDQN.py:326, so a resumed run
+    restarts epsilon at 1; `torch.save(brain.qnetwork_target.state_dict(), ...)` still gives that file.)"""
+    torch.save({"local": brain.qnetwork_local.state_dict(), "target": brain.qnetwork_target.state_dict(),
+                "optimizer": brain.optimizer.state_dict(), "epsilon": float(epsilon),
+                "t_step": brain.t_step, "counters": dict(counters or {})}, path)
+
+
+def load_checkpoint(path, brain):
+    ck = torch.load(path, map_location=brain.device, weights_only=True)
+    brain.qnetwork_local.load_state_dict(ck["local"])
+    brain.qnetwork_target.load_state_dict(ck["target"])
+    brain.optimizer.load_state_dict(ck["optimizer"])
+    brain.t_step = ck["t_step"]
+    return ck["epsilon"], ck["counters"]
+
+
 def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BATCH_SIZE, capacity=1 << 20,
-          in_channels=3, seed=0x5EED, log_every=50, save_path=None):
+          in_channels=3, seed=0x5EED, log_every=50, save_path=None, log_dir=None, resume=None):
     """Batched self-play DDQN: the loop of DDQN.py:225-346 with N envs per launch.
     Honours the reference's cadence as defaults (App. A #12): one learn step per 2 env-steps
     (UPDATE_EVERY=4 counted in per-player `brain.step` calls), epsilon x0.999 per 20 finished
@@ -194,6 +212,12 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
     S = width + 2
     codes = env.reset().reshape(2 * n_envs, S, S).clone()
     epsilon, games, learn_steps, transitions = float(EPSILON_START), 0, 0, 0
+    if resume:
+        epsilon, _ = load_checkpoint(resume, brain)
+    writer = None
+    if log_dir and rank == 0:
+        from tron.scalars import ScalarWriter
+        writer = ScalarWriter(log_dir)
     t0 = time.perf_counter()
     for it in range(steps):
         planes = pop_up_planes(codes)                                             # [2N,3,S,S] for the CNN
@@ -214,11 +238,19 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
             if epsilon * DECAY_RATE > ESPILON_END:
                 epsilon *= DECAY_RATE
         if log_every and rank == 0 and it % log_every == log_every - 1:
-            print(f"step {it + 1}: games {games} eps {epsilon:.4f} loss {float(brain.get_loss()):.4f}", flush=True)
+            loss = float(brain.get_loss())
+            print(f"step {it + 1}: games {games} eps {epsilon:.4f} loss {loss:.4f}", flush=True)
+            if writer:                                                            # DDQN.py:342-344
+                writer.add_scalar('Training loss', loss, games)
+                writer.add_scalar('Duration', n_envs * (it + 1) / max(games, 1), games)
+                writer.add_scalar('Epsilon', epsilon, games)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if writer:
+        writer.close()
     if save_path and rank == 0:
         torch.save(brain.qnetwork_target.state_dict(), save_path)                 # DDQN.py:326 saves the TARGET net
+        save_checkpoint(save_path + ".full", brain, epsilon, dict(games=games, learn_steps=learn_steps))
     return dict(env_steps=n_envs * steps * world, transitions_pushed=transitions * world,
                 transitions_learned=learn_steps * batch_size * world, learn_steps=learn_steps, games=games * world,
                 seconds=dt, env_steps_per_s=n_envs * steps * world / dt,

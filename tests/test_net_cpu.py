@@ -102,3 +102,42 @@ def test_dqn_learn_step_smooth_l1():
                                                  r + 0.9 * model(s2).max(1)[0] * (1 - term.float()))
     loss = DQN.learn_step(model, opt, s, a, s2, r, term)
     assert torch.allclose(loss, exp, rtol=1e-5, atol=1e-6)
+
+
+def test_checkpoint_roundtrip_and_scalars(tmp_path):
+    import DDQN
+    from tron.scalars import ScalarWriter, read_scalars
+    torch.manual_seed(0)
+    a = DDQN.Agent(10, 3, device="cpu", make_memory=False)
+    exp = (torch.rand(8, 3, 12, 12), torch.randint(0, 4, (8, 1)), torch.randn(8, 1), torch.rand(8, 3, 12, 12),
+           torch.zeros(8, 1))
+    a.qnetwork_local.dropout.p = 0.0
+    a.learn(exp, 0.9)
+    path = str(tmp_path / "ddqn.full")
+    DDQN.save_checkpoint(path, a, epsilon=0.42, counters={"games": 7})
+    b = DDQN.Agent(10, 3, device="cpu", make_memory=False)
+    eps, counters = DDQN.load_checkpoint(path, b)
+    assert eps == 0.42 and counters == {"games": 7}
+    b.qnetwork_local.dropout.p = 0.0
+    la, lb = a.learn(exp, 0.9), b.learn(exp, 0.9)          # same next step => optimizer state restored too
+    assert torch.allclose(la, lb) and all(torch.equal(p, q) for p, q in
+                                          zip(a.qnetwork_local.parameters(), b.qnetwork_local.parameters()))
+    w = ScalarWriter(str(tmp_path / "run"))
+    w.add_scalar("Training loss", 1.5, 20)
+    w.close()
+    recs = read_scalars(w.path)
+    assert recs[0]["tag"] == "Training loss" and recs[0]["value"] == 1.5 and recs[0]["step"] == 20
+
+
+def test_ascii_window():
+    import io
+    from tron.map import Map, Tile
+    from tron.window import Window, render_ascii
+    m = Map(3, 3, Tile.EMPTY, Tile.WALL)
+    m[0, 0] = Tile.PLAYER_ONE_HEAD
+    m[2, 1] = Tile.PLAYER_TWO_slide
+    assert render_ascii(m).split("\n") == ["#####", "#A..#", "#...#", "#.-.#", "#####"]
+    buf = io.StringIO()
+    win = Window(stream=buf)
+    win.render_map(m)
+    assert win.frames == 1 and "#A..#" in buf.getvalue()
