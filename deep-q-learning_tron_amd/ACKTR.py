@@ -73,47 +73,74 @@ class Brain(object):
             self.optimizer = optim.RMSprop(self.actor_critic.parameters(), config.lr, eps=config.eps,
                                            alpha=config.alpha)
 
-    def update(self, rollouts):
-        """One update from a full rollout (ACKTR.py:88-159)."""
+    def update(self, rollouts, micro_batch=None):
+        """One update from a full rollout (ACKTR.py:88-159).  With `micro_batch`, the T*N samples are
+        pushed through the network in slices of that size: losses, gradients and K-FAC factor sums
+        are accumulated with the weights that make the result equal to the single big batch."""
         num_steps, num_processes = rollouts.rewards.size(0), rollouts.rewards.size(1)
+        B = num_steps * num_processes
         obs_shape = rollouts.observations.shape[2:]
         self.optimizer.zero_grad()
-        obs = rollouts.observations[:-1].reshape(-1, *obs_shape).to(self.device).detach()
-        acts = rollouts.actions.view(-1, 1).to(self.device).detach()
-        if rollouts.probs is None:
-            values, action_log_probs, entropy = self.actor_critic.evaluate_actions(obs, acts)
-        else:
-            values, action_log_probs, entropy = self.actor_critic.evaluate_actions(
-                obs, acts, rollouts.probs.view(-1, rollouts.probs.size(-1)).to(self.device).detach())
-        values = values.view(num_steps, num_processes, 1)
-        action_log_probs = action_log_probs.view(num_steps, num_processes, 1)
-        advantages = rollouts.returns[:-1].to(self.device).detach() - values
-        value_loss = advantages.pow(2).mean()
-        radvantages = advantages.detach().mean()
-        action_gain = (action_log_probs * advantages.detach()).mean()
-
-        if self.acktr and self.optimizer.steps % self.optimizer.Ts == 0:
-            # sampled Fisher (Martens 2014): statistics of the gradients of these two losses
-            self.actor_critic.zero_grad()
-            pg_fisher_loss = -action_log_probs.mean()
-            value_noise = torch.randn(values.size(), device=values.device)
-            sample_values = values + value_noise
-            vf_fisher_loss = -(values - sample_values.detach()).pow(2).mean()
-            fisher_loss = pg_fisher_loss + vf_fisher_loss
-            self.optimizer.acc_stats = True
-            fisher_loss.backward(retain_graph=True)
-            self.optimizer.acc_stats = False
-
-        # the reference's loss reads the coefficients from config, not from the Brain (ACKTR.py:147-148)
-        total_loss = (value_loss * config.value_loss_coef - action_gain * config.policy_loss_coef
-                      - entropy * config.entropy_coef)
-        total_loss.backward()
+        obs = rollouts.observations[:-1].reshape(-1, *obs_shape)
+        acts = rollouts.actions.view(-1, 1)
+        probs = None if rollouts.probs is None else rollouts.probs.view(-1, rollouts.probs.size(-1))
+        rets = rollouts.returns[:-1].reshape(-1, 1)
+        fisher = self.acktr and self.optimizer.steps % self.optimizer.Ts == 0
+        mb = B if not micro_batch else min(int(micro_batch), B)
+        split = mb < B
+        if split and self.acktr:
+            self.optimizer.begin_accumulate(B)
+        noise = torch.randn(B, 1, device=self.device) if fisher else None     # value noise of the sampled Fisher
+        sums = torch.zeros(5, device=self.device)     # value_loss, action_gain, entropy, logp, advantage
+        grads = None
+        for lo in range(0, B, mb):
+            hi = min(lo + mb, B)
+            w = (hi - lo) / B
+            o = obs[lo:hi].to(self.device).detach()
+            a = acts[lo:hi].to(self.device).detach()
+            if probs is None:
+                values, action_log_probs, entropy = self.actor_critic.evaluate_actions(o, a)
+            else:
+                values, action_log_probs, entropy = self.actor_critic.evaluate_actions(
+                    o, a, probs[lo:hi].to(self.device).detach())
+            advantages = rets[lo:hi].to(self.device).detach() - values
+            value_loss = advantages.pow(2).mean()
+            action_gain = (action_log_probs * advantages.detach()).mean()
+            if fisher:
+                # sampled Fisher (Martens 2014): statistics of the gradients of these two losses
+                self.actor_critic.zero_grad()
+                pg_fisher_loss = -action_log_probs.mean()
+                sample_values = values + noise[lo:hi]
+                vf_fisher_loss = -(values - sample_values.detach()).pow(2).mean()
+                self.optimizer.acc_stats = True
+                ((pg_fisher_loss + vf_fisher_loss) * w).backward(retain_graph=True)
+                self.optimizer.acc_stats = False
+                # NB the reference does not clear .grad here (ACKTR.py:131-150): the Fisher loss's
+                # gradient stays in and is added to the update's gradient.  Honoured.
+            # the reference's loss reads the coefficients from config, not from the Brain (ACKTR.py:147-148)
+            total = (value_loss * config.value_loss_coef - action_gain * config.policy_loss_coef
+                     - entropy * config.entropy_coef)
+            (total * w).backward()
+            if split and fisher:                        # keep this slice's gradient: the next Fisher pass zeroes .grad
+                g = [p.grad.detach().clone() for p in self.actor_critic.parameters()]
+                grads = g if grads is None else [x.add_(y) for x, y in zip(grads, g)]
+            sums += w * torch.stack([value_loss.detach(), action_gain.detach(), entropy.detach(),
+                                     action_log_probs.detach().mean(), advantages.detach().mean()])
+        if split:
+            if grads is not None:                       # otherwise .grad accumulated across the slices by itself
+                for p, g in zip(self.actor_critic.parameters(), grads):
+                    p.grad = g
+            if self.acktr:
+                self.optimizer.end_accumulate()
         self.optimizer.step()
-        return total_loss, value_loss, action_gain, entropy, action_log_probs.mean(), radvantages
+        value_loss, action_gain, entropy, logp, radv = sums.unbind(0)
+        total_loss = value_loss * config.value_loss_coef - action_gain * config.policy_loss_coef - entropy * config.entropy_coef
+        return total_loss, value_loss, action_gain, entropy, logp, radv
 
 
 def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterations=100, acktr=True,
-          num_steps=NUM_ADVANCED_STEP, gamemode=None, seed=0x5EED, log_every=0, save_path=None, args=None):
+          num_steps=NUM_ADVANCED_STEP, gamemode=None, seed=0x5EED, log_every=0, save_path=None, args=None,
+          micro_batch=8192, act_batch=16384):
     """Batched self-play ACKTR/A2C on VecTron.  Returns counters and the Brain."""
     from tron.vec import VecTron
     gamemode = config.GAME_MODE if gamemode is None else gamemode
@@ -144,8 +171,12 @@ def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterat
             if not is_map:
                 probs = env_vectors()
             with torch.no_grad():
-                acts = [net.act(rollouts[p].observations[step]) if is_map
-                        else net.act(rollouts[p].observations[step], probs[p]) for p in range(2)]
+                acts = []
+                for p in range(2):
+                    o = rollouts[p].observations[step]
+                    acts.append(torch.cat([net.act(o[i:i + act_batch]) if is_map
+                                           else net.act(o[i:i + act_batch], probs[p][i:i + act_batch])
+                                           for i in range(0, n_envs, act_batch)]))
             actions = torch.cat(acts, 1).to(torch.int8)
             obs, reward, done, _ = env.step(actions, autoreset=True)
             masks = (1 - done.to(torch.float32)).unsqueeze(1)
@@ -153,12 +184,16 @@ def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterat
             for p in range(2):
                 rollouts[p].insert(obs[:, p], acts[p], reward[:, p:p + 1], masks, None if is_map else probs[p])
         with torch.no_grad():
-            nxt = [net.get_value(rollouts[p].observations[-1]) if is_map
-                   else net.get_value(rollouts[p].observations[-1], probs[p]) for p in range(2)]
+            nxt = []
+            for p in range(2):
+                o = rollouts[p].observations[-1]
+                nxt.append(torch.cat([net.get_value(o[i:i + act_batch]) if is_map
+                                      else net.get_value(o[i:i + act_batch], probs[p][i:i + act_batch])
+                                      for i in range(0, n_envs, act_batch)]))
         for p in range(2):
             rollouts[p].compute_returns(nxt[p])
-        stats = brain.update(rollouts[0])
-        brain.update(rollouts[1])
+        stats = brain.update(rollouts[0], micro_batch)
+        brain.update(rollouts[1], micro_batch)
         for p in range(2):
             rollouts[p].after_update()
         if log_every and it % log_every == log_every - 1:

@@ -62,9 +62,11 @@ def split_biases(model):
             split_biases(child)
 
 
-def cov_inputs(a, module):
-    """A-factor sample of one batch (kfac.py:41-58)."""
-    batch = a.size(0)
+def cov_inputs(a, module, batch=None):
+    """A-factor sample of one batch (kfac.py:41-58).  `batch` = size of the WHOLE batch when `a` is
+    only a micro-batch of it (the result is then this micro-batch's additive share)."""
+    share = 1.0 if batch is None else a.size(0) / batch
+    batch = a.size(0) if batch is None else batch
     if isinstance(module, nn.Conv2d):
         # im2col in batch chunks of <= ~256 MB so large rollouts (16 384 envs x 5 steps) stay bounded
         oh = (a.size(2) + 2 * module.padding[0] - module.kernel_size[0]) // module.stride[0] + 1
@@ -82,20 +84,22 @@ def cov_inputs(a, module):
             acc.addmm_(rows.t(), rows / batch)
         return acc
     if isinstance(module, AddBias):
-        return torch.ones(1, 1, device=a.device, dtype=a.dtype)      # ones(B,1)^T ones(B,1) / B
+        return torch.full((1, 1), share, device=a.device, dtype=a.dtype)   # ones(B,1)^T ones(B,1) / B
     return a.t() @ (a / batch)
 
 
-def cov_grads(g, module):
-    """G-factor sample of one batch (kfac.py:61-76)."""
-    batch = g.size(0)
+def cov_grads(g, module, batch=None):
+    """G-factor sample of one batch (kfac.py:61-76).  The gradients are those of a loss averaged
+    over the whole batch; `batch` is its size when `g` covers only a micro-batch."""
+    scale = 1.0 if batch is None else batch / g.size(0)        # rows of the whole batch / rows here
+    batch = g.size(0) if batch is None else batch
     if isinstance(module, nn.Conv2d):
         oh, ow = g.size(2), g.size(3)
         g = g.permute(0, 2, 3, 1).reshape(-1, g.size(1)) * (oh * ow)
     elif isinstance(module, AddBias):
         g = g.reshape(g.size(0), g.size(1), -1).sum(-1)
     g_ = g * batch
-    return g_.t() @ (g_ / g.size(0))
+    return g_.t() @ (g_ / (g.size(0) * scale))
 
 
 class KFACOptimizer(optim.Optimizer):
@@ -113,6 +117,8 @@ class KFACOptimizer(optim.Optimizer):
             m.register_full_backward_hook(self._save_grad_output)
         self.steps = 0
         self.acc_stats = False
+        self._whole_batch = None          # set by accumulate(): hooks then add micro-batch shares
+        self._sum_aa, self._sum_gg = {}, {}
         self.m_aa, self.m_gg = {}, {}
         self.Q_a, self.Q_g, self.d_a, self.d_g = {}, {}, {}, {}
         self.momentum, self.stat_decay, self.lr = momentum, stat_decay, lr
@@ -129,12 +135,33 @@ class KFACOptimizer(optim.Optimizer):
     def _save_input(self, module, inputs):
         if torch.is_grad_enabled() and self.steps % self.Ts == 0:
             with torch.no_grad():
-                self._running(self.m_aa, module, cov_inputs(inputs[0].detach(), module))
+                if self._whole_batch is None:
+                    self._running(self.m_aa, module, cov_inputs(inputs[0].detach(), module))
+                else:
+                    part = cov_inputs(inputs[0].detach(), module, self._whole_batch)
+                    self._sum_aa[module] = part if module not in self._sum_aa else self._sum_aa[module].add_(part)
 
     def _save_grad_output(self, module, grad_input, grad_output):
         if self.acc_stats:
             with torch.no_grad():
-                self._running(self.m_gg, module, cov_grads(grad_output[0].detach(), module))
+                if self._whole_batch is None:
+                    self._running(self.m_gg, module, cov_grads(grad_output[0].detach(), module))
+                else:
+                    part = cov_grads(grad_output[0].detach(), module, self._whole_batch)
+                    self._sum_gg[module] = part if module not in self._sum_gg else self._sum_gg[module].add_(part)
+
+    # ---- micro-batched statistics: one running-average update per step, like a single big batch ----
+    def begin_accumulate(self, whole_batch):
+        self._whole_batch = int(whole_batch)
+        self._sum_aa, self._sum_gg = {}, {}
+
+    def end_accumulate(self):
+        for module, s in self._sum_aa.items():
+            self._running(self.m_aa, module, s)
+        for module, s in self._sum_gg.items():
+            self._running(self.m_gg, module, s)
+        self._whole_batch = None
+        self._sum_aa, self._sum_gg = {}, {}
 
     # ---- the step -------------------------------------------------------------------------------
     @torch.no_grad()

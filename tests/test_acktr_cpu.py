@@ -121,3 +121,32 @@ def test_brain_update_matches_reference(g, tag, mode):
                 ref = g[f"{tag}_{key}_{mn}"]
                 assert np.allclose(got, ref, rtol=1e-4, atol=1e-7 + 1e-4 * np.abs(ref).max()), (mn, key)
         assert brain.optimizer.steps == 2
+
+
+@pytest.mark.parametrize("mode", ["a2c", "acktr"])
+def test_micro_batched_update_equals_single_batch(g, mode):
+    """Brain.update(rollouts, micro_batch=...) is the same update as the single big batch: same
+    losses and same gradient; for K-FAC also the same weights after two steps.  (RMSprop's first
+    steps divide by ~|g|, so A2C weights are compared through their gradients.)"""
+    import ACKTR
+    import Net.ACNet as A
+    outs = []
+    for mb in (None, 16, 33):
+        net = A.Mulnet()
+        brain = ACKTR.Brain(net, None, acktr=(mode == "acktr"), device="cpu")
+        shapes = collections.OrderedDict((k, tuple(v.shape)) for k, v in net.state_dict().items())
+        net.load_state_dict(det_state_dict(shapes, salt=4))
+        net.dropout.p = 0.0
+        ro = _rollouts(g, "mul")
+        stats, grads = [], None
+        for k in range(2 if mode == "acktr" else 1):
+            torch.manual_seed(1000 + k)
+            stats.append([float(t) for t in brain.update(ro, micro_batch=mb)])
+            if k == 0:
+                grads = torch.cat([p.grad.detach().reshape(-1) for p in net.parameters()]).numpy().copy()
+        outs.append((np.array(stats), grads, torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()))
+    for st, gr, w in outs[1:]:
+        assert np.allclose(st, outs[0][0], rtol=1e-4, atol=1e-5)
+        assert np.allclose(gr, outs[0][1], rtol=1e-3, atol=1e-6 + 1e-5 * np.abs(outs[0][1]).max())
+        if mode == "acktr":
+            assert np.allclose(w, outs[0][2], rtol=1e-4, atol=2e-6), np.abs(w - outs[0][2]).max()
