@@ -218,6 +218,48 @@ def test_step_without_obs_and_totals(T):
 
 
 # ----------------------------------------------------- full size: properties --
+@pytest.mark.parametrize("N,W,mode,steps", [
+    (1, 2, None, 6),            # smallest board, a single env (BASELINE configs[0] shape is N=1)
+    (1, 10, "temper", 20),
+    (3, 96, None, 6),           # largest supported side: 98x98 cells, LDS tile of 4 envs
+    (5, 95, "ice", 5),          # largest odd side (bytewise global access)
+    (65, 16, None, 10),         # one env past a tile boundary
+    (4096, 10, None, 25),       # BASELINE configs[1] env shape
+    (4096, 10, "temper", 25),
+])
+def test_extreme_and_config_shapes_vs_oracle(T, N, W, mode, steps):
+    tv, oracle = T
+    env = tv.VecTron(N, W, mode=mode, seed=42, rank=1, obs_format="codes", reward="acktr")
+    ref = oracle.VecOracle(N, W, mode=mode, seed=42, stream=1, reward=oracle.REWARD_ACKTR)
+    env.reset()
+    ref.reset_all()
+    for t in range(steps):
+        obs, r, d, w = env.step()
+        o, dd, ww, rr = ref.step(autoreset=True)
+        assert np.array_equal(np_(obs).reshape(N, 2, -1), o), t
+        assert np.array_equal(np_(d), dd) and np.array_equal(np_(w), ww) and np.array_equal(np_(r), rr), t
+    _compare_state(env, ref, "end")
+
+
+def test_config5_shape_16384x32_temper_prefix(T):
+    """BASELINE configs[4] env shape (ACKTR: 16 384 envs, 32x32, temper, f32 planes): the first 1024
+    envs equal the oracle on the same seed; planes equal pop_up of the codes everywhere."""
+    tv, oracle = T
+    N, W, NP = 16384, 32, 1024
+    env = tv.VecTron(N, W, mode="temper", seed=7, obs_format="planes3", reward="acktr")
+    ref = oracle.VecOracle(NP, W, mode="temper", seed=7, reward=oracle.REWARD_ACKTR)
+    env.reset()
+    ref.reset_all()
+    for _ in range(8):
+        obs, r, d, w = env.step()
+        o, dd, ww, rr = ref.step(autoreset=True)
+    assert np.array_equal(np_(d[:NP]), dd) and np.array_equal(np_(r[:NP]), rr)
+    assert np.array_equal(np_(env.grid()[:NP]).reshape(NP, -1), ref.grid)
+    codes = env.encode("codes")
+    assert np.array_equal(np_(codes[:NP]).reshape(NP, 2, -1), o)
+    assert torch.equal(tv.pop_up_planes(codes.reshape(2 * N, W + 2, W + 2)).view(N, 2, 3, W + 2, W + 2), obs)
+
+
 def test_full_size_incremental_matches_full_rewrite(T):
     """65 536 x 24x24: the in-place incremental step and the full-rewrite step stay identical."""
     tv, _ = T
