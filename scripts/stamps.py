@@ -7,7 +7,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "deep-q-learning_tron_amd")]
 import numpy as np, torch
 from tron.vec import VecTron
 
-ed = int(os.environ.get("TRON_DIRECT_ENVS", "64"))
+ed = int(os.environ.get("TRON_TILE_ENVS", "32"))
 N, W = 65536, 24
 env = VecTron(N, W, seed=0x5EED, obs_format="codes")
 env.reset()
@@ -30,3 +30,9 @@ for wv in (0, 1):
 d = t[:, 0, 7] - t[:, 0, 0]
 print("block lifetime (wave0 start->stream issued): median %.2f max %.2f" % (np.median(d), d.max()))
 print("last stamp of any block: %.2f us" % (t[:, :, 7].max() - t0))
+st = np.sort(t[:, 0, 0] - t0); en = np.sort(t[:, 0, 7] - t0)
+print("block starts  (us) pct 0/25/50/75/90/100:", np.percentile(st, [0, 25, 50, 75, 90, 100]).round(2))
+print("block ends    (us) pct 0/25/50/75/90/100:", np.percentile(en, [0, 25, 50, 75, 90, 100]).round(2))
+life = t[:, 0, 7] - t[:, 0, 0]
+early = t[:, 0, 0] - t0 < 1.0
+print("lifetime of blocks started <1us: median %.2f ; started later: median %.2f (n=%d)" % (np.median(life[early]), np.median(life[~early]) if (~early).any() else 0, int((~early).sum())))
