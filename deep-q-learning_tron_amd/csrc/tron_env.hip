@@ -575,6 +575,7 @@ __global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, ui
     const bool mine = lane < ne;
     const int env = e0 + lane;
 
+    STAMP(0);
     // ---- 1: state words (wave 0: st4, wave 1: rs4), then the tile
     EnvRegs R{};
     uint4 rs = make_uint4(0u, 0u, 0u, 0u);
@@ -626,7 +627,9 @@ __global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, ui
             if (i < nchunks) tile[i] = v[k];
         }
     }
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
 
     if (DO_STEP) {
         // ---- 2: the move, wave 0, one env per lane, LDS only
@@ -641,7 +644,9 @@ __global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, ui
                 rec_out[lane] = ro;
             }
         }
+        STAMP(3);
         __syncthreads();
+        STAMP(4);
 
         // ---- 3a: waves 1-3 write the records out (lane = env)
         if (wave >= 1 && mine) {
@@ -657,6 +662,7 @@ __global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, ui
                     reinterpret_cast<float2 *>(out.reward)[env] = make_float2(__uint_as_float(ro.y), __uint_as_float(ro.z));
             }
         }
+#ifndef TRON_STAMPS
         if (out.totals && wave == 3) {
             const uint32_t f = mine ? rec_out[lane].x : 0u;
             const int wn = ((f & RES_STEPPED) && (f & RES_DONE)) ? (int)((f >> 4) & 3u) : -1;
@@ -669,6 +675,7 @@ __global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, ui
                 if (b0) atomicAdd(&out.totals[3], (unsigned long long)__popcll(b0));
             }
         }
+#endif
     } else {
         return;                                                        // nothing to re-encode: the planes are the state
     }
@@ -697,6 +704,7 @@ __global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, ui
         store_chunk<true>(o1, nb, w1);
         store_chunk<true>(o1 + G, nb, w2);
     }
+    STAMP(7);
 }
 
 // ------------------------------------------------------------ incremental step --
