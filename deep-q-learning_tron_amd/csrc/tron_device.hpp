@@ -31,7 +31,7 @@ struct Params {
     const int8_t *fresh;       // [G] empty board with WALL border (map.py:45-48)
 };
 
-enum { RNG_STEP = 0, RNG_RESET = 2, RNG_INIT = 3 };
+enum { RNG_STEP = 0, RNG_RESET = 2, RNG_INIT = 3, RNG_MINIMAX = 4 };
 enum { META_ALIVE0 = 1u, META_ALIVE1 = 2u, META_DONE = 4u };
 
 __device__ __forceinline__ uint32_t pack_pos(int r1, int c1, int r2, int c2)

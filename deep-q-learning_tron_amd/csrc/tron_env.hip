@@ -23,6 +23,7 @@
 // A lone wave retires about one instruction per five cycles, so the serial section
 // between the barriers is LDS-only and ~200 instructions; everything heavier is off it.
 #include "tron_device.hpp"
+#include "tron_minimax.hpp"
 #include "../../include/tron_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -1376,6 +1377,27 @@ int tron_rollout_random(tron_handle h, int32_t k_steps, int32_t obs_fmt, void *o
     if (h->P.obs_state && (obs_fmt == TRON_OBS_PLANES3_F32 || obs_fmt == TRON_OBS_PLANES4_F32) && k_steps > 0)
         return obs_planes(h, obs_fmt, obs, S_(stream));
     return TRON_OK;
+}
+
+int tron_minimax_actions(tron_handle h, int32_t player, int32_t depth, int32_t mode, int8_t *out_actions,
+                         int32_t *out_values, int8_t *out_expanded, void *stream)
+{
+    if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
+    if (!out_actions || (player != 1 && player != 2)) return TRON_ERR_BAD_ARG;
+    if (mode != TRON_MINIMAX_VORONOI && mode != TRON_MINIMAX_DISTWALL) return TRON_ERR_BAD_ARG;
+    if (depth != 2 || h->P.S > 64) return TRON_ERR_UNSUPPORTED;
+    MinimaxSrc src{};
+    if (h->P.obs_state) {       // the attached planes are the boards: player p's plane is its observation
+        src.codes = h->P.obs_state + (size_t)(player - 1) * (size_t)h->P.G;
+        src.stride = 2u * (size_t)h->P.G;
+    } else {
+        src.grid = h->P.grid;
+    }
+    src.player = player;
+    src.st4 = h->P.st4;
+    src.seed = h->P.seed;
+    src.stream = h->P.stream;
+    return launch_minimax(src, h->P.N, h->P.S, mode, out_actions, out_values, out_expanded, S_(stream));
 }
 
 int tron_encode_codes(const int8_t *tiles, int64_t n, int32_t cells, int32_t player, int8_t *codes_out, void *stream)

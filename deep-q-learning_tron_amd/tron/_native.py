@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRON_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libtron_hip.so")
 
-OK = 0
+OK, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_ALLOC, ERR_LAUNCH, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5      # tron_status
 MODE = {None: 0, "none": 0, "ice": 1, "temper": 2}                 # tron/game.py:86,163
 OBS_NONE, OBS_CODES_I8, OBS_PLANES3_F32, OBS_PLANES4_F32 = 0, 1, 2, 3
 OBS = {None: OBS_NONE, "none": OBS_NONE, "codes": OBS_CODES_I8, "planes3": OBS_PLANES3_F32,
@@ -39,6 +39,8 @@ SIGNATURES = {
     "tron_get_state": (C.c_int, [_vp] + [_vp] * 10),
     "tron_encode_codes": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "tron_pop_up": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "tron_minimax_actions": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "tron_minimax_codes": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "tron_replay_create": (C.c_int, [_i64, _i32, _u32, _u32, C.POINTER(_vp)]),
     "tron_replay_destroy": (C.c_int, [_vp]),
     "tron_replay_push": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -46,6 +48,8 @@ SIGNATURES = {
     "tron_replay_size": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "tron_replay_indices": (C.c_int, [_vp, _i32, _vp, _vp]),
 }
+
+MINIMAX = {"voronoi": 0, "distwall": 1}
 
 _lib = None
 

@@ -162,6 +162,20 @@ class VecTron:
             nat.check(self._lib.tron_rollout_random(self._h, int(k_steps), self._fmt, nat.ptr(self.obs),
                                                     nat.ptr(totals), nat.stream_ptr()), "tron_rollout_random")
 
+    def minimax_actions(self, player, mode="voronoi", out=None, want_values=False):
+        """MinimaxPlayer(2, mode).action(game.map(), player) for every env (minimax.py:284-297):
+        int8 [N] actions 0..3 = UP, RIGHT, DOWN, LEFT (-1 for finished games).  With want_values
+        also the root children's values int32 [N, 4] and the searched-moves bit mask int8 [N]."""
+        if out is None:
+            out = torch.empty(self.N, dtype=torch.int8, device=self.device)
+        values = torch.empty(self.N, 4, dtype=torch.int32, device=self.device) if want_values else None
+        expanded = torch.empty(self.N, dtype=torch.int8, device=self.device) if want_values else None
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_minimax_actions(self._h, int(player), 2, nat.MINIMAX[mode], nat.ptr(out),
+                                                     nat.ptr(values), nat.ptr(expanded), nat.stream_ptr()),
+                      "tron_minimax_actions")
+        return (out, values, expanded) if want_values else out
+
     # -- read-back ---------------------------------------------------------
     def grid(self):
         """int8 [N, W+2, W+2] Tile values (map.py:9-17)."""
@@ -197,6 +211,27 @@ def encode_codes(tiles, player):
     nat.check(nat.lib().tron_encode_codes(nat.ptr(t), n, t.numel() // n, int(player), nat.ptr(out),
                                           nat.stream_ptr()), "tron_encode_codes")
     return out
+
+
+def minimax_codes(codes, draws=None, mode="voronoi", depth=2):
+    """The reference's MinimaxPlayer(depth, mode) search (minimax.py:216-297) on a stack of
+    observation-code images int8 [n, S, S] of the player to move.  Returns (actions int8 [n] in
+    0..3 = UP, RIGHT, DOWN, LEFT, root values int32 [n, 4], searched-moves bit mask int8 [n]).
+    draws: uint32-valued int64/int32 tensor [n] for random.choice / randint (None = zeros)."""
+    c = codes.contiguous()
+    n, side = c.shape[0], c.shape[-1]
+    act = torch.empty(n, dtype=torch.int8, device=c.device)
+    values = torch.empty(n, 4, dtype=torch.int32, device=c.device)
+    expanded = torch.empty(n, dtype=torch.int8, device=c.device)
+    d = None
+    if draws is not None:
+        d = draws.to(torch.int64) & 0xFFFFFFFF
+        d = torch.where(d >= 2 ** 31, d - 2 ** 32, d).to(torch.int32).contiguous()      # same 32 bits
+    with torch.cuda.device(c.device):
+        nat.check(nat.lib().tron_minimax_codes(nat.ptr(c), n, side, int(depth), nat.MINIMAX[mode], nat.ptr(d),
+                                               nat.ptr(act), nat.ptr(values), nat.ptr(expanded), nat.stream_ptr()),
+                  "tron_minimax_codes")
+    return act, values, expanded
 
 
 def pop_up_planes(codes):

@@ -181,6 +181,26 @@ int tron_replay_size(tron_replay_handle r, int64_t *size, int64_t *capacity);
 /* The slots drawn by the last tron_replay_sample, i64[batch] (tests, logging). */
 int tron_replay_indices(tron_replay_handle r, int32_t batch, int64_t *indices_out, void *stream);
 
+/* ---- Minimax/Voronoi opponent (tron/minimax.py; MinimaxPlayer(2, "voronoi") at util.py:82-83,
+ * ACKTR.py:13,286-287) ------------------------------------------------------------------------ */
+enum { TRON_MINIMAX_VORONOI = 0, TRON_MINIMAX_DISTWALL = 1 };   /* minimax.py:228-233 */
+/* MinimaxPlayer.action for `player` (1|2) in every env (minimax.py:284-297 on
+ * game.map().state_for_player(player), as game.py:181 calls it): out_actions i8[N] in the env's
+ * action coding 0..3 = UP, RIGHT, DOWN, LEFT (the reference's 1..4 minus one), ready to be a column
+ * of tron_step_encode's actions.  Finished envs get -1.  random.choice among equal moves /
+ * random.randint for a boxed-in head draw from Philox (env, tick, purpose 4, player).
+ * out_values i32[N][4] / out_expanded i8[N] (bit a = root move a was searched) may be NULL.
+ * Only depth 2 exists in the reference's call sites; other depths -> TRON_ERR_UNSUPPORTED.
+ * Boards up to 62x62.                                                                       */
+int tron_minimax_actions(tron_handle h, int32_t player, int32_t depth, int32_t mode, int8_t *out_actions,
+                         int32_t *out_values, int8_t *out_expanded, void *stream);
+/* The same search on arbitrary observation-code images i8[n][side][side] (each must hold one +10
+ * and one -10 head inside its border, as every live game's does; others get -1).  draws u32[n]:
+ * choice -> ties[mulhi(u, len)], randint(1,4) -> 1 + mulhi(u, 4); NULL = all zero.          */
+int tron_minimax_codes(const int8_t *codes, int64_t n, int32_t side, int32_t depth, int32_t mode,
+                       const uint32_t *draws, int8_t *out_actions, int32_t *out_values, int8_t *out_expanded,
+                       void *stream);
+
 const char *tron_strerror(int status);
 int tron_abi_version(void);
 

@@ -16,7 +16,7 @@ MODES = {None: 0, "none": 0, "ice": 1, "temper": 2}
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("tron_oracle.c", "tron_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("tron_oracle.c", "minimax_oracle.c", "tron_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
@@ -65,6 +65,9 @@ def lib():
         L.orc_state_for_player.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_pop_up.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_rewards.argtypes = [C.POINTER(Reward), C.c_int, C.c_int, C.c_uint32, C.c_void_p]
+        L.orc_minimax_move.restype = C.c_int
+        L.orc_minimax_move.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
         L.orc_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_vec_reset_env.argtypes = [C.POINTER(_Vec), C.c_int]
         L.orc_vec_init_env.argtypes = [C.POINTER(_Vec), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -129,6 +132,26 @@ def rewards(table, done, winner, step_index=0):
     out = np.zeros(2, np.float32)
     lib().orc_rewards(C.byref(r), int(done), int(winner), int(step_index), _p(out))
     return out
+
+
+MM_VORONOI, MM_DISTWALL = 0, 1
+
+
+def minimax_move(codes, depth=2, mode=MM_VORONOI, stream=None):
+    """MinimaxPlayer.action's search on one [S, S] observation-code image (minimax.py:216-288).
+    Returns (move 1..4, root values int32[4], root expanded bool[4], draws used)."""
+    codes = np.ascontiguousarray(codes, dtype=np.int8)
+    S = codes.shape[0]
+    assert codes.shape == (S, S)
+    stream = np.zeros(64, np.uint32) if stream is None else np.ascontiguousarray(stream, dtype=np.uint32)
+    values = np.zeros(4, np.int32)
+    expanded = np.zeros(4, np.int8)
+    used = C.c_int32(0)
+    move = lib().orc_minimax_move(_p(codes), S, int(depth), int(mode), _p(stream), len(stream), _p(values), _p(expanded),
+                                  C.addressof(used))
+    if move < 0:
+        raise RuntimeError("orc_minimax_move: the reference would raise here (%d)" % move)
+    return move, values, expanded.astype(bool), used.value
 
 
 class ScalarGame:

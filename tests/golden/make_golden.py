@@ -515,12 +515,141 @@ def gen_acktr():
     print("acktr: done;", {k: out[k].tolist() for k in out if k.endswith("stats0")})
 
 
+# --------------------------------------------------------------------------
+# G-minimax: MinimaxPlayer.action (tron/minimax.py) on live boards
+# --------------------------------------------------------------------------
+class StreamRandom:
+    """Stands in for the `random` module inside tron.minimax: draws come from a recorded u32
+    stream with randint(1,4) := 1 + mulhi(u,4), choice(seq) := seq[mulhi(u,len(seq))]."""
+
+    def __init__(self, stream):
+        self.s, self.i = stream, 0
+
+    def _next(self):
+        v = int(self.s[self.i])
+        self.i += 1
+        return v
+
+    def randint(self, a, b):
+        assert (a, b) == (1, 4)
+        return 1 + ((self._next() * 4) >> 32)
+
+    def choice(self, seq):
+        return seq[(self._next() * len(seq)) >> 32]
+
+
+def _board_from_tiles(W, tiles):
+    """Map with interior tiles[r][c] (Tile.value ints)."""
+    by_val = {t.value: t for t in RM.Tile}
+    m = RM.Map(W, W, RM.Tile.EMPTY, RM.Tile.WALL)
+    for r in range(W):
+        for c in range(W):
+            m[r, c] = by_val[int(tiles[r][c])]
+    return m
+
+
+def _random_board(W, rng, fill, slide_tiles):
+    tiles = np.zeros((W, W), np.int8)
+    for r in range(W):
+        for c in range(W):
+            if rng.random() < fill:
+                tiles[r, c] = rng.choice((1, 3, 5, 6) if slide_tiles else (1, 3))
+    cells = [(r, c) for r in range(W) for c in range(W)]
+    h1 = rng.choice(cells)
+    if rng.random() < 0.4:      # heads close together: crashes and contested cells
+        near = [(r, c) for (r, c) in cells if (r, c) != h1 and abs(r - h1[0]) + abs(c - h1[1]) <= 2]
+        h2 = rng.choice(near) if near else rng.choice([x for x in cells if x != h1])
+    else:
+        h2 = rng.choice([x for x in cells if x != h1])
+    tiles[h1] = 2
+    tiles[h2] = 4
+    return tiles
+
+
+def gen_minimax():
+    from netgen import mm_stream
+    import tron.minimax as RMM
+    from tron.player import Direction
+    rng = pyrandom.Random(909)
+    out = {}
+    summary = []
+    plan = [(3, 60, (2, 4)), (4, 120, (2, 4)), (5, 80, (2, 4)), (6, 80, (2, 4)), (10, 160, (2,)), (11, 40, (2,)),
+            (24, 40, (2,)), (32, 16, (2,))]
+    for W, n_boards, depths in plan:
+        boards = []
+        # (a) random tile soups at several densities, some with slide tiles
+        for k in range(n_boards // 2):
+            boards.append(_random_board(W, rng, rng.choice((0.0, 0.1, 0.25, 0.4, 0.6, 0.8)), k % 5 == 0))
+        # (b) positions out of 'mostly safe' self-play (long snakes, rooms)
+        while len(boards) < n_boards:
+            while True:
+                st = [rng.randrange(W) for _ in range(4)]
+                if (st[0], st[1]) != (st[2], st[3]):
+                    break
+            g = new_game(W, st)
+            stop = rng.randrange(1, 3 * W)
+            done = False
+            for _ in range(stop):
+                last = raw_grid(g)[1:-1, 1:-1].copy()
+                a = safe_actions(g, W, rng, 0.95)
+                _, _, done = g.step(a[0], a[1])
+                if done:
+                    break
+            boards.append(last if done else raw_grid(g)[1:-1, 1:-1].copy())
+        recs = {k: [] for k in ("player", "depth", "mode", "seed", "codes", "move", "values", "expanded", "draws")}
+        for tiles in boards:
+            m = _board_from_tiles(W, tiles)
+            for pid in (1, 2):
+                for depth in depths:
+                    for mode_id, mode in ((0, "voronoi"), (1, RMM.Mode.DISTWALL)):
+                        if depth == 4 and (rng.random() < 0.5 or (W > 5 and mode_id == 0 and rng.random() < 0.7)):
+                            continue
+                        seed = rng.getrandbits(32)
+                        stream = mm_stream(seed, 96).astype(np.uint64)
+                        sr = StreamRandom(stream)
+                        RMM.random = sr
+                        try:
+                            mp = RMM.MinimaxPlayer(depth, mode)
+                            d = mp.action(m, pid)
+                        finally:
+                            RMM.random = pyrandom
+                        values = np.zeros(4, np.int32)
+                        expanded = np.zeros(4, np.int8)
+                        for ch in mp.minimax.root._children:
+                            values[ch.get_action() - 1] = ch.get_value()
+                            expanded[ch.get_action() - 1] = 1
+                        recs["player"].append(pid)
+                        recs["depth"].append(depth)
+                        recs["mode"].append(mode_id)
+                        recs["seed"].append(seed)
+                        assert sr.i <= 96
+                        recs["codes"].append(np.asarray(m.state_for_player(pid), np.int8))
+                        recs["move"].append({Direction.UP: 1, Direction.RIGHT: 2, Direction.DOWN: 3, Direction.LEFT: 4}[d])
+                        recs["values"].append(values)
+                        recs["expanded"].append(expanded)
+                        recs["draws"].append(sr.i)
+        n = len(recs["move"])
+        dt = dict(player=np.int8, depth=np.int8, mode=np.int8, seed=np.uint32, codes=np.int8,
+                  move=np.int8, values=np.int32, expanded=np.int8, draws=np.int16)
+        for k, v in recs.items():
+            out[f"W{W}_{k}"] = np.array(v, dt[k])
+        ex = np.array(recs["expanded"])
+        summary.append(f"W={W}: {n} searches, root all-blocked {int((ex.sum(1) == 0).sum())},"
+                       f" value range [{np.array(recs['values']).min()}, {np.array(recs['values']).max()}]")
+    out["widths"] = np.array([p[0] for p in plan], np.int32)
+    np.savez_compressed(os.path.join(OUT, "minimax.npz"), **out)
+    print("minimax:", "; ".join(summary))
+
+
 def main():
     if "--net-only" in sys.argv:
         gen_net()
         return
     if "--acktr-only" in sys.argv:
         gen_acktr()
+        return
+    if "--minimax-only" in sys.argv:
+        gen_minimax()
         return
     gen_step_exhaustive()
     gen_episodes("episodes_none_4", 4, 300, 101, None, p_safe=0.6, keep_steps=True)
@@ -538,6 +667,7 @@ def main():
     gen_encode()
     gen_reset()
     gen_reward()
+    gen_minimax()
     gen_net()
     gen_acktr()
 

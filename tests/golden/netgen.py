@@ -29,3 +29,14 @@ def det_state_dict(shapes, salt=0):
             scale = 1.0 / np.sqrt(fan_in)
         out[name] = torch.from_numpy(det_tensor(shape, k + 100 * salt, scale))
     return out
+
+
+def mm_stream(seed, n=96):
+    """The u32 draw stream of one minimax fixture case: fmix32(seed + i * golden) (murmur3 finaliser)."""
+    x = (np.uint64(seed) + np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(13)
+    x = (x * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    return x.astype(np.uint32)

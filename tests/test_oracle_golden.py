@@ -147,3 +147,24 @@ def test_vec_matches_scalar_and_autoreset():
                 assert np.count_nonzero(v.grid[i] == 2) == 1 and np.count_nonzero(v.grid[i] == 4) == 1
                 assert np.array_equal(obs[i, 1], oracle.state_for_player(v.grid[i], 2))
     assert v.episode.max() > 1
+
+
+def test_minimax_matches_reference():
+    """oracle.minimax_move == the reference's MinimaxPlayer.action on every recorded board:
+    returned move, the root children's values, which children exist, and the draws consumed."""
+    from golden.netgen import mm_stream
+    g = load_golden("minimax")
+    total = 0
+    for W in g["widths"]:
+        k = f"W{int(W)}_"
+        for i in range(len(g[k + "move"])):
+            stream = mm_stream(int(g[k + "seed"][i]), 96)
+            move, values, expanded, used = oracle.minimax_move(g[k + "codes"][i], int(g[k + "depth"][i]),
+                                                               int(g[k + "mode"][i]), stream)
+            where = (int(W), i)
+            assert np.array_equal(expanded, g[k + "expanded"][i].astype(bool)), where
+            assert np.array_equal(values, g[k + "values"][i]), where
+            assert move == int(g[k + "move"][i]), where
+            assert used == int(g[k + "draws"][i]), where
+            total += 1
+    assert total > 2500
