@@ -140,8 +140,11 @@ class Brain(object):
 
 def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterations=100, acktr=True,
           num_steps=NUM_ADVANCED_STEP, gamemode=None, seed=0x5EED, log_every=0, save_path=None, args=None,
-          micro_batch=8192, act_batch=16384):
-    """Batched self-play ACKTR/A2C on VecTron.  Returns counters and the Brain."""
+          micro_batch=8192, act_batch=16384, ai_p1=True, ai_p2=True):
+    """Batched self-play ACKTR/A2C on VecTron.  Returns counters and the Brain.
+    ai_p1 / ai_p2 False seat MinimaxPlayer(2, "voronoi") there (ACKTR.py:176-177,286-287): that
+    player's executed move comes from the search; like the reference, the rollout still stores
+    the move the net sampled."""
     from tron.vec import VecTron
     gamemode = config.GAME_MODE if gamemode is None else gamemode
     constants = {"1": config.reward_cons1, "2": config.reward_cons2, "3": config.reward_cons3}[str(reward)]
@@ -178,6 +181,9 @@ def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterat
                                            else net.act(o[i:i + act_batch], probs[p][i:i + act_batch])
                                            for i in range(0, n_envs, act_batch)]))
             actions = torch.cat(acts, 1).to(torch.int8)
+            for p, is_ai in enumerate((ai_p1, ai_p2)):
+                if not is_ai:
+                    actions[:, p] = env.minimax_actions(p + 1)
             obs, reward, done, _ = env.step(actions, autoreset=True)
             masks = (1 - done.to(torch.float32)).unsqueeze(1)
             games += int(done.sum())

@@ -24,7 +24,9 @@ def model_actions(model, planes, prob_plane, env_vec):
 
 def rating(model, model2=None, n_games=10000, slides=None, width=10, gamemode="ice", fair=True, seed=0x5EED,
            max_steps=None, verbose=True):
-    """Returns a list of dicts {slide, p1_win, p2_win, draw, p1_rate} (play.py:76-98)."""
+    """Returns a list of dicts {slide, p1_win, p2_win, draw, p1_rate} (play.py:76-98).
+    model2="minimax" seats MinimaxPlayer(2, "voronoi") as player 2 — the "minimax rating" that
+    ACKTR.py:408-421 logs (there it is played net against net)."""
     model2 = model2 or model
     slides = [0.03 * i for i in range(13)] if slides is None else list(slides)     # play.py:74,98
     n = n_games * len(slides)
@@ -42,7 +44,7 @@ def rating(model, model2=None, n_games=10000, slides=None, width=10, gamemode="i
     for _ in range(max_steps or width * width):
         planes = pop_up_planes(obs.reshape(2 * n, S, S)).view(n, 2, 3, S, S)
         a1 = model_actions(model, planes[:, 0], prob_plane, env1)
-        a2 = model_actions(model2, planes[:, 1], prob_plane, env2)
+        a2 = env.minimax_actions(2) if isinstance(model2, str) else model_actions(model2, planes[:, 1], prob_plane, env2)
         obs, _, done, _ = env.step(torch.stack([a1, a2], 1), autoreset=False)
         if bool(done.all()):
             break

@@ -163,7 +163,12 @@ class Game:
         """One move of both players on the device (game.py:149-252).  Returns True."""
         if self.done:
             raise RuntimeError("stepping a finished game is undefined in the reference; make a new Game")
-        a = torch.tensor([[int(action_p1) & 3, int(action_p2) & 3]], dtype=torch.int8)
+        a = torch.tensor([[int(action_p1 or 0) & 3, int(action_p2 or 0) & 3]], dtype=torch.int8)
+        for i, pp in enumerate(self.pps):         # game.py:179-181: a non-AC player picks its own move
+            if hasattr(pp.player, "minimax"):
+                from .minimax import _kernel_mode
+                a = a.to(self._env.device)
+                a[:, i] = self._env.minimax_actions(i + 1, _kernel_mode(pp.player.mode))
         obs, _, _, _ = self._env.step(a, autoreset=False)
         o = obs[0].cpu().numpy().astype(np.int64)
         self._pull()

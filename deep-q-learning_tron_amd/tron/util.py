@@ -8,6 +8,7 @@ from config import *          # noqa: F401,F403  (the reference star-imports con
 from .game import *           # noqa: F401,F403
 from .game import Game, PositionPlayer
 from .player import ACPlayer, KeyboardPlayer  # noqa: F401
+from .minimax import MinimaxPlayer
 from .vec import pop_up_planes
 
 
@@ -24,12 +25,11 @@ def prob_map(x, width=None, height=None):         # util.py:38-45; size defaults
 
 
 def make_game(p1, p2, mode=None, gamemode=None, slide_pram=None, width=None):
-    """util.py:46-84.  p1/p2 False selected the Minimax opponent in the reference — out of scope."""
+    """util.py:46-84.  p1/p2 False puts MinimaxPlayer(2, "voronoi") in that seat (util.py:82-83)."""
     import config
-    if not (p1 and p2):
-        raise NotImplementedError("MinimaxPlayer opponents are out of scope (SURVEY.md §2); pass p1=p2=True")
     w = width or config.MAP_WIDTH
-    pps = [PositionPlayer(1, ACPlayer(), [0, 0]), PositionPlayer(2, ACPlayer(), [0, 0])]
+    pps = [PositionPlayer(1, ACPlayer() if p1 else MinimaxPlayer(2, "voronoi"), [0, 0]),
+           PositionPlayer(2, ACPlayer() if p2 else MinimaxPlayer(2, "voronoi"), [0, 0])]
     return Game(w, w, pps, gamemode, slide_pram, _fair_start=(mode == "fair"))
 
 

@@ -89,8 +89,8 @@ def test_game_env_scalars_and_setters():
     assert game.get_rate(0) == e["rate"][i, j] and game.get_rate() == e["rate_none"][i]
     fair = make_game(True, True, mode="fair", gamemode="ice", slide_pram=0.3)
     assert fair.slide == 0.3 and fair.mode == "ice"
-    with pytest.raises(NotImplementedError):
-        make_game(False, True)
+    from tron.minimax import MinimaxPlayer
+    assert isinstance(make_game(False, True).pps[0].player, MinimaxPlayer)      # util.py:82
 
 
 def test_main_loop_with_stub_model_and_ai_action():
@@ -203,6 +203,10 @@ def test_batched_rating_sweep():
     for r in res:
         assert r["p1_win"] + r["p2_win"] + r["draw"] == 400
         assert 0.3 < r["p1_rate"] < 0.7           # symmetric random play
+    # the "minimax rating" (ACKTR.py:408-421): a random policy against MinimaxPlayer(2, "voronoi") loses
+    res = play.rating(Rand(), "minimax", n_games=300, slides=[0.0, 0.15], width=10, verbose=False)
+    for r in res:
+        assert r["p1_win"] + r["p2_win"] + r["draw"] == 300 and r["p1_rate"] < 0.2
 
 
 def test_acktr_batched_trainer_runs():
@@ -214,3 +218,63 @@ def test_acktr_batched_trainer_runs():
     assert out["brain"].optimizer.steps == 6
     out = ACKTR.train(n_envs=48, width=6, model="mul", reward="3", iterations=2, acktr=False, gamemode="temper", seed=4)
     assert out["env_steps"] == 2 * 5 * 48 and all(np.isfinite(out["last_stats"]))
+    # ai_p2=False: player 2's moves come from the minimax search (ACKTR.py:286-287)
+    out = ACKTR.train(n_envs=32, width=6, model="mul", reward="3", iterations=2, acktr=False, seed=5, ai_p2=False)
+    assert out["env_steps"] == 2 * 5 * 32 and all(np.isfinite(out["last_stats"]))
+
+
+def _tiles_from_codes(codes, player):
+    """Invert Map.state_for_player(player) (map.py:67-84; slide tiles come back as bodies)."""
+    own_body, own_head, foe_body, foe_head = (1, 2, 3, 4) if player == 1 else (3, 4, 1, 2)
+    lut = {1: 0, -1: -1, -2: own_body, -3: foe_body, 10: own_head, -10: foe_head}
+    return np.vectorize(lut.get, otypes=[np.int8])(codes)
+
+
+def test_minimax_player_facade(monkeypatch):
+    """MinimaxPlayer(2, mode).action(map, id) -> Direction, on boards recorded from the reference;
+    random.getrandbits is pinned to the draw the reference's root consumed."""
+    import random
+    from golden.netgen import mm_stream
+    from tron.map import Map
+    from tron.minimax import MinimaxPlayer, Mode, Minimax
+    from tron.player import Direction
+    g = load_golden("minimax")
+    k = "W10_"
+    sel = np.nonzero(g[k + "depth"] == 2)[0][:60]
+    for i in sel:
+        pid = int(g[k + "player"][i])
+        m = Map.from_codes(10, _tiles_from_codes(g[k + "codes"][i], pid))
+        assert np.array_equal(m.state_for_player(pid), g[k + "codes"][i])
+        draw = int(mm_stream(int(g[k + "seed"][i]), 96)[int(g[k + "draws"][i]) - 1])
+        monkeypatch.setattr(random, "getrandbits", lambda n, d=draw: d)
+        mode = Mode.DISTWALL if int(g[k + "mode"][i]) == 1 else "voronoi"
+        d = MinimaxPlayer(2, mode).action(m, pid)
+        assert isinstance(d, Direction) and d.value == int(g[k + "move"][i]), int(i)
+        assert Minimax(2, mode).get_move(g[k + "codes"][i].T) == int(g[k + "move"][i])
+    with pytest.raises(Exception):
+        MinimaxPlayer(3, "voronoi").action(m, pid)          # depths the reference never builds
+
+
+def test_make_game_against_minimax():
+    """make_game(True, False): player 2 is MinimaxPlayer(2, "voronoi") and ignores the action it is
+    handed (game.py:179-181); each of its moves is one of the oracle's best moves for the map
+    before the step."""
+    import oracle
+    from tron.util import make_game
+    from tron.minimax import MinimaxPlayer
+    rng = np.random.default_rng(3)
+    games = moves = 0
+    while games < 10:
+        game = make_game(True, False)
+        assert isinstance(game.pps[1].player, MinimaxPlayer) and not isinstance(game.pps[0].player, MinimaxPlayer)
+        while not game.done:
+            before = game.map().state_for_player(2)
+            _, values, expanded, _ = oracle.minimax_move(before, 2, 0, np.zeros(8, np.uint32))
+            game.step(int(rng.integers(4)), None)
+            d = game.pps[1].player.direction.value - 1
+            if expanded.any():
+                best = values[expanded].max()
+                assert expanded[d] and values[d] == best, (games, moves)
+            moves += 1
+        games += 1
+    assert moves > 15
