@@ -34,27 +34,31 @@ using namespace tron;
 constexpr int MM_BLOCK = 256;
 constexpr int MM_WAVES = MM_BLOCK / 64;
 
-template <typename M>
-__device__ __forceinline__ M from_row_above(M v, int lane)           // lane r <- lane r-1
+// whole-wave shifts by one lane on the DPP path (no LDS crossbar round trip): wave_shr:1 hands lane
+// r the value of lane r-1, wave_shl:1 that of lane r+1; the lane with no source keeps `old` = 0
+__device__ __forceinline__ uint32_t dpp_from_above(uint32_t v)
 {
-    if constexpr (sizeof(M) == 8) {
-        const uint32_t lo = __shfl_up((uint32_t)v, 1), hi = __shfl_up((uint32_t)(v >> 32), 1);
-        return lane == 0 ? (M)0 : (M)(((uint64_t)hi << 32) | lo);
-    } else {
-        const uint32_t x = __shfl_up((uint32_t)v, 1);
-        return lane == 0 ? (M)0 : (M)x;
-    }
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t dpp_from_below(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);
 }
 template <typename M>
-__device__ __forceinline__ M from_row_below(M v, int lane)           // lane r <- lane r+1
+__device__ __forceinline__ M from_row_above(M v)                     // lane r <- lane r-1
 {
-    if constexpr (sizeof(M) == 8) {
-        const uint32_t lo = __shfl_down((uint32_t)v, 1), hi = __shfl_down((uint32_t)(v >> 32), 1);
-        return lane == 63 ? (M)0 : (M)(((uint64_t)hi << 32) | lo);
-    } else {
-        const uint32_t x = __shfl_down((uint32_t)v, 1);
-        return lane == 63 ? (M)0 : (M)x;
-    }
+    if constexpr (sizeof(M) == 8)
+        return (M)(((uint64_t)dpp_from_above((uint32_t)(v >> 32)) << 32) | dpp_from_above((uint32_t)v));
+    else
+        return (M)dpp_from_above((uint32_t)v);
+}
+template <typename M>
+__device__ __forceinline__ M from_row_below(M v)                     // lane r <- lane r+1
+{
+    if constexpr (sizeof(M) == 8)
+        return (M)(((uint64_t)dpp_from_below((uint32_t)(v >> 32)) << 32) | dpp_from_below((uint32_t)v));
+    else
+        return (M)dpp_from_below((uint32_t)v);
 }
 __device__ __forceinline__ int wave_sum(int v)
 {
@@ -136,8 +140,8 @@ __device__ __forceinline__ int voronoi(M open, M x3, int lane, Leaf L)
     M vis1 = f1, vis2 = f2;
     int acc = popc<M>(x3);
     while (__ballot((f1 | f2) != 0)) {
-        const M e1 = (M)((f1 << 1) | (f1 >> 1) | from_row_above<M>(f1, lane) | from_row_below<M>(f1, lane));
-        const M e2 = (M)((f2 << 1) | (f2 >> 1) | from_row_above<M>(f2, lane) | from_row_below<M>(f2, lane));
+        const M e1 = (M)((f1 << 1) | (f1 >> 1) | from_row_above<M>(f1) | from_row_below<M>(f1));
+        const M e2 = (M)((f2 << 1) | (f2 >> 1) | from_row_above<M>(f2) | from_row_below<M>(f2));
         const M n1 = e1 & open & ~vis1, n2 = e2 & open & ~vis2;
         acc += popc<M>(n1 & ~vis2 & ~n2) - popc<M>(n2 & ~vis1 & ~n1);
         vis1 |= n1;
