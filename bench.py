@@ -157,18 +157,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step = env.step_fn(autoreset=True)             # ctypes arguments bound once: the loop is launch-only
-    for _ in range(args.warmup):
-        step()
+    # The K steps go out through tron_rollout_random: K dependent launches of the fused kernel (in-kernel
+    # Philox actions, autoreset) on a side stream — the launch loop is native, not Python.
+    side = torch.cuda.Stream()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record()                                   # same stream the kernels are launched on
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    barrier()
-    wall = time.perf_counter() - t0
+    with torch.cuda.stream(side):
+        if args.incremental:                       # the in-place variant has no rollout entry point: launch loop
+            step = env.step_fn(autoreset=True)
+
+            def run(k):
+                for _ in range(k):
+                    step()
+        else:
+            run = env.rollout_random
+        run(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record()                               # same stream the kernels are launched on
+        run(args.steps)
+        ev1.record()
+        barrier()
+        wall = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps   # avg fused-kernel launch, HIP events
 
     t = torch.tensor([wall], dtype=torch.float64, device="cuda")

@@ -1361,6 +1361,22 @@ int tron_get_state(tron_handle h, int8_t *pos, int8_t *alive, int8_t *dir, int8_
     return launch_status();
 }
 
+namespace {
+
+int rollout_launches(tron_env *h, int32_t k_steps, int32_t obs_fmt, void *obs, StepOut out, hipStream_t st)
+{
+    for (int k = 0; k < k_steps; ++k) {
+        const int rc = h->P.obs_state ? launch_obs<true>(h, nullptr, TRON_STEP_AUTORESET, out, st)
+                                      : launch_fmt<true>(h, obs_fmt, nullptr, nullptr, TRON_STEP_AUTORESET, obs, out, st);
+        if (rc != TRON_OK) return rc;
+    }
+    if (h->P.obs_state && (obs_fmt == TRON_OBS_PLANES3_F32 || obs_fmt == TRON_OBS_PLANES4_F32) && k_steps > 0)
+        return obs_planes(h, obs_fmt, obs, st);
+    return TRON_OK;
+}
+
+}  // namespace
+
 int tron_rollout_random(tron_handle h, int32_t k_steps, int32_t obs_fmt, void *obs, unsigned long long *totals,
                         void *stream)
 {
@@ -1368,15 +1384,7 @@ int tron_rollout_random(tron_handle h, int32_t k_steps, int32_t obs_fmt, void *o
     if (k_steps < 0 || (obs_fmt != TRON_OBS_NONE) != (obs != nullptr)) return TRON_ERR_BAD_ARG;
     StepOut out{nullptr, nullptr, nullptr, totals};
     if (h->P.obs_state && obs_fmt == TRON_OBS_CODES_I8 && obs != h->P.obs_state) return TRON_ERR_BAD_ARG;
-    for (int k = 0; k < k_steps; ++k) {
-        const int rc = h->P.obs_state ? launch_obs<true>(h, nullptr, TRON_STEP_AUTORESET, out, S_(stream))
-                                      : launch_fmt<true>(h, obs_fmt, nullptr, nullptr, TRON_STEP_AUTORESET, obs, out,
-                                                         S_(stream));
-        if (rc != TRON_OK) return rc;
-    }
-    if (h->P.obs_state && (obs_fmt == TRON_OBS_PLANES3_F32 || obs_fmt == TRON_OBS_PLANES4_F32) && k_steps > 0)
-        return obs_planes(h, obs_fmt, obs, S_(stream));
-    return TRON_OK;
+    return rollout_launches(h, k_steps, obs_fmt, obs, out, S_(stream));
 }
 
 int tron_minimax_actions(tron_handle h, int32_t player, int32_t depth, int32_t mode, int8_t *out_actions,
