@@ -54,23 +54,32 @@ def pmc_traffic(envs, width, obs, mode):
     return None, None
 
 
-def cpu_baseline(width, budget_s=12.0):
-    """The CPU oracle (C restatement of the reference, `kind: port`) on one host core, same
-    unit of work: step + both observations + autoreset, i.i.d. uniform actions."""
+def cpu_baseline(width, budget_s=14.0):
+    """The CPU oracle (C restatement of the reference, `kind: port`), same unit of work: step + both
+    observations + autoreset, i.i.d. uniform actions.  Timed on one host core and on all the cores
+    this process may use (one env per OpenMP iteration); `value` is the all-cores rate."""
     import oracle
-    n = 4096
-    ref = oracle.VecOracle(n, width, seed=0x5EED)
-    ref.reset_all()
-    ref.step(autoreset=True)                       # warm
-    t0 = time.perf_counter()
-    steps = 0
-    while time.perf_counter() - t0 < budget_s:
-        ref.step(autoreset=True)
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    cores = len(os.sched_getaffinity(0))
+    rates = {}
+    for threads in ([1, cores] if cores > 1 else [1]):
+        n = 4096 * (1 if threads == 1 else max(1, min(16, threads // 2)))
+        oracle.set_threads(threads)
+        ref = oracle.VecOracle(n, width, seed=0x5EED)
+        ref.reset_all()
+        ref.step(autoreset=True)                   # warm
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < budget_s / 2:
+            ref.step(autoreset=True)
+            steps += 1
+        dt = time.perf_counter() - t0
+        rates[threads] = (n * steps / dt, steps, n, dt)
+    oracle.set_threads(1)
+    v, steps, n, dt = rates[cores]
+    return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port", "value_1core": rates[1][0],
             "sample": f"{steps} steps x {n} envs {width}x{width}, mode=None, autoreset, Philox actions, "
-                      f"{dt:.1f} s on 1 host core (oracle/libtron_oracle.so)"}
+                      f"{dt:.1f} s on {cores} host threads (oracle/libtron_oracle.so, OpenMP over envs); "
+                      f"1 core: {rates[1][0] / 1e6:.2f} M env-steps/s over {rates[1][3]:.1f} s"}
 
 
 def dqn_bench(args):

@@ -281,11 +281,16 @@ void orc_vec_init_env(orc_vec_t *v, int i, const int8_t start[4], const int16_t 
     v->episode[i] += 1;
 }
 
+static int orc_threads = 1;
+void orc_set_threads(int n) { orc_threads = n < 1 ? 1 : n; }
+
 void orc_vec_step(orc_vec_t *v, const int8_t *actions, const float *uniforms, int autoreset,
                   int8_t *obs_codes, int8_t *out_done, int8_t *out_winner, float *out_reward)
 {
     int G = (v->W + 2) * (v->W + 2);
     uint32_t key[2] = { v->seed, v->stream };
+    /* envs are independent (each Game owns its map, ACKTR.py:183,289): one env per OpenMP iteration */
+#pragma omp parallel for schedule(static) num_threads(orc_threads)
     for (int i = 0; i < v->N; ++i) {
         int8_t *grid = &v->grid[(size_t)i * G];
         int8_t act[2];

@@ -65,6 +65,7 @@ def lib():
         L.orc_state_for_player.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_pop_up.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_rewards.argtypes = [C.POINTER(Reward), C.c_int, C.c_int, C.c_uint32, C.c_void_p]
+        L.orc_set_threads.argtypes = [C.c_int]
         L.orc_minimax_move.restype = C.c_int
         L.orc_minimax_move.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p]
@@ -135,6 +136,11 @@ def rewards(table, done, winner, step_index=0):
 
 
 MM_VORONOI, MM_DISTWALL = 0, 1
+
+
+def set_threads(n):
+    """Host threads VecOracle.step uses (OpenMP over envs); results are identical for any n."""
+    lib().orc_set_threads(int(n))
 
 
 def minimax_move(codes, depth=2, mode=MM_VORONOI, stream=None):

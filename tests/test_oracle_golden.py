@@ -168,3 +168,21 @@ def test_minimax_matches_reference():
             assert used == int(g[k + "draws"][i]), where
             total += 1
     assert total > 2500
+
+
+def test_vec_oracle_is_thread_count_invariant():
+    """The OpenMP split of orc_vec_step (bench.py's all-cores cpu_baseline) changes nothing."""
+    a = oracle.VecOracle(1500, 10, mode="temper", seed=7)
+    b = oracle.VecOracle(1500, 10, mode="temper", seed=7)
+    a.reset_all()
+    b.reset_all()
+    try:
+        for _ in range(12):
+            oracle.set_threads(1)
+            ra = a.step(autoreset=True)
+            oracle.set_threads(4)
+            rb = b.step(autoreset=True)
+            for x, y in zip(ra, rb):
+                assert np.array_equal(x, y)
+    finally:
+        oracle.set_threads(1)
