@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--incremental", action="store_true",
                     help="secondary variant: in-place observation update (only touched cells and restarted boards "
                          "are written); reported under its own label, not comparable with the default line")
+    ap.add_argument("--actions", default="uniform", choices=["uniform", "nonreversing"],
+                    help="synthetic policy: i.i.d. uniform over the 4 headings (headline), or uniform over the 3 "
+                         "that do not reverse the last move (longer episodes; secondary line, SURVEY.md 8(d))")
     ap.add_argument("--dqn", action="store_true",
                     help="secondary metric: DQN transitions/s of the batched DDQN trainer (BASELINE configs[1] by "
                          "default: 4096 envs 10x10; use --envs/--width for others)")
@@ -172,13 +175,14 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(side):
         if args.incremental:                       # the in-place variant has no rollout entry point: launch loop
-            step = env.step_fn(autoreset=True)
+            step = env.step_fn(autoreset=True, nonreversing=args.actions == "nonreversing")
 
             def run(k):
                 for _ in range(k):
                     step()
         else:
-            run = env.rollout_random
+            def run(k):
+                env.rollout_random(k, nonreversing=args.actions == "nonreversing")
         run(args.warmup)
         barrier()
         t0 = time.perf_counter()
@@ -210,7 +214,8 @@ def main():
             achieved = b_alg * args.envs / (kern_ms * 1e-3) / 1e9
             hbm_bytes = hbm_src = None
         out = {
-            "metric": "env-steps/sec" if not args.incremental else "env-steps/sec (incremental observation update)",
+            "metric": "env-steps/sec" + (" (incremental observation update)" if args.incremental else "") +
+                      (" (non-reversing uniform actions)" if args.actions == "nonreversing" else ""),
             "value": total_env_steps / wall,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -223,7 +228,8 @@ def main():
             "dtype": "i8",
             "data": "synthetic",
             "config": {"workload": f"{args.envs} parallel {args.width}x{args.width} TRON envs per GPU, "
-                                   f"mode={args.mode}, random actions (in-kernel Philox), autoreset, "
+                                   f"mode={args.mode}, {'non-reversing ' if args.actions == 'nonreversing' else ''}random actions "
+                                   f"(in-kernel Philox), autoreset, "
                                    f"obs={args.obs} for both players",
                        "envs_per_gpu": args.envs, "grid": f"{args.width}x{args.width}",
                        "parallelism": f"env-shard x{world}"},

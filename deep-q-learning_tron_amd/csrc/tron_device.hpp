@@ -73,6 +73,16 @@ struct NewGame {
     int r1, c1, r2, c2, w0, w1, degree;
 };
 
+// One Philox word -> one player's action when the caller supplies none.  Default: uniform over the
+// four headings (DQN.py:64, DDQN.py:110).  nonreversing (TRON_STEP_NONREVERSING, the secondary
+// synthetic policy of SURVEY.md §8(d)): uniform over the three headings that do not reverse the
+// player's last move (`last` = its Direction value 1..4 from the meta word, 0 before its first move).
+__device__ __forceinline__ int draw_action(uint32_t x, uint32_t last, bool nonreversing)
+{
+    if (nonreversing && last) return (int)((last - 1u + 3u + __umulhi(x, 3u)) & 3u);
+    return (int)(x & 3u);
+}
+
 // util.make_game start placement + Game.__init__ draws (util.py:46-84, game.py:83,87) over the
 // reset stream of (env, episode): u32 number n is word n%4 of Philox(ctr = {env, episode,
 // RNG_RESET, n/4}).  (x, y) of the reference are (row, col).  Only player 1 is re-drawn on a

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, u
     const uint32_t nchunks = (uint32_t)ne * cpe;
     const int8_t *gtile = P.grid + (size_t)e0 * G;
     const bool sliding = (P.mode != TRON_MODE_NONE);
-    const bool autoreset = (flags & TRON_STEP_AUTORESET) != 0u;
+    const bool autoreset = (flags & TRON_STEP_AUTORESET) != 0u, nonrev = (flags & TRON_STEP_NONREVERSING) != 0u;
     const bool w0 = DO_STEP && tid < WAVE;
 
     STAMP(0);
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, u
                 if (!have_actions || (sliding && !have_uniforms)) {
                     uint32_t x[4];
                     philox4x32_10((uint32_t)env, R.tick, RNG_STEP, 0u, P.seed, P.stream, x);
-                    a[0] = (int)(x[0] & 3u);
-                    a[1] = (int)(x[1] & 3u);
+                    a[0] = draw_action(x[0], (R.meta >> 8) & 0xFu, nonrev);
+                    a[1] = draw_action(x[1], (R.meta >> 12) & 0xFu, nonrev);
                     if (!have_uniforms) {
                         u[0] = (float)(x[2] >> 8) * (1.0f / 16777216.0f);
                         u[1] = (float)(x[3] >> 8) * (1.0f / 16777216.0f);
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, ui
     const int ne = min(E, P.N - e0);
     const uint32_t nchunks = (uint32_t)ne * cpe;
     int8_t *otile = P.obs_state + (size_t)e0 * 2u * G;              // this tile's [ne][2][G] planes
-    const bool autoreset = (flags & TRON_STEP_AUTORESET) != 0u;
+    const bool autoreset = (flags & TRON_STEP_AUTORESET) != 0u, nonrev = (flags & TRON_STEP_NONREVERSING) != 0u;
     const bool mine = lane < ne;
     const int env = e0 + lane;
 
@@ -609,8 +609,8 @@ __global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, ui
                 if (!actions) {
                     uint32_t x[4];
                     philox4x32_10((uint32_t)env, R.tick, RNG_STEP, 0u, P.seed, P.stream, x);
-                    a[0] = (int)(x[0] & 3u);
-                    a[1] = (int)(x[1] & 3u);
+                    a[0] = draw_action(x[0], (R.meta >> 8) & 0xFu, nonrev);
+                    a[1] = draw_action(x[1], (R.meta >> 12) & 0xFu, nonrev);
                 } else {
                     a[0] = (int)(R.act & 3u);
                     a[1] = (int)((R.act >> 8) & 3u);
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(BLOCK) void k_inc(Params P, uint32_t cpe, const int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int env = blockIdx.x * WAVE + lane;
     const bool mine = env < P.N;
-    const bool autoreset = (flags & TRON_STEP_AUTORESET) != 0u;
+    const bool autoreset = (flags & TRON_STEP_AUTORESET) != 0u, nonrev = (flags & TRON_STEP_NONREVERSING) != 0u;
 
     uint4 st = make_uint4(0u, META_DONE, 0u, 0u), rs = make_uint4(0u, 0u, 0u, 0u);
     uint32_t act = 0u;
@@ -768,8 +768,8 @@ __global__ __launch_bounds__(BLOCK) void k_inc(Params P, uint32_t cpe, const int
             if (!actions) {
                 uint32_t x[4];
                 philox4x32_10((uint32_t)env, st.w, RNG_STEP, 0u, P.seed, P.stream, x);
-                a[0] = (int)(x[0] & 3u);
-                a[1] = (int)(x[1] & 3u);
+                a[0] = draw_action(x[0], (m >> 8) & 0xFu, nonrev);
+                a[1] = draw_action(x[1], (m >> 12) & 0xFu, nonrev);
             } else {
                 a[0] = (int)(act & 3u);
                 a[1] = (int)((act >> 8) & 3u);
@@ -1287,7 +1287,7 @@ int tron_step_encode(tron_handle h, const int8_t *actions, const float *uniforms
 {
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
     if ((obs_fmt != TRON_OBS_NONE) != (obs != nullptr)) return TRON_ERR_BAD_ARG;
-    if (flags & ~(TRON_STEP_AUTORESET | TRON_STEP_INCREMENTAL)) return TRON_ERR_BAD_ARG;
+    if (flags & ~(TRON_STEP_AUTORESET | TRON_STEP_INCREMENTAL | TRON_STEP_NONREVERSING)) return TRON_ERR_BAD_ARG;
     if ((flags & TRON_STEP_INCREMENTAL) && !h->P.obs_state) return TRON_ERR_UNSUPPORTED;
     StepOut out{out_done, out_winner, out_reward, nullptr};
     if (h->P.obs_state) {
@@ -1363,11 +1363,12 @@ int tron_get_state(tron_handle h, int8_t *pos, int8_t *alive, int8_t *dir, int8_
 
 namespace {
 
-int rollout_launches(tron_env *h, int32_t k_steps, int32_t obs_fmt, void *obs, StepOut out, hipStream_t st)
+int rollout_launches(tron_env *h, int32_t k_steps, uint32_t flags, int32_t obs_fmt, void *obs, StepOut out,
+                     hipStream_t st)
 {
     for (int k = 0; k < k_steps; ++k) {
-        const int rc = h->P.obs_state ? launch_obs<true>(h, nullptr, TRON_STEP_AUTORESET, out, st)
-                                      : launch_fmt<true>(h, obs_fmt, nullptr, nullptr, TRON_STEP_AUTORESET, obs, out, st);
+        const int rc = h->P.obs_state ? launch_obs<true>(h, nullptr, flags, out, st)
+                                      : launch_fmt<true>(h, obs_fmt, nullptr, nullptr, flags, obs, out, st);
         if (rc != TRON_OK) return rc;
     }
     if (h->P.obs_state && (obs_fmt == TRON_OBS_PLANES3_F32 || obs_fmt == TRON_OBS_PLANES4_F32) && k_steps > 0)
@@ -1377,14 +1378,15 @@ int rollout_launches(tron_env *h, int32_t k_steps, int32_t obs_fmt, void *obs, S
 
 }  // namespace
 
-int tron_rollout_random(tron_handle h, int32_t k_steps, int32_t obs_fmt, void *obs, unsigned long long *totals,
-                        void *stream)
+int tron_rollout_random(tron_handle h, int32_t k_steps, uint32_t flags, int32_t obs_fmt, void *obs,
+                        unsigned long long *totals, void *stream)
 {
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
     if (k_steps < 0 || (obs_fmt != TRON_OBS_NONE) != (obs != nullptr)) return TRON_ERR_BAD_ARG;
+    if (flags & ~TRON_STEP_NONREVERSING) return TRON_ERR_BAD_ARG;        // autoreset is implied
     StepOut out{nullptr, nullptr, nullptr, totals};
     if (h->P.obs_state && obs_fmt == TRON_OBS_CODES_I8 && obs != h->P.obs_state) return TRON_ERR_BAD_ARG;
-    return rollout_launches(h, k_steps, obs_fmt, obs, out, S_(stream));
+    return rollout_launches(h, k_steps, flags | TRON_STEP_AUTORESET, obs_fmt, obs, out, S_(stream));
 }
 
 int tron_minimax_actions(tron_handle h, int32_t player, int32_t depth, int32_t mode, int8_t *out_actions,

@@ -16,6 +16,7 @@ OBS = {None: OBS_NONE, "none": OBS_NONE, "codes": OBS_CODES_I8, "planes3": OBS_P
        "planes4": OBS_PLANES4_F32}
 STEP_AUTORESET = 1
 STEP_INCREMENTAL = 2
+STEP_NONREVERSING = 4
 
 _vp, _i32, _i64, _u32, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_double
 
@@ -34,7 +35,7 @@ SIGNATURES = {
     "tron_step_encode": (C.c_int, [_vp, _vp, _vp, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "tron_step": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "tron_encode": (C.c_int, [_vp, _i32, _vp, _vp]),
-    "tron_rollout_random": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "tron_rollout_random": (C.c_int, [_vp, _i32, _u32, _i32, _vp, _vp, _vp]),
     "tron_get_grid": (C.c_int, [_vp, _vp, _vp]),
     "tron_get_state": (C.c_int, [_vp] + [_vp] * 10),
     "tron_encode_codes": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),

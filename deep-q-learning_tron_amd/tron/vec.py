@@ -119,26 +119,29 @@ class VecTron:
                                            nat.stream_ptr()), "tron_reset")
         return self.encode() if self._fmt != nat.OBS_NONE else None
 
-    def step(self, actions=None, uniforms=None, autoreset=True):
+    def step(self, actions=None, uniforms=None, autoreset=True, nonreversing=False):
         """One Game.step for every env.  actions int8 [N,2] in 0..3 (None: i.i.d. uniform
-        from the env's Philox stream); uniforms f32 [N,2] for ice/temper (None: Philox).
+        from the env's Philox stream, or — nonreversing=True — uniform over the three headings
+        that do not reverse the player's last move); uniforms f32 [N,2] for ice/temper (None: Philox).
         Returns (obs, reward, done, winner) — tensors owned by this object, overwritten by
         the next call."""
         a = self._dev_arg(actions, torch.int8, (self.N, 2))
         u = self._dev_arg(uniforms, torch.float32, (self.N, 2))
-        flags = (nat.STEP_AUTORESET if autoreset else 0) | (nat.STEP_INCREMENTAL if self.incremental else 0)
+        flags = ((nat.STEP_AUTORESET if autoreset else 0) | (nat.STEP_INCREMENTAL if self.incremental else 0) |
+                 (nat.STEP_NONREVERSING if nonreversing else 0))
         with torch.cuda.device(self.device):
             nat.check(self._lib.tron_step_encode(self._h, nat.ptr(a), nat.ptr(u), flags, self._fmt,
                                                  nat.ptr(self.obs), nat.ptr(self.done), nat.ptr(self.winner),
                                                  nat.ptr(self.reward), nat.stream_ptr()), "tron_step_encode")
         return self.obs, self.reward, self.done, self.winner
 
-    def step_fn(self, autoreset=True):
+    def step_fn(self, autoreset=True, nonreversing=False):
         """A zero-argument callable that launches one random-action step (Philox actions) with all
         ctypes arguments bound once — for launch loops where Python argument handling per call
         would otherwise dominate a ~25 us kernel.  Same outputs as step()."""
         fn = self._lib.tron_step_encode
-        flags = (nat.STEP_AUTORESET if autoreset else 0) | (nat.STEP_INCREMENTAL if self.incremental else 0)
+        flags = ((nat.STEP_AUTORESET if autoreset else 0) | (nat.STEP_INCREMENTAL if self.incremental else 0) |
+                 (nat.STEP_NONREVERSING if nonreversing else 0))
         args = (self._h, None, None, flags, self._fmt, nat.ptr(self.obs),
                 nat.ptr(self.done), nat.ptr(self.winner), nat.ptr(self.reward), nat.stream_ptr())
 
@@ -156,10 +159,11 @@ class VecTron:
             nat.check(self._lib.tron_encode(self._h, fmt, nat.ptr(out), nat.stream_ptr()), "tron_encode")
         return out
 
-    def rollout_random(self, k_steps, totals=None):
+    def rollout_random(self, k_steps, totals=None, nonreversing=False):
         """k_steps random-action steps with autoreset (the BASELINE synthetic rollout)."""
         with torch.cuda.device(self.device):
-            nat.check(self._lib.tron_rollout_random(self._h, int(k_steps), self._fmt, nat.ptr(self.obs),
+            nat.check(self._lib.tron_rollout_random(self._h, int(k_steps), nat.STEP_NONREVERSING if nonreversing else 0,
+                                                    self._fmt, nat.ptr(self.obs),
                                                     nat.ptr(totals), nat.stream_ptr()), "tron_rollout_random")
 
     def minimax_actions(self, player, mode="voronoi", out=None, want_values=False):

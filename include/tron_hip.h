@@ -57,6 +57,9 @@ enum {
 #define TRON_STEP_INCREMENTAL 2u /* observation-is-state only: update the attached planes in place — write just
                                   * the <=4 cells a move touches and the boards that restart, instead of
                                   * rewriting both planes.  Same results, different traffic contract.       */
+#define TRON_STEP_NONREVERSING 4u /* when actions == NULL: each player draws uniformly from the three headings
+                                   * that do not reverse its last move (all four before its first move) instead
+                                   * of from all four — the longer-episode synthetic policy of SURVEY.md §8(d) */
 
 typedef struct tron_env *tron_handle;
 
@@ -129,9 +132,10 @@ int tron_step(tron_handle h, const int8_t *actions, const float *uniforms, uint3
 int tron_encode(tron_handle h, int32_t obs_fmt, void *obs, void *stream);
 
 /* K random-action steps with autoreset, one launch per step on `stream`
- * (the synthetic rollout of BASELINE.json).  totals u64[4] (device, may be
- * NULL) accumulates {env_steps, p1_wins, p2_wins, draws}.                     */
-int tron_rollout_random(tron_handle h, int32_t k_steps, int32_t obs_fmt, void *obs,
+ * (the synthetic rollout of BASELINE.json).  flags: 0 or TRON_STEP_NONREVERSING.
+ * totals u64[4] (device, may be NULL) accumulates {env_steps, p1_wins,
+ * p2_wins, draws}.                                                            */
+int tron_rollout_random(tron_handle h, int32_t k_steps, uint32_t flags, int32_t obs_fmt, void *obs,
                         unsigned long long *totals, void *stream);
 
 /* --- state read-back (parity dumps, the scalar Game facade) --------------------

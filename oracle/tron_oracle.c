@@ -284,7 +284,7 @@ void orc_vec_init_env(orc_vec_t *v, int i, const int8_t start[4], const int16_t 
 static int orc_threads = 1;
 void orc_set_threads(int n) { orc_threads = n < 1 ? 1 : n; }
 
-void orc_vec_step(orc_vec_t *v, const int8_t *actions, const float *uniforms, int autoreset,
+void orc_vec_step(orc_vec_t *v, const int8_t *actions, const float *uniforms, int flags,
                   int8_t *obs_codes, int8_t *out_done, int8_t *out_winner, float *out_reward)
 {
     int G = (v->W + 2) * (v->W + 2);
@@ -300,6 +300,12 @@ void orc_vec_step(orc_vec_t *v, const int8_t *actions, const float *uniforms, in
             uint32_t ctr[4] = { (uint32_t)i, v->tick[i], ORC_RNG_ACTION, 0 }, x[4];
             orc_philox4x32_10(ctr, key, x);
             act[0] = (int8_t)(x[0] & 3); act[1] = (int8_t)(x[1] & 3);
+            if (flags & ORC_STEP_NONREVERSING)
+                /* secondary synthetic policy: uniform over the three headings that do
+                 * not reverse the player's last one; a player that has not moved yet draws from all four */
+                for (int p = 0; p < 2; ++p)
+                    if (v->dir[2 * i + p])
+                        act[p] = (int8_t)((v->dir[2 * i + p] - 1 + 3 + (int)(((uint64_t)x[p] * 3u) >> 32)) & 3);
             u[0] = (float)(x[2] >> 8) * (1.0f / 16777216.0f);
             u[1] = (float)(x[3] >> 8) * (1.0f / 16777216.0f);
         }
@@ -321,7 +327,7 @@ void orc_vec_step(orc_vec_t *v, const int8_t *actions, const float *uniforms, in
         }
         if (out_done)   out_done[i] = v->done[i];
         if (out_winner) out_winner[i] = v->winner[i];
-        if (autoreset && v->done[i])
+        if ((flags & ORC_STEP_AUTORESET) && v->done[i])
             orc_vec_reset_env(v, i);                 /* ACKTR.py:307-310 */
         if (obs_codes) {
             orc_state_for_player(grid, G, 1, &obs_codes[((size_t)i * 2 + 0) * G]);

@@ -231,13 +231,13 @@ class VecOracle:
             if mask[i]:
                 lib().orc_vec_reset_env(C.byref(self.v), i)
 
-    def step(self, actions=None, uniforms=None, autoreset=False, want_obs=True):
+    def step(self, actions=None, uniforms=None, autoreset=False, want_obs=True, nonreversing=False):
         a = None if actions is None else np.ascontiguousarray(actions, np.int8)
         u = None if uniforms is None else np.ascontiguousarray(uniforms, np.float32)
         obs = np.empty((self.N, 2, self.G), np.int8) if want_obs else None
         done = np.empty(self.N, np.int8)
         winner = np.empty(self.N, np.int8)
         reward = np.empty((self.N, 2), np.float32)
-        lib().orc_vec_step(C.byref(self.v), _p(a), _p(u), int(bool(autoreset)), _p(obs), _p(done), _p(winner),
+        lib().orc_vec_step(C.byref(self.v), _p(a), _p(u), (1 if autoreset else 0) | (4 if nonreversing else 0), _p(obs), _p(done), _p(winner),
                            _p(reward))
         return obs, done, winner, reward

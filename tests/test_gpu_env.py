@@ -167,6 +167,40 @@ def test_hip_vs_oracle_philox(T, N, W, mode, fair, autoreset, reward):
     assert ref.episode.max() > 1
 
 
+@pytest.mark.parametrize("N,W,mode,variant", [(300, 10, None, "obs"), (300, 10, None, "grid"), (260, 24, None, "inc"),
+                                              (200, 8, "temper", "grid"), (90, 7, "ice", "grid")])
+def test_nonreversing_policy_vs_oracle(T, N, W, mode, variant):
+    """TRON_STEP_NONREVERSING: in-kernel actions drawn from the three headings that do not reverse the
+    last move (SURVEY.md §8(d) secondary policy) — same draws as the oracle, in every kernel; and
+    no player ever reverses."""
+    tv, oracle = T
+    env = tv.VecTron(N, W, mode=mode, seed=77, rank=1, obs_format="codes", slide=0.25,
+                     obs_is_state=variant != "grid", incremental=variant == "inc")
+    ref = oracle.VecOracle(N, W, mode=mode, seed=77, stream=1, slide=0.25)
+    env.reset()
+    ref.reset_all()
+    lens = []
+    for t in range(40):
+        before = ref.dir.copy()
+        obs, r, d, w = env.step(autoreset=True, nonreversing=True)
+        o, dd, ww, rr = ref.step(autoreset=True, nonreversing=True)
+        assert np.array_equal(np_(obs).reshape(N, 2, -1), o), t
+        assert np.array_equal(np_(d), dd) and np.array_equal(np_(w), ww) and np.array_equal(np_(r), rr), t
+        _compare_state(env, ref, t)
+        lens.append(dd.mean())
+        if mode is None:                           # no slides: the direction taken is the action drawn
+            st = np_(env.state()["dir"])
+            moved = (before > 0) & (dd[:, None] == 0)
+            assert not np.any(moved & (((st - before) % 4) == 2)), t
+    if mode is None:
+        assert np.mean(lens) < 0.34                # fewer games end per step than under uniform actions (0.36-0.43)
+    # through the rollout entry point as well
+    env.rollout_random(5, nonreversing=True)
+    for _ in range(5):
+        ref.step(autoreset=True, nonreversing=True, want_obs=False)
+    _compare_state(env, ref, "rollout")
+
+
 @pytest.mark.parametrize("W,mode", [(10, None), (6, "ice"), (9, "temper")])
 def test_explicit_actions_and_planes(T, W, mode):
     """Caller-supplied actions/uniforms + the f32 plane formats (pop_up, prob_map plane)."""
