@@ -48,8 +48,8 @@ class Net(nn.Module):
         return value, action_log_probs, entropy
 
     @staticmethod
-    def mish(x):                                            # ACNet.py:56-57
-        return x * torch.tanh(F.softplus(x))
+    def mish(x):                                            # ACNet.py:56-57, fused (see DQNNet.Net.mish)
+        return F.mish(x)
 
     # ---- the trunk every net shares (e.g. ACNet.py:97-116) -------------------------------
     def _build_trunk(self, in_channels, width):

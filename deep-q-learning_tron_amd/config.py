@@ -6,6 +6,11 @@ import os
 # MIOpen's default exhaustive "find" costs tens of seconds for every new (batch, shape) the CNN sees;
 # the trainers change batch sizes freely, so use the heuristic immediate mode unless the user chose one.
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+# In that mode MIOpen ranks solvers without a workspace, so every 3x3 weight gradient falls back to
+# the fp32 Winograd kernel: 9.9 ms per call at batch 4096 x 12x12, 65 % of the DDQN trainer's GPU time
+# (rocprofv3, round 1).  Without the Winograd family the implicit-GEMM kernels are picked instead:
+# 44.6 K -> 118 K learned transitions/s.  (MIOPEN_FIND_MODE=NORMAL reaches 137 K after ~50 s of search.)
+os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
 
 import torch  # noqa: E402
 
