@@ -62,25 +62,55 @@ def split_biases(model):
             split_biases(child)
 
 
+def extract_patches(a, kernel_size, padding, stride):
+    """[B, C, H, W] -> [B*OH*OW, C*kh*kw] input patches, one row per (sample, output position): the
+    reference's `_extract_patches` (kfac.py:28-38) flattened.  On the GPU this is ONE launch of
+    csrc/tron_kfac.hip (the fused kernel kfac.py:9-12 asks for); F.unfold runs one im2col per sample."""
+    kh, kw = kernel_size
+    if (a.is_cuda and a.dtype == torch.float32 and padding[0] == padding[1] and stride[0] == stride[1]):
+        from tron import _native as nat
+        a = a.contiguous()
+        B, C, H, W = a.shape
+        oh = (H + 2 * padding[0] - kh) // stride[0] + 1
+        ow = (W + 2 * padding[1] - kw) // stride[1] + 1
+        out = torch.empty(B * oh * ow, C * kh * kw, device=a.device, dtype=a.dtype)
+        with torch.cuda.device(a.device):
+            rc = nat.lib().tron_extract_patches(nat.ptr(a), B, C, H, W, kh, kw, padding[0], stride[0], nat.ptr(out),
+                                                nat.stream_ptr())
+        if rc == nat.OK:
+            return out
+        if rc != nat.ERR_UNSUPPORTED:
+            nat.check(rc, "tron_extract_patches")
+    cols = F.unfold(a, kernel_size, padding=padding, stride=stride)                      # [B, d, L]
+    return cols.transpose(1, 2).reshape(-1, cols.size(1))
+
+
 def cov_inputs(a, module, batch=None):
     """A-factor sample of one batch (kfac.py:41-58).  `batch` = size of the WHOLE batch when `a` is
     only a micro-batch of it (the result is then this micro-batch's additive share)."""
     share = 1.0 if batch is None else a.size(0) / batch
     batch = a.size(0) if batch is None else batch
     if isinstance(module, nn.Conv2d):
-        # im2col in batch chunks of <= ~256 MB so large rollouts (16 384 envs x 5 steps) stay bounded
         oh = (a.size(2) + 2 * module.padding[0] - module.kernel_size[0]) // module.stride[0] + 1
         ow = (a.size(3) + 2 * module.padding[1] - module.kernel_size[1]) // module.stride[1] + 1
         d = a.size(1) * module.kernel_size[0] * module.kernel_size[1]
-        chunk = max(1, min(batch, (64 << 20) // max(d * oh * ow, 1)))
-        if chunk >= batch:
-            cols = F.unfold(a, module.kernel_size, padding=module.padding, stride=module.stride)   # [B, d, L]
-            rows = cols.transpose(1, 2).reshape(-1, d) / (oh * ow)
+        if a.is_cuda:
+            # rows/(oh*ow) then rows^T (rows/batch) of the reference is P^T P / (batch (oh ow)^2): the patch
+            # matrix goes into the GEMM unscaled, in chunks of <= 1 GB so 16 384 envs x 5 steps stay bounded
+            chunk = max(1, (256 << 20) // max(d * oh * ow, 1))
+            acc = torch.zeros(d, d, device=a.device, dtype=a.dtype)
+            for i in range(0, a.size(0), chunk):
+                p = extract_patches(a[i:i + chunk], module.kernel_size, module.padding, module.stride)
+                acc.addmm_(p.t(), p)
+            return acc.mul_(1.0 / (batch * float(oh * ow) ** 2))
+        # im2col in batch chunks of <= ~256 MB
+        chunk = max(1, min(a.size(0), (64 << 20) // max(d * oh * ow, 1)))
+        if chunk >= a.size(0):
+            rows = extract_patches(a, module.kernel_size, module.padding, module.stride) / (oh * ow)
             return rows.t() @ (rows / batch)
         acc = torch.zeros(d, d, device=a.device, dtype=a.dtype)
-        for i in range(0, batch, chunk):
-            cols = F.unfold(a[i:i + chunk], module.kernel_size, padding=module.padding, stride=module.stride)
-            rows = cols.transpose(1, 2).reshape(-1, d) / (oh * ow)
+        for i in range(0, a.size(0), chunk):
+            rows = extract_patches(a[i:i + chunk], module.kernel_size, module.padding, module.stride) / (oh * ow)
             acc.addmm_(rows.t(), rows / batch)
         return acc
     if isinstance(module, AddBias):

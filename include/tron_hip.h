@@ -205,6 +205,15 @@ int tron_minimax_codes(const int8_t *codes, int64_t n, int32_t side, int32_t dep
                        const uint32_t *draws, int8_t *out_actions, int32_t *out_values, int8_t *out_expanded,
                        void *stream);
 
+/* ---- K-FAC helper of the ACKTR path (Net/kfac.py:28-38 `_extract_patches`; its TODO at kfac.py:9-12
+ * asks for this kernel) -------------------------------------------------------------------------- */
+/* x f32[batch][channels][height][width] -> out f32[batch*OH*OW][channels*kh*kw], row = (sample, oy, ox),
+ * column = c*kh*kw + i*kw + j, value x[n][c][oy*stride-pad+i][ox*stride-pad+j] or 0 outside:
+ * F.unfold(x, (kh,kw), padding=pad, stride=stride).transpose(1,2).reshape(-1, C*kh*kw) in one launch.
+ * channels*kh*(width+2*pad)*4 bytes must fit 64 KB of LDS (else TRON_ERR_UNSUPPORTED).           */
+int tron_extract_patches(const float *x, int64_t batch, int32_t channels, int32_t height, int32_t width,
+                         int32_t kh, int32_t kw, int32_t pad, int32_t stride, float *out, void *stream);
+
 const char *tron_strerror(int status);
 int tron_abi_version(void);
 

@@ -1,0 +1,71 @@
+"""GPU tests of the K-FAC patch-extraction kernel (csrc/tron_kfac.hip) behind Net/kfac.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+SHAPES = [  # B, C, H, W, k, pad, stride
+    (5, 3, 12, 12, 3, 1, 1),      # conv1 at 10x10
+    (3, 32, 26, 26, 3, 1, 1),     # conv2/3 at 24x24
+    (2, 64, 34, 34, 3, 1, 1),     # conv5/6 at 32x32
+    (4, 64, 17, 17, 7, 3, 2),     # conv7 after the pool at 32x32
+    (7, 5, 9, 11, 3, 0, 1),       # no padding, odd sizes, non-square
+    (6, 8, 13, 13, 3, 1, 2),      # strided 3x3
+    (1, 1, 3, 3, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("B,C,H,W,k,pad,stride", SHAPES)
+def test_extract_patches_equals_unfold(B, C, H, W, k, pad, stride):
+    """Pure data movement: bit-identical to F.unfold(...).transpose(1, 2).reshape(-1, C*k*k)."""
+    import torch.nn.functional as F
+    from Net.kfac import extract_patches
+    torch.manual_seed(B * 100 + C)
+    x = torch.randn(B, C, H, W, device="cuda")
+    got = extract_patches(x, (k, k), (pad, pad), (stride, stride))
+    cols = F.unfold(x, (k, k), padding=pad, stride=stride)
+    want = cols.transpose(1, 2).reshape(-1, cols.size(1))
+    assert got.shape == want.shape and torch.equal(got, want)
+    # a non-contiguous view (a micro-batch slice of a bigger rollout tensor) works too
+    big = torch.randn(B + 2, C, H, W, device="cuda")
+    assert torch.equal(extract_patches(big[1:-1], (k, k), (pad, pad), (stride, stride)),
+                       F.unfold(big[1:-1], (k, k), padding=pad, stride=stride).transpose(1, 2).reshape(-1, C * k * k))
+
+
+def test_extract_patches_unsupported_falls_back_to_unfold():
+    """Rows that do not fit 64 KB of LDS are refused by the kernel; the helper then uses F.unfold."""
+    import torch.nn.functional as F
+    import tron._native as nat
+    from Net.kfac import extract_patches
+    x = torch.randn(1, 256, 8, 40, device="cuda")
+    out = torch.empty(8 * 40, 256 * 9, device="cuda")
+    rc = nat.lib().tron_extract_patches(nat.ptr(x), 1, 256, 8, 40, 3, 3, 1, 1, nat.ptr(out), nat.stream_ptr())
+    assert rc == nat.ERR_UNSUPPORTED
+    want = F.unfold(x, (3, 3), padding=1, stride=1).transpose(1, 2).reshape(-1, 256 * 9)
+    assert torch.equal(extract_patches(x, (3, 3), (1, 1), (1, 1)), want)
+    assert nat.lib().tron_extract_patches(None, 1, 1, 3, 3, 3, 3, 1, 1, nat.ptr(out), nat.stream_ptr()) == nat.ERR_BAD_ARG
+    assert nat.lib().tron_extract_patches(nat.ptr(x), 1, 256, 8, 40, 9, 9, 0, 1, nat.ptr(out), nat.stream_ptr()) == nat.ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("C,side,k,pad,stride", [(32, 12, 3, 1, 1), (64, 9, 7, 3, 2)])
+def test_cov_inputs_gpu_matches_cpu(C, side, k, pad, stride):
+    """The A-factor from the kernel + one GEMM == the reference-ordered CPU computation (kfac.py:41-58),
+    also when the batch arrives in micro-batches."""
+    import torch.nn as nn
+    from Net.kfac import cov_inputs
+    torch.manual_seed(1)
+    conv = nn.Conv2d(C, 8, k, padding=pad, stride=stride)
+    a = torch.randn(24, C, side, side)
+    want = cov_inputs(a, conv)
+    got = cov_inputs(a.cuda(), conv)
+    assert torch.allclose(got.cpu(), want, rtol=1e-4, atol=1e-6)
+    parts = sum(cov_inputs(a[i:i + 8].cuda(), conv, 24) for i in range(0, 24, 8))
+    assert torch.allclose(parts.cpu(), want, rtol=1e-4, atol=1e-6)
