@@ -141,3 +141,80 @@ def test_ascii_window():
     win = Window(stream=buf)
     win.render_map(m)
     assert win.frames == 1 and "#A..#" in buf.getvalue()
+
+
+def test_tensorboard_event_file(tmp_path):
+    """tron/tbevents.py writes TensorBoard's on-disk format by hand (tensorboard is absent): CRC-32C
+    known answers, TFRecord framing, and the Event wire encoding decoded by google.protobuf against
+    message types declared here from the published event.proto / summary.proto field numbers."""
+    from tron import tbevents as tb
+    from tron.scalars import ScalarWriter
+    assert tb.crc32c(b"123456789") == 0xE3069283            # the CRC-32C check value
+    assert tb.crc32c(bytes(32)) == 0x8A9136AA               # RFC 3720 B.4: 32 bytes of zeros
+    assert tb.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43      # RFC 3720 B.4: 32 bytes of ones
+    w = ScalarWriter(str(tmp_path / "run"))
+    w.add_scalar("Training loss", 1.5, 20)
+    w.add_scalar("Epsilon", 0.875, 1 << 33)
+    w.close()
+    ev = tb.read_events(w.events_path)                      # verifies every checksum
+    assert ev[0]["file_version"] == "brain.Event:2"
+    assert (ev[1]["tag"], ev[1]["value"], ev[1]["step"]) == ("Training loss", 1.5, 20)
+    assert (ev[2]["tag"], ev[2]["value"], ev[2]["step"]) == ("Epsilon", 0.875, 1 << 33)
+    data = open(w.events_path, "rb").read()
+    with open(w.events_path, "wb") as f:                    # a flipped payload bit is caught
+        f.write(data[:-6] + bytes([data[-6] ^ 1]) + data[-5:])
+    with pytest.raises(ValueError):
+        tb.read_events(w.events_path)
+
+    pb = pytest.importorskip("google.protobuf")
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="tb_subset.proto", package="tbsub", syntax="proto3")
+    T = descriptor_pb2.FieldDescriptorProto
+    val = fd.message_type.add(name="Value")
+    val.field.add(name="tag", number=1, type=T.TYPE_STRING, label=T.LABEL_OPTIONAL)
+    val.field.add(name="simple_value", number=2, type=T.TYPE_FLOAT, label=T.LABEL_OPTIONAL)
+    summ = fd.message_type.add(name="Summary")
+    summ.field.add(name="value", number=1, type=T.TYPE_MESSAGE, type_name=".tbsub.Value", label=T.LABEL_REPEATED)
+    evm = fd.message_type.add(name="Event")
+    evm.field.add(name="wall_time", number=1, type=T.TYPE_DOUBLE, label=T.LABEL_OPTIONAL)
+    evm.field.add(name="step", number=2, type=T.TYPE_INT64, label=T.LABEL_OPTIONAL)
+    evm.field.add(name="file_version", number=3, type=T.TYPE_STRING, label=T.LABEL_OPTIONAL)
+    evm.field.add(name="summary", number=5, type=T.TYPE_MESSAGE, type_name=".tbsub.Summary", label=T.LABEL_OPTIONAL)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    Event = message_factory.GetMessageClass(pool.FindMessageTypeByName("tbsub.Event"))
+    e = Event()
+    e.ParseFromString(tb.encode_scalar_event("Duration", 2.25, 123456789012, 1700000000.5))
+    assert e.wall_time == 1700000000.5 and e.step == 123456789012
+    assert e.summary.value[0].tag == "Duration" and e.summary.value[0].simple_value == 2.25
+    e = Event()
+    e.ParseFromString(tb.encode_version_event(5.0))
+    assert e.file_version == "brain.Event:2" and e.wall_time == 5.0
+
+
+def test_png_window(tmp_path):
+    """Window(png_dir=...) writes the frame window.py:19-37 draws: reference colours and geometry."""
+    import struct
+    import zlib
+    from tron.map import Map, Tile
+    from tron.window import Window, render_rgb
+    import io
+    m = Map(3, 3, Tile.EMPTY, Tile.WALL)
+    m[0, 0] = Tile.PLAYER_ONE_HEAD
+    m[2, 1] = Tile.PLAYER_TWO_slide
+    img = render_rgb(m, 10)
+    assert img.shape == (50, 50, 3)
+    assert tuple(img[0, 0]) == (255, 255, 255) and tuple(img[10, 10]) == (0, 0, 0)
+    assert tuple(img[11, 11]) == (0, 34, 255) and tuple(img[20, 20]) == (0, 34, 255)      # head at (row 0, col 0), 0.1 offset
+    assert tuple(img[31 + 5, 21 + 5]) == (250, 100, 0)                                     # P2 slide at (row 2, col 1)
+    win = Window(stream=io.StringIO(), png_dir=str(tmp_path / "frames"), factor=10)
+    win.render_map(m)
+    data = open(tmp_path / "frames" / "frame_00001.png", "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    w, h, depth, ctype = struct.unpack(">IIBB", data[16:26])
+    assert (w, h, depth, ctype) == (50, 50, 8, 2)
+    idat_len = struct.unpack(">I", data[33:37])[0]
+    assert data[37:41] == b"IDAT"
+    raw = zlib.decompress(data[41:41 + idat_len])
+    rows = np.frombuffer(raw, np.uint8).reshape(50, 1 + 150)
+    assert np.all(rows[:, 0] == 0) and np.array_equal(rows[:, 1:].reshape(50, 50, 3), img)
