@@ -54,12 +54,31 @@ def pmc_traffic(envs, width, obs, mode):
     return None, None
 
 
+def host_cores():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box
+    shows all of the host's CPUs in the mask but grants a share of them)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return min(n, int(os.environ.get("TRON_CPU_BASELINE_THREADS", "16")))
+
+
 def cpu_baseline(width, budget_s=14.0):
     """The CPU oracle (C restatement of the reference, `kind: port`), same unit of work: step + both
     observations + autoreset, i.i.d. uniform actions.  Timed on one host core and on all the cores
     this process may use (one env per OpenMP iteration); `value` is the all-cores rate."""
     import oracle
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     rates = {}
     for threads in ([1, cores] if cores > 1 else [1]):
         n = 4096 * (1 if threads == 1 else max(1, min(16, threads // 2)))
