@@ -129,6 +129,13 @@ __device__ __forceinline__ void store_chunk_obs(void *__restrict__ obs, size_t e
 }
 
 // state words of one env, loaded ahead of the tile
+// chunk index -> env within the tile: i / cpe by multiplication with ceil(2^32 / cpe); that constant
+// does not fit 32 bits for cpe == 1 (boards of at most 16 cells), where the quotient is i itself
+__device__ __forceinline__ uint32_t chunk_env(uint32_t i, uint32_t cpe, uint32_t cpe_magic)
+{
+    return cpe == 1u ? i : __umulhi(i, cpe_magic);
+}
+
 struct EnvRegs {
     uint32_t pos, meta, eplen, tick;           // st4
     uint32_t envp, episode, nstart, nenvp;     // rs4
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, u
 #pragma unroll
         for (int k = 0; k < DK; ++k) {
             const uint32_t i = base + (uint32_t)tid + (uint32_t)k * BLOCK;
-            const uint32_t le = __umulhi(i, cpe_magic);
+            const uint32_t le = chunk_env(i, cpe, cpe_magic);
             const uint32_t c = (i - le * cpe) * 16u;
             if (i < nchunks) v[k] = load_chunk<ALIGNED>(gtile + (size_t)le * G + c);
         }
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, u
 
     // ---- 3b: the stream
     for (uint32_t i = (uint32_t)tid; i < nchunks; i += BLOCK) {
-        const uint32_t le = __umulhi(i, cpe_magic);
+        const uint32_t le = chunk_env(i, cpe, cpe_magic);
         const uint32_t k = i - le * cpe;
         const uint32_t c = k * 16u;
         const int nb = min(16, G - (int)c);                               // valid cells in this chunk
@@ -599,7 +606,7 @@ __global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, ui
 #pragma unroll
         for (int k = 0; k < DK; ++k) {
             const uint32_t i = base + (uint32_t)tid + (uint32_t)k * BLOCK;
-            const uint32_t le = __umulhi(i, cpe_magic);
+            const uint32_t le = chunk_env(i, cpe, cpe_magic);
             const uint32_t c = (i - le * cpe) * 16u;
             if (i < nchunks) v[k] = load_chunk<true>(otile + (size_t)le * 2u * G + c);   // player-1 plane
         }
@@ -683,7 +690,7 @@ __global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, ui
 
     // ---- 3b: the stream: both planes of every chunk
     for (uint32_t i = (uint32_t)tid; i < nchunks; i += BLOCK) {
-        const uint32_t le = __umulhi(i, cpe_magic);
+        const uint32_t le = chunk_env(i, cpe, cpe_magic);
         const uint32_t k = i - le * cpe;
         const uint32_t c = k * 16u;
         const int nb = min(16, G - (int)c);

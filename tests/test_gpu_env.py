@@ -201,6 +201,33 @@ def test_nonreversing_policy_vs_oracle(T, N, W, mode, variant):
     _compare_state(env, ref, "rollout")
 
 
+def test_fuzz_hip_vs_oracle(T):
+    """Property test: for arbitrary (N, W, mode, fair, autoreset, policy, kernel choice, seed) a few
+    Philox-driven steps leave HIP and oracle in identical states with identical outputs."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    tv, oracle = T
+
+    @settings(max_examples=30, deadline=None, derandomize=True)
+    @given(N=st.integers(1, 150), W=st.integers(2, 40), mode=st.sampled_from([None, "ice", "temper"]),
+           fair=st.booleans(), autoreset=st.booleans(), nonrev=st.booleans(), ois=st.booleans(),
+           seed=st.integers(0, 2 ** 32 - 1), slide=st.sampled_from([0.0, 0.15, 0.5, 1.0]))
+    def run(N, W, mode, fair, autoreset, nonrev, ois, seed, slide):
+        env = tv.VecTron(N, W, mode=mode, fair=fair, seed=seed, rank=5, obs_format="codes", slide=slide, obs_is_state=ois)
+        ref = oracle.VecOracle(N, W, mode=mode, seed=seed, stream=5, fair=fair, slide=slide)
+        env.reset()
+        ref.reset_all()
+        for t in range(6):
+            obs, r, d, w = env.step(autoreset=autoreset, nonreversing=nonrev)
+            o, dd, ww, rr = ref.step(autoreset=autoreset, nonreversing=nonrev)
+            assert np.array_equal(np_(obs).reshape(N, 2, -1), o)
+            assert np.array_equal(np_(d), dd) and np.array_equal(np_(w), ww) and np.array_equal(np_(r), rr)
+        _compare_state(env, ref, (N, W, mode, fair, autoreset, nonrev, ois, seed))
+        env.close()
+
+    run()
+
+
 @pytest.mark.parametrize("W,mode", [(10, None), (6, "ice"), (9, "temper")])
 def test_explicit_actions_and_planes(T, W, mode):
     """Caller-supplied actions/uniforms + the f32 plane formats (pop_up, prob_map plane)."""
@@ -254,6 +281,8 @@ def test_step_without_obs_and_totals(T):
 # ----------------------------------------------------- full size: properties --
 @pytest.mark.parametrize("N,W,mode,steps", [
     (1, 2, None, 6),            # smallest board, a single env (BASELINE configs[0] shape is N=1)
+    (70, 2, None, 6),           # 16-cell boards: ONE 16-byte chunk per env (found by the fuzz test: chunk -> env
+    (70, 2, "ice", 6),          #   mapping by multiplication needs its own case when cpe == 1)
     (1, 10, "temper", 20),
     (3, 96, None, 6),           # largest supported side: 98x98 cells, LDS tile of 4 envs
     (5, 95, "ice", 5),          # largest odd side (bytewise global access)
