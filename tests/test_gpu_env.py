@@ -228,6 +228,52 @@ def test_fuzz_hip_vs_oracle(T):
     run()
 
 
+def test_fuzz_formats_actions_resets(T):
+    """Property test over the other entry points: f32 plane formats, the incremental kernel, explicit
+    actions / slide uniforms, masked resets between steps, encode() into another format."""
+    pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    tv, oracle = T
+
+    @settings(max_examples=30, deadline=None, derandomize=True)
+    @given(N=st.integers(1, 90), W=st.integers(2, 34), mode=st.sampled_from([None, "ice", "temper"]),
+           fmt=st.sampled_from(["codes", "planes3", "planes4", "inc"]), explicit=st.booleans(),
+           seed=st.integers(0, 2 ** 32 - 1))
+    def run(N, W, mode, fmt, explicit, seed):
+        rng = np.random.RandomState(seed % (2 ** 31))
+        inc = fmt == "inc"
+        env = tv.VecTron(N, W, mode=mode, seed=seed, obs_format="codes" if inc else fmt, incremental=inc, slide=0.3)
+        ref = oracle.VecOracle(N, W, mode=mode, seed=seed, slide=0.3)
+        env.reset()
+        ref.reset_all()
+        S = W + 2
+        for t in range(6):
+            a = rng.randint(0, 4, size=(N, 2)).astype(np.int8) if explicit else None
+            u = (rng.randint(0, 1 << 24, size=(N, 2)) / float(1 << 24)).astype(np.float32) if explicit else None
+            obs, r, d, w = env.step(None if a is None else torch.from_numpy(a), None if u is None else torch.from_numpy(u),
+                                    autoreset=False)
+            o, dd, ww, rr = ref.step(a, u, autoreset=False)
+            if fmt in ("codes", "inc"):
+                assert np.array_equal(np_(obs).reshape(N, 2, -1), o)
+            else:
+                planes = np.stack([oracle.pop_up(o[i, p]) for i in range(N) for p in range(2)]).reshape(N, 2, 3, S, S)
+                assert np.array_equal(np_(obs)[:, :, :3], planes)
+                if fmt == "planes4":
+                    assert np.all(np_(obs)[:, :, 3] == np.float32(oracle.degree_slide(0.3)))
+            assert np.array_equal(np_(d), dd) and np.array_equal(np_(w), ww) and np.array_equal(np_(r), rr)
+            if t % 2 == 1:                          # DDQN-style: restart some of the finished games by hand
+                mask = (ref.done.astype(bool) & (rng.rand(N) < 0.7)).astype(np.int8)
+                env.reset(mask=torch.from_numpy(mask))
+                ref.reset_masked(mask)
+        _compare_state(env, ref, (N, W, mode, fmt, explicit, seed))
+        codes = env.encode("codes")
+        assert np.array_equal(np_(codes).reshape(N, 2, -1),
+                              np.stack([[oracle.state_for_player(ref.grid[i], p) for p in (1, 2)] for i in range(N)]))
+        env.close()
+
+    run()
+
+
 @pytest.mark.parametrize("W,mode", [(10, None), (6, "ice"), (9, "temper")])
 def test_explicit_actions_and_planes(T, W, mode):
     """Caller-supplied actions/uniforms + the f32 plane formats (pop_up, prob_map plane)."""
