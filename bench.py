@@ -38,7 +38,7 @@ def alg_bytes_per_env_step(width):
 
 
 def pmc_traffic(envs, width, obs, mode):
-    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes
+    """HBM bytes per STEP of the step kernel from the committed rocprofv3 PMC passes
     (profiles/r*_summary.json, made by scripts/pmc_summary.py: FETCH_SIZE x2 per the gfx950
     correction + WRITE_SIZE, KiB -> bytes).  Only valid for the exact workload it was taken on."""
     import glob
@@ -49,8 +49,8 @@ def pmc_traffic(envs, width, obs, mode):
         return None, None
     summ = json.load(open(files[-1]))
     for name, k in summ["kernels"].items():
-        if "k_obs<true>" in name:
-            return k["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+        if "k_obs_roll" in name:                   # one launch = steps_per_launch steps of every env
+            return k["hbm_bytes_per_launch"] / summ.get("steps_per_launch", 1), os.path.relpath(files[-1], ROOT)
     return None, None
 
 
@@ -135,8 +135,8 @@ def dqn_bench(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=320)     # multiples of the rollout's 64 steps per launch
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65536; --dqn: 4096)")
     ap.add_argument("--width", type=int, default=None, help="board side (default 24; --dqn: 10)")
     ap.add_argument("--obs", default="codes", choices=["codes", "planes3", "planes4"])
@@ -210,7 +210,14 @@ def main():
         ev1.record()
         barrier()
         wall = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps   # avg fused-kernel launch, HIP events
+    # launches in the timed region: the observation-is-state rollout is persistent (<= 64 steps per launch of
+    # k_obs_roll, include/tron_hip.h TRON_ROLLOUT_CHUNK); every other path launches once per step
+    persistent = (env.obs_is_state and not args.incremental and args.steps > 1
+                  and not os.environ.get("TRON_ROLL_PER_STEP"))
+    chunk = int(os.environ.get("TRON_ROLL_CHUNK", "64")) if persistent else 1
+    n_launches = (args.steps + chunk - 1) // chunk
+    step_ms = ev0.elapsed_time(ev1) / args.steps   # per step, HIP events on the launch stream
+    kern_ms = ev0.elapsed_time(ev1) / n_launches   # avg launch of the step kernel
 
     t = torch.tensor([wall], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -223,14 +230,14 @@ def main():
         if args.obs != "codes":                    # f32 planes: 2 players x C planes x 4 B per cell
             g = (args.width + 2) ** 2
             b_alg = g + 32 + 2 * (3 if args.obs == "planes3" else 4) * g * 4
-        achieved = b_alg * args.envs / (kern_ms * 1e-3) / 1e9
-        hbm_bytes, hbm_src = pmc_traffic(args.envs, args.width, args.obs, args.mode)
+        achieved = b_alg * args.envs / (step_ms * 1e-3) / 1e9
+        hbm_bytes, hbm_src = pmc_traffic(args.envs, args.width, args.obs, args.mode) if persistent else (None, None)
         if args.incremental:
             # bytes this variant needs per env-step: state words + outputs (~70 B), 2 cells read, 8 written,
             # and both planes (2G) for the ~36 % of envs that restart under random play
             g = (args.width + 2) ** 2
             b_alg = 80 + int(0.36 * 2 * g)
-            achieved = b_alg * args.envs / (kern_ms * 1e-3) / 1e9
+            achieved = b_alg * args.envs / (step_ms * 1e-3) / 1e9
             hbm_bytes = hbm_src = None
         out = {
             "metric": "env-steps/sec" + (" (incremental observation update)" if args.incremental else "") +
@@ -254,11 +261,14 @@ def main():
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if hbm_bytes is None else hbm_bytes / (kern_ms * 1e-3) / 1e9,
-                         "traffic_bytes_per_launch": hbm_bytes, "traffic_source": hbm_src,
+                         "traffic": None if hbm_bytes is None else hbm_bytes / (step_ms * 1e-3) / 1e9,
+                         "traffic_bytes_per_step": hbm_bytes, "traffic_source": hbm_src,
                          "kernel": ("k_inc (in-place update: touched cells + restarted boards only)" if args.incremental
-                                    else "k_obs<step> (observation-is-state, int8 codes)"), "kernel_ms": kern_ms,
-                         "alg_bytes_per_env_step": b_alg, "alg_bytes_per_launch": b_alg * args.envs},
+                                    else "k_obs_roll (persistent rollout of the observation-is-state step, int8 codes)"
+                                    if persistent else "k_obs / k_tile (one launch per step)"),
+                         "kernel_ms": kern_ms, "launches": n_launches, "steps_per_launch": args.steps / n_launches,
+                         "alg_bytes_per_env_step": b_alg,
+                         "alg_bytes_per_launch": b_alg * args.envs * args.steps / n_launches},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.width)

@@ -61,6 +61,8 @@ enum {
                                    * that do not reverse its last move (all four before its first move) instead
                                    * of from all four — the longer-episode synthetic policy of SURVEY.md §8(d) */
 
+#define TRON_ROLLOUT_CHUNK 64     /* steps per persistent rollout launch (tron_rollout_random) */
+
 typedef struct tron_env *tron_handle;
 
 /* --- lifetime ---------------------------------------------------------------
@@ -131,8 +133,12 @@ int tron_step(tron_handle h, const int8_t *actions, const float *uniforms, uint3
  * it (DDQN.py:243-255, game.py:294-304).                                      */
 int tron_encode(tron_handle h, int32_t obs_fmt, void *obs, void *stream);
 
-/* K random-action steps with autoreset, one launch per step on `stream`
- * (the synthetic rollout of BASELINE.json).  flags: 0 or TRON_STEP_NONREVERSING.
+/* K random-action steps with autoreset on `stream` (the synthetic rollout of
+ * BASELINE.json).  With an attached observation buffer (tron_attach_obs_state) the
+ * steps run as persistent launches of at most TRON_ROLLOUT_CHUNK steps each: envs
+ * never interact, so every workgroup steps its own envs without a chip-wide drain
+ * between steps — same results, bit for bit, as one launch per step (the other
+ * storage modes / formats do launch per step).  flags: 0 or TRON_STEP_NONREVERSING.
  * totals u64[4] (device, may be NULL) accumulates {env_steps, p1_wins,
  * p2_wins, draws}.                                                            */
 int tron_rollout_random(tron_handle h, int32_t k_steps, uint32_t flags, int32_t obs_fmt, void *obs,

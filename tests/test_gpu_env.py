@@ -324,6 +324,30 @@ def test_step_without_obs_and_totals(T):
     _compare_state(env, ref, "rollout")
 
 
+@pytest.mark.parametrize("N,W,K", [(300, 10, 37), (5000, 24, 70), (33, 2, 9)])
+def test_persistent_rollout_equals_stepwise(T, N, W, K):
+    """tron_rollout_random on the observation-is-state path is ONE launch in which every workgroup steps
+    its own tiles K times (k_obs_roll): same state, observations and totals as K oracle steps."""
+    tv, oracle = T
+    env = tv.VecTron(N, W, seed=2024, rank=6, obs_format="codes")
+    assert env.obs_is_state
+    ref = oracle.VecOracle(N, W, seed=2024, stream=6)
+    env.reset()
+    ref.reset_all()
+    totals = torch.zeros(4, dtype=torch.int64, device="cuda")
+    env.rollout_random(K, totals)
+    exp = np.zeros(4, np.int64)
+    for _ in range(K):
+        o, d, w, _ = ref.step(autoreset=True)
+        exp += [N, int(((d == 1) & (w == 1)).sum()), int(((d == 1) & (w == 2)).sum()), int(((d == 1) & (w == 0)).sum())]
+    assert np.array_equal(np_(totals), exp)
+    assert np.array_equal(np_(env.obs).reshape(N, 2, -1), o)
+    _compare_state(env, ref, "persistent rollout")
+    env.step()                                      # and the per-step kernel carries on from there
+    ref.step(autoreset=True)
+    _compare_state(env, ref, "step after rollout")
+
+
 # ----------------------------------------------------- full size: properties --
 @pytest.mark.parametrize("N,W,mode,steps", [
     (1, 2, None, 6),            # smallest board, a single env (BASELINE configs[0] shape is N=1)
