@@ -12,11 +12,11 @@ def per_kernel(path, counter):
             vals.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
     return {k: statistics.median(v) for k, v in vals.items()}
 
-def main(fetch_dir, write_dir, stats_csv, out_json, note):
+def main(fetch_dir, write_dir, stats_csv, out_json, note, steps_per_launch=1):
     f = per_kernel(glob.glob(fetch_dir + "/**/*counter_collection.csv", recursive=True)[0], "FETCH_SIZE")
     w = per_kernel(glob.glob(write_dir + "/**/*counter_collection.csv", recursive=True)[0], "WRITE_SIZE")
     stats = {r["Name"]: r for r in csv.DictReader(open(stats_csv))}
-    out = {"note": note, "kernels": {}}
+    out = {"note": note, "steps_per_launch": int(steps_per_launch), "kernels": {}}
     for k in sorted(set(f) | set(w)):
         if "k_tile" not in k and "k_obs" not in k:
             continue
@@ -30,4 +30,4 @@ def main(fetch_dir, write_dir, stats_csv, out_json, note):
     print(json.dumps(out, indent=1))
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:7])
