@@ -210,10 +210,9 @@ def main():
         ev1.record()
         barrier()
         wall = time.perf_counter() - t0
-    # launches in the timed region: the observation-is-state rollout is persistent (<= 64 steps per launch of
-    # k_obs_roll, include/tron_hip.h TRON_ROLLOUT_CHUNK); every other path launches once per step
-    persistent = (env.obs_is_state and not args.incremental and args.steps > 1
-                  and not os.environ.get("TRON_ROLL_PER_STEP"))
+    # launches in the timed region: the rollout is persistent (<= 64 steps per launch of k_obs_roll / k_tile_roll,
+    # include/tron_hip.h TRON_ROLLOUT_CHUNK); the incremental variant launches once per step
+    persistent = not args.incremental and args.steps > 1 and not os.environ.get("TRON_ROLL_PER_STEP")
     chunk = int(os.environ.get("TRON_ROLL_CHUNK", "64")) if persistent else 1
     n_launches = (args.steps + chunk - 1) // chunk
     step_ms = ev0.elapsed_time(ev1) / args.steps   # per step, HIP events on the launch stream
@@ -231,7 +230,8 @@ def main():
             g = (args.width + 2) ** 2
             b_alg = g + 32 + 2 * (3 if args.obs == "planes3" else 4) * g * 4
         achieved = b_alg * args.envs / (step_ms * 1e-3) / 1e9
-        hbm_bytes, hbm_src = pmc_traffic(args.envs, args.width, args.obs, args.mode) if persistent else (None, None)
+        hbm_bytes, hbm_src = (pmc_traffic(args.envs, args.width, args.obs, args.mode)
+                              if persistent and env.obs_is_state else (None, None))
         if args.incremental:
             # bytes this variant needs per env-step: state words + outputs (~70 B), 2 cells read, 8 written,
             # and both planes (2G) for the ~36 % of envs that restart under random play
@@ -264,8 +264,9 @@ def main():
                          "traffic": None if hbm_bytes is None else hbm_bytes / (step_ms * 1e-3) / 1e9,
                          "traffic_bytes_per_step": hbm_bytes, "traffic_source": hbm_src,
                          "kernel": ("k_inc (in-place update: touched cells + restarted boards only)" if args.incremental
+                                    else "k_obs / k_tile (one launch per step)" if not persistent
                                     else "k_obs_roll (persistent rollout of the observation-is-state step, int8 codes)"
-                                    if persistent else "k_obs / k_tile (one launch per step)"),
+                                    if env.obs_is_state else "k_tile_roll (persistent rollout, board-owning layout)"),
                          "kernel_ms": kern_ms, "launches": n_launches, "steps_per_launch": args.steps / n_launches,
                          "alg_bytes_per_env_step": b_alg,
                          "alg_bytes_per_launch": b_alg * args.envs * args.steps / n_launches},

@@ -288,13 +288,14 @@ __device__ inline void lane_move(const Params &P, unsigned char *g, const EnvReg
 }
 
 // ---------------------------------------------------------------- the kernel --
+// One tile of E envs through one step (or one encode); shared by k_tile (one tile per workgroup per
+// launch) and k_tile_roll (the persistent rollout, see k_obs_roll).
 template <int FMT, bool DO_STEP, bool ALIGNED>
-__global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, uint32_t cpe_magic,
-                                                const int8_t *__restrict__ actions,
-                                                const float *__restrict__ uniforms, uint32_t flags,
-                                                void *__restrict__ obs, StepOut out)
+__device__ __forceinline__ void tile_step(const Params &P, int E, uint32_t cpe, uint32_t cpe_magic,
+                                          const int8_t *__restrict__ actions, const float *__restrict__ uniforms,
+                                          uint32_t flags, void *__restrict__ obs, const StepOut &out, int tile_idx,
+                                          unsigned char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int G = P.G;
     uint4 *tile = reinterpret_cast<uint4 *>(smem);                  // [E*cpe]
     uint4 *tmpl = tile + (size_t)E * cpe;                           // [cpe] fresh board as chunks
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, u
     uint32_t *dirty = reinterpret_cast<uint32_t *>(plane4 + E);     // [ceil(E*cpe/32)] chunk bitmask
 
     const int tid = threadIdx.x;
-    const int e0 = blockIdx.x * E;
+    const int e0 = tile_idx * E;
     const int ne = min(E, P.N - e0);
     const int env = e0 + tid;
     const bool mine = tid < ne;
@@ -466,6 +467,29 @@ __global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, u
                                       (FMT == TRON_OBS_PLANES4_F32) ? plane4[le] : 0.0f);
     }
     STAMP(7);
+}
+
+template <int FMT, bool DO_STEP, bool ALIGNED>
+__global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, uint32_t cpe_magic,
+                                                const int8_t *__restrict__ actions,
+                                                const float *__restrict__ uniforms, uint32_t flags,
+                                                void *__restrict__ obs, StepOut out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    tile_step<FMT, DO_STEP, ALIGNED>(P, E, cpe, cpe_magic, actions, uniforms, flags, obs, out, (int)blockIdx.x, smem);
+}
+
+// persistent rollout on the board-owning layout (every mode / format / side): see k_obs_roll
+template <int FMT, bool ALIGNED>
+__global__ __launch_bounds__(BLOCK) void k_tile_roll(Params P, int E, uint32_t cpe, uint32_t cpe_magic, uint32_t flags,
+                                                     void *__restrict__ obs, StepOut out, int k_steps, int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    for (int s = 0; s < k_steps; ++s)
+        for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
+            tile_step<FMT, true, ALIGNED>(P, E, cpe, cpe_magic, nullptr, nullptr, flags, obs, out, t, smem);
+            __syncthreads();
+        }
 }
 
 // ------------------------------------------------- observation-is-state kernel --
@@ -1120,6 +1144,40 @@ int launch_one(tron_env *h, const int8_t *actions, const float *uniforms, uint32
     return launch_status();
 }
 
+template <int FMT, bool ALIGNED>
+int launch_roll_one(tron_env *h, int k_steps, uint32_t flags, void *obs, StepOut out, hipStream_t st)
+{
+    auto kern = k_tile_roll<FMT, ALIGNED>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        attr_done = true;
+    }
+    const int ntiles = (h->P.N + h->E - 1) / h->E;
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(BLOCK), h->smem, st, h->P, h->E, h->cpe, h->cpe_magic, flags, obs, out,
+                       k_steps, ntiles);
+    return launch_status();
+}
+
+int launch_roll_fmt(tron_env *h, int fmt, int k_steps, uint32_t flags, void *obs, StepOut out, hipStream_t st)
+{
+#define TRON_CASE(F)                                                                        \
+    case F:                                                                                 \
+        return h->aligned ? launch_roll_one<F, true>(h, k_steps, flags, obs, out, st)       \
+                          : launch_roll_one<F, false>(h, k_steps, flags, obs, out, st);
+    switch (fmt) {
+        TRON_CASE(TRON_OBS_NONE)
+        TRON_CASE(TRON_OBS_CODES_I8)
+        TRON_CASE(TRON_OBS_PLANES3_F32)
+        TRON_CASE(TRON_OBS_PLANES4_F32)
+    default:
+        return TRON_ERR_BAD_ARG;
+    }
+#undef TRON_CASE
+}
+
 template <bool DO_STEP>
 int launch_fmt(tron_env *h, int fmt, const int8_t *a, const float *u, uint32_t flags, void *obs, StepOut out,
                hipStream_t st)
@@ -1438,6 +1496,13 @@ int rollout_launches(tron_env *h, int32_t k_steps, uint32_t flags, int32_t obs_f
         if (rc != TRON_OK) return rc;
         k_steps = 0;
         if (obs_fmt == TRON_OBS_PLANES3_F32 || obs_fmt == TRON_OBS_PLANES4_F32) return obs_planes(h, obs_fmt, obs, st);
+        return TRON_OK;
+    }
+    if (!h->P.obs_state && !per_step && k_steps > 1) {             // board-owning layout: same idea, k_tile_roll
+        for (int left = k_steps; left > 0; left -= TRON_ROLLOUT_CHUNK) {
+            const int rc = launch_roll_fmt(h, obs_fmt, left < TRON_ROLLOUT_CHUNK ? left : TRON_ROLLOUT_CHUNK, flags, obs, out, st);
+            if (rc != TRON_OK) return rc;
+        }
         return TRON_OK;
     }
     for (int k = 0; k < k_steps; ++k) {

@@ -348,6 +348,29 @@ def test_persistent_rollout_equals_stepwise(T, N, W, K):
     _compare_state(env, ref, "step after rollout")
 
 
+@pytest.mark.parametrize("N,W,K,kw", [(260, 10, 70, dict(mode="temper")), (90, 7, 33, dict(mode="ice", slide=0.4)),
+                                      (150, 9, 20, dict(obs_format="planes3")), (64, 12, 65, dict(obs_format="planes4", mode="temper")),
+                                      (100, 10, 40, dict(obs_is_state=False))])
+def test_persistent_rollout_board_layout(T, N, W, K, kw):
+    """The same for the board-owning layout (k_tile_roll): every mode, format and side."""
+    tv, oracle = T
+    fmt = kw.get("obs_format", "codes")
+    env = tv.VecTron(N, W, seed=99, rank=2, **dict(dict(obs_format="codes"), **kw))
+    assert not env.obs_is_state
+    ref = oracle.VecOracle(N, W, mode=kw.get("mode"), seed=99, stream=2, slide=kw.get("slide", 0.15))
+    env.reset()
+    ref.reset_all()
+    env.rollout_random(K)
+    for _ in range(K):
+        o, _, _, _ = ref.step(autoreset=True)
+    _compare_state(env, ref, "board rollout")
+    if fmt == "codes":
+        assert np.array_equal(np_(env.obs).reshape(N, 2, -1), o)
+    else:
+        planes = np.stack([oracle.pop_up(o[i, p]) for i in range(N) for p in range(2)]).reshape(N, 2, 3, W + 2, W + 2)
+        assert np.array_equal(np_(env.obs)[:, :, :3], planes)
+
+
 # ----------------------------------------------------- full size: properties --
 @pytest.mark.parametrize("N,W,mode,steps", [
     (1, 2, None, 6),            # smallest board, a single env (BASELINE configs[0] shape is N=1)
