@@ -315,6 +315,7 @@ __device__ __forceinline__ void tile_step(const Params &P, int E, uint32_t cpe, 
     const bool sliding = (P.mode != TRON_MODE_NONE);
     const bool autoreset = (flags & TRON_STEP_AUTORESET) != 0u, nonrev = (flags & TRON_STEP_NONREVERSING) != 0u;
     const bool w0 = DO_STEP && tid < WAVE;
+    constexpr bool PLANES_BY_ROW = ALIGNED && (FMT == TRON_OBS_PLANES3_F32 || FMT == TRON_OBS_PLANES4_F32);
 
     STAMP(0);
     // ---- 1: state words first (their latency hides under the tile load), then the tile
@@ -463,8 +464,38 @@ __device__ __forceinline__ void tile_step(const Params &P, int E, uint32_t cpe, 
         }
         const uint32_t w[4] = {t.x, t.y, t.z, t.w};
         if (wb) store_chunk<ALIGNED>(P.grid + (size_t)(e0 + le) * G + c, nb, w);
-        store_chunk_obs<FMT, ALIGNED>(obs, (size_t)(e0 + le), G, c, nb, w,
-                                      (FMT == TRON_OBS_PLANES4_F32) ? plane4[le] : 0.0f);
+        if (PLANES_BY_ROW) {
+            if (DO_STEP && wb) tile[i] = t;                                // the plane pass reads the tile from LDS
+        } else {
+            store_chunk_obs<FMT, ALIGNED>(obs, (size_t)(e0 + le), G, c, nb, w,
+                                          (FMT == TRON_OBS_PLANES4_F32) ? plane4[le] : 0.0f);
+        }
+    }
+    if (PLANES_BY_ROW) {
+        // f32 planes, 16-byte aligned rows: one wave per env, one lane per 4 cells, so every store
+        // instruction writes 64 x 16 contiguous bytes of one plane (per-chunk stores would leave each
+        // lane its own 64-byte run: a quarter of every line per instruction)
+        constexpr int CH = (FMT == TRON_OBS_PLANES4_F32) ? 4 : 3;
+        __syncthreads();
+        const int wave = tid >> 6, lane = tid & 63, quads = G >> 2;
+        for (int le = wave; le < ne; le += BLOCK / WAVE) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(tile + (size_t)le * cpe);
+            float4 *ob = reinterpret_cast<float4 *>(reinterpret_cast<float *>(obs) + (size_t)(e0 + le) * 2u * CH * G);
+            const float p4 = (FMT == TRON_OBS_PLANES4_F32) ? plane4[le] : 0.0f;
+            for (int j = lane; j < quads; j += WAVE) {
+                const uint32_t wd = src[j];
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int ch = 0; ch < CH; ++ch) {
+                        const uint32_t bits = (ch < 3) ? plane_bits(ch, p != 0) : 0u;
+                        ob[(size_t)(p * CH + ch) * quads + j] =
+                            (ch == 3) ? make_float4(p4, p4, p4, p4)
+                                      : make_float4(plane_val(bits, wd), plane_val(bits, wd >> 8),
+                                                    plane_val(bits, wd >> 16), plane_val(bits, wd >> 24));
+                    }
+            }
+        }
     }
     STAMP(7);
 }
