@@ -14,6 +14,7 @@ MODE = {None: 0, "none": 0, "ice": 1, "temper": 2}                 # tron/game.p
 OBS_NONE, OBS_CODES_I8, OBS_PLANES3_F32, OBS_PLANES4_F32 = 0, 1, 2, 3
 OBS = {None: OBS_NONE, "none": OBS_NONE, "codes": OBS_CODES_I8, "planes3": OBS_PLANES3_F32,
        "planes4": OBS_PLANES4_F32}
+ABI_VERSION = 2                                                    # include/tron_hip.h TRON_ABI_VERSION
 STEP_AUTORESET = 1
 STEP_INCREMENTAL = 2
 STEP_NONREVERSING = 4
@@ -72,6 +73,9 @@ def lib():
         # library binds to THAT runtime: one HIP runtime per process, shared streams and pointers.
         import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
+        if L.tron_abi_version() != ABI_VERSION:
+            raise TronNativeError(f"{LIB_PATH} has ABI {L.tron_abi_version()}, this package binds ABI {ABI_VERSION}: rebuild it "
+                                  "(deep-q-learning_tron_amd/csrc/build.sh)")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError here = ABI mismatch, also loud
             fn.restype = res

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TRON_ABI_VERSION 1
+#define TRON_ABI_VERSION 2
 
 typedef enum {
     TRON_OK = 0,
