@@ -7,9 +7,10 @@ al. 2017), written for PyTorch-ROCm:
   `convK.add_bias._bias`, which is kept;
 * per module, running Kronecker factors  A = E[a a^T]  (inputs, via a forward pre-hook) and
   G = E[g g^T]  (output gradients of the sampled-Fisher loss, via a backward hook) with decay
-  0.99 (kfac.py:41-76,156-189).  Conv inputs are unfolded with `F.unfold` (one im2col kernel +
-  one GEMM on rocBLAS) — the fused `_extract_patches` the reference's TODO asks for
-  (kfac.py:9-12) — with the reference's normalisation by output positions;
+  0.99 (kfac.py:41-76,156-189).  On the GPU the conv input patches come from ONE launch of
+  csrc/tron_kfac.hip per chunk of samples — the fused `_extract_patches` the reference's TODO asks
+  for (kfac.py:9-12); `F.unfold` would run one im2col kernel per sample — followed by one rocBLAS
+  GEMM, with the reference's two normalisations folded into a single scalar;
 * every `Tf` steps the factors are eigendecomposed with `torch.linalg.eigh` (hipSOLVER on
   ROCm; `torch.symeig`, kfac.py:220-223, no longer exists); eigenvalues <= 1e-6 are zeroed;
 * the update is  v = Q_g [ (Q_g^T grad Q_a) / (d_g d_a^T + damping) ] Q_a^T,  KL-clipped by

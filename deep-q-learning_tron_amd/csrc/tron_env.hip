@@ -22,6 +22,16 @@
 // planes, ~4 dirty 16-byte chunks per env, and ~100 bytes of state/outputs per env.
 // A lone wave retires about one instruction per five cycles, so the serial section
 // between the barriers is LDS-only and ~200 instructions; everything heavier is off it.
+//
+// Kernels in this file:
+//   k_tile / tile_step      board-owning layout (grid[N][G] + caller's obs): every mode, format, side
+//   k_obs / obs_tile        observation-is-state (mode None, int8 codes, even side): the caller's
+//                           attached obs buffer is the env state; read G, write 2G per env-step
+//   k_obs_roll, k_tile_roll tron_rollout_random: the same per-tile step, but each workgroup steps
+//                           its own tile up to TRON_ROLLOUT_CHUNK times in ONE launch
+//   k_inc                   TRON_STEP_INCREMENTAL: writes only the touched cells + restarted boards
+//   k_reset, k_obs_reset, k_obs_to_grid, k_obs_planes, k_get_state, k_encode_codes, k_pop_up, ...
+//                           resets, read-back and stateless encodes
 #include "tron_device.hpp"
 #include "tron_minimax.hpp"
 #include "../../include/tron_hip.h"
