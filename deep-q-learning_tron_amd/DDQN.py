@@ -257,6 +257,35 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
                 learned_transitions_per_s=learn_steps * batch_size * world / dt, brain=brain)
 
 
-if __name__ == "__main__":
-    out = train()
+def main():
+    """`python DDQN.py` trained one hard-wired configuration in the reference (DDQN.py:206-349); the same
+    loop here takes its sizes from the command line.  Under torch.distributed.run every rank trains its
+    own env shard and replay shard and the gradients are averaged over RCCL."""
+    import argparse
+    import os
+    import torch.distributed as dist
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096, help="parallel self-play games per GPU")
+    ap.add_argument("--width", type=int, default=MAP_WIDTH)
+    ap.add_argument("--steps", type=int, default=2000, help="env steps (each steps every game once)")
+    ap.add_argument("--batch", type=int, default=BATCH_SIZE, help="learn batch (config.py:7)")
+    ap.add_argument("--capacity", type=int, default=1 << 20, help="replay slots in HBM")
+    ap.add_argument("--log-every", type=int, default=50)
+    ap.add_argument("--log-dir", default=None, help="TensorBoard event files + scalars.jsonl")
+    ap.add_argument("--save", default="save/DDQN.bak", help="target-net state_dict, like DDQN.py:326")
+    ap.add_argument("--resume", default=None, help="full checkpoint written by save_checkpoint")
+    a = ap.parse_args()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+        dist.init_process_group(os.environ.get("TRON_DIST_BACKEND", "nccl"))
+    if a.save:
+        os.makedirs(os.path.dirname(a.save) or ".", exist_ok=True)
+    out = train(n_envs=a.envs, width=a.width, steps=a.steps, batch_size=a.batch, capacity=a.capacity,
+                log_every=a.log_every, save_path=a.save, log_dir=a.log_dir, resume=a.resume)
     print({k: v for k, v in out.items() if k != "brain"})
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
