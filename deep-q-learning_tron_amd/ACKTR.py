@@ -9,6 +9,7 @@ train :162-437) with the env loop replaced by one VecTron launch per step.
   env is replaced and the observation stored is the NEW game's (ACKTR.py:307-310); masks = 1 - done.
 """
 import argparse
+import os
 import time
 
 import torch
@@ -208,6 +209,7 @@ def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterat
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if save_path:
+        os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
         torch.save(brain.actor_critic.state_dict(), save_path)          # ACKTR.py:399
     return dict(iterations=iterations, env_steps=iterations * num_steps * n_envs, games=games, seconds=dt,
                 env_steps_per_s=iterations * num_steps * n_envs / dt, updates=2 * iterations, brain=brain,
