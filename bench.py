@@ -191,6 +191,8 @@ def main():
     # The K steps go out through tron_rollout_random: K dependent launches of the fused kernel (in-kernel
     # Philox actions, autoreset) on a side stream — the launch loop is native, not Python.
     side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())  # the reset above ran on the current stream; torch's side streams
+    torch.cuda.synchronize()                       # do not order themselves behind it
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(side):
         if args.incremental:                       # the in-place variant has no rollout entry point: launch loop

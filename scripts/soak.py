@@ -29,6 +29,7 @@ env.reset()
 ref.reset_all()
 totals = torch.zeros(4, dtype=torch.int64, device="cuda")
 side = torch.cuda.Stream()
+torch.cuda.synchronize()              # reset ran on the default stream; side streams do not wait for it
 t0 = time.perf_counter()
 with torch.cuda.stream(side):
     env.rollout_random(a.steps, totals, nonreversing=a.nonreversing)
