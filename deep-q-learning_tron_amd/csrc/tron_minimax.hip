@@ -60,20 +60,23 @@ __device__ __forceinline__ M from_row_below(M v)                     // lane r <
     else
         return (M)dpp_from_below((uint32_t)v);
 }
-__device__ __forceinline__ int wave_sum(int v)
+// sums / minima over the GROUP consecutive lanes that hold one board (every lane gets the result)
+template <int GROUP>
+__device__ __forceinline__ int group_sum(int v)
 {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return __builtin_amdgcn_readfirstlane(v);
+    for (int o = GROUP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
 }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+template <int GROUP>
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t v)
 {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = GROUP / 2; o > 0; o >>= 1) {
         const uint32_t w = (uint32_t)__shfl_xor((int)v, o);
         v = w < v ? w : v;
     }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    return v;
 }
 template <typename M>
 __device__ __forceinline__ int popc(M v)
@@ -88,14 +91,14 @@ __device__ __forceinline__ int ctz(M v)          // v != 0
     else return __ffs((int)v) - 1;
 }
 // first set cell in the reference's argmax order: game_map[x][y] scanned x-major = column-major here
-template <typename M>
-__device__ __forceinline__ uint32_t first_colmajor(M mask, int lane)     // (col << 8) | row, or ~0u
+template <typename M, int GROUP>
+__device__ __forceinline__ uint32_t first_colmajor(M mask, int row)      // (col << 8) | row, or ~0u
 {
-    const uint32_t key = mask ? (((uint32_t)ctz(mask) << 8) | (uint32_t)lane) : 0xFFFFFFFFu;
-    return wave_min_u32(key);
+    const uint32_t key = mask ? (((uint32_t)ctz(mask) << 8) | (uint32_t)row) : 0xFFFFFFFFu;
+    return group_min_u32<GROUP>(key);
 }
 template <typename M>
-__device__ __forceinline__ M bit_at(int lane, int r, int c) { return lane == r ? (M)((M)1 << c) : (M)0; }
+__device__ __forceinline__ M bit_at(int row, int r, int c) { return row == r ? (M)((M)1 << c) : (M)0; }
 
 // run of set bits of `m` starting next to bit c, towards higher (dir=+1) or lower (dir=-1) bits
 template <typename M>
@@ -113,16 +116,17 @@ __device__ __forceinline__ int run_from(M m, int c, int dir)
     else return __clz((int)t);
 }
 
-// Minimax.distance_walls (minimax.py:128-147) on the leaf's empty-cell mask
-template <typename M>
-__device__ __forceinline__ int distance_walls(M open, int lane, int r, int c)
+// Minimax.distance_walls (minimax.py:128-147) on the leaf's empty-cell mask; gbase = first lane of the board
+template <typename M, int GROUP>
+__device__ __forceinline__ int distance_walls(M open, int gbase, int r, int c)
 {
-    // my row's mask at lane r -> everyone; the column as a mask over rows
+    // the row's mask at lane gbase + r -> every lane of the board; the column as a mask over its rows
     const M row = (M)(sizeof(M) == 8
-                          ? (((uint64_t)(uint32_t)__shfl((int)(uint32_t)((uint64_t)open >> 32), r) << 32) |
-                             (uint32_t)__shfl((int)(uint32_t)open, r))
-                          : (uint64_t)(uint32_t)__shfl((int)(uint32_t)open, r));
-    const uint64_t col = __ballot((open >> c) & 1);
+                          ? (((uint64_t)(uint32_t)__shfl((int)(uint32_t)((uint64_t)open >> 32), gbase + r) << 32) |
+                             (uint32_t)__shfl((int)(uint32_t)open, gbase + r))
+                          : (uint64_t)(uint32_t)__shfl((int)(uint32_t)open, gbase + r));
+    uint64_t col = __ballot((open >> c) & 1) >> gbase;
+    if constexpr (GROUP < 64) col &= (1ull << GROUP) - 1ull;
     const int up = run_from<uint64_t>(col, r, -1), down = run_from<uint64_t>(col, r, +1);
     const int right = run_from<M>(row, c, +1), left = run_from<M>(row, c, -1);
     return 4 + up + right + down + left;
@@ -132,11 +136,14 @@ struct Leaf {
     int s1r, s1c, s2r, s2c;
 };
 
-// get_voronoi_value on one leaf; `open` = cells equal to 1 in the leaf map, x3 = enemy bodies
-template <typename M>
-__device__ __forceinline__ int voronoi(M open, M x3, int lane, Leaf L)
+// get_voronoi_value on one leaf per board of the wave; `open` = cells equal to 1 in the leaf map, x3 =
+// enemy bodies.  Boards with active == false take no part (their frontier is empty from the start).  Rows
+// of neighbouring boards never leak into each other: the first lane of a board is its border row and the
+// last one is a border row or beyond the board, so `& open` clears whatever the wave-wide shift brings in.
+template <typename M, int GROUP>
+__device__ __forceinline__ int voronoi(M open, M x3, int row, Leaf L, bool active)
 {
-    M f1 = bit_at<M>(lane, L.s1r, L.s1c), f2 = bit_at<M>(lane, L.s2r, L.s2c);
+    M f1 = active ? bit_at<M>(row, L.s1r, L.s1c) : (M)0, f2 = active ? bit_at<M>(row, L.s2r, L.s2c) : (M)0;
     M vis1 = f1, vis2 = f2;
     int acc = popc<M>(x3);
     while (__ballot((f1 | f2) != 0)) {
@@ -150,38 +157,42 @@ __device__ __forceinline__ int voronoi(M open, M x3, int lane, Leaf L)
         f2 = n2;
     }
     acc -= popc<M>(open & ~vis1 & ~vis2);
-    return wave_sum(acc);
+    return group_sum<GROUP>(acc);
 }
 
-template <typename M>
+// GROUP lanes per board (one lane per row): 64 / GROUP boards share a wave.  Everything that was
+// wave-uniform for one board per wave is per-board here and lives in vector registers; the tree is walked
+// by all boards of the wave together, each skipping (by predicate) the moves it does not have.
+template <typename M, int GROUP>
 __global__ __launch_bounds__(MM_BLOCK) void k_minimax(MinimaxSrc src, int n, int S, int mode, int8_t *__restrict__ out_actions,
                                                      int32_t *__restrict__ out_values, int8_t *__restrict__ out_expanded)
 {
     extern __shared__ int8_t mm_lds[];
+    constexpr int BPW = 64 / GROUP;                                  // boards per wave
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int board = blockIdx.x * MM_WAVES + wave;
+    const int grp = lane / GROUP, row = lane % GROUP, gbase = grp * GROUP;
+    const int board = (blockIdx.x * MM_WAVES + wave) * BPW + grp;
     const int G = S * S;
-    int8_t *tile = mm_lds + (size_t)wave * (size_t)((G + 15) & ~15);
+    int8_t *tile = mm_lds + (size_t)(wave * BPW + grp) * (size_t)((G + 15) & ~15);
     const bool have = board < n;
 
     if (have) {
         if (src.codes) {
             const int8_t *p = src.codes + (size_t)board * src.stride;
-            for (int i = lane; i < G; i += 64) tile[i] = p[i];
+            for (int i = row; i < G; i += GROUP) tile[i] = p[i];
         } else {
             const int8_t *p = src.grid + (size_t)board * (size_t)G;
-            for (int i = lane; i < G; i += 64) tile[i] = code1(p[i], src.player == 2);
+            for (int i = row; i < G; i += GROUP) tile[i] = code1(p[i], src.player == 2);
         }
     }
     __syncthreads();
-    if (!have) return;
 
     // my row as masks
     M E = 0, X3 = 0, H10 = 0, Hm10 = 0;
-    if (lane < S) {
-        const int8_t *row = tile + lane * S;
+    if (have && row < S) {
+        const int8_t *rp = tile + row * S;
         for (int c = 0; c < S; ++c) {
-            const int v = row[c];
+            const int v = rp[c];
             const M b = (M)((M)1 << c);
             E |= (v == 1) ? b : (M)0;
             X3 |= (v == -3) ? b : (M)0;
@@ -189,30 +200,27 @@ __global__ __launch_bounds__(MM_BLOCK) void k_minimax(MinimaxSrc src, int n, int
             Hm10 |= (v == -10) ? b : (M)0;
         }
     }
-    const uint32_t kme = first_colmajor<M>(H10, lane), kop = first_colmajor<M>(Hm10, lane);
-    const int r0 = (int)(kme & 0xFFu), c0 = (int)(kme >> 8), r1 = (int)(kop & 0xFFu), c1 = (int)(kop >> 8);
-    const bool valid = kme != 0xFFFFFFFFu && kop != 0xFFFFFFFFu && r0 >= 1 && c0 >= 1 && r0 <= S - 2 && c0 <= S - 2 &&
-                       r1 >= 1 && c1 >= 1 && r1 <= S - 2 && c1 <= S - 2;
+    const uint32_t kme = first_colmajor<M, GROUP>(H10, row), kop = first_colmajor<M, GROUP>(Hm10, row);
+    int r0 = (int)(kme & 0xFFu), c0 = (int)(kme >> 8), r1 = (int)(kop & 0xFFu), c1 = (int)(kop >> 8);
+    const bool valid = have && kme != 0xFFFFFFFFu && kop != 0xFFFFFFFFu && r0 >= 1 && c0 >= 1 && r0 <= S - 2 &&
+                       c0 <= S - 2 && r1 >= 1 && c1 >= 1 && r1 <= S - 2 && c1 <= S - 2;
     bool done = false;
     uint32_t rnd = 0u;
-    if (src.st4) {
-        const uint4 st = src.st4[board];
-        done = (st.y & META_DONE) != 0;
-        uint32_t x[4];
-        philox4x32_10((uint32_t)board, st.w, RNG_MINIMAX, (uint32_t)src.player, src.seed, src.stream, x);
-        rnd = x[0];
-    } else if (src.rnd) {
-        rnd = src.rnd[board];
-    }
-    if (!valid || done) {       // no live pair of heads: the reference's behaviour is index arithmetic on junk
-        if (lane == 0) {
-            out_actions[board] = (int8_t)-1;
-            if (out_expanded) out_expanded[board] = 0;
-            if (out_values)
-                for (int a = 0; a < 4; ++a) out_values[(size_t)board * 4 + a] = 0;
+    if (have) {
+        if (src.st4) {
+            const uint4 st = src.st4[board];
+            done = (st.y & META_DONE) != 0;
+            uint32_t x[4];
+            philox4x32_10((uint32_t)board, st.w, RNG_MINIMAX, (uint32_t)src.player, src.seed, src.stream, x);
+            rnd = x[0];
+        } else if (src.rnd) {
+            rnd = src.rnd[board];
         }
-        return;
     }
+    // no live pair of heads: the reference's behaviour is index arithmetic on junk; such a board sits the
+    // search out (its lanes keep the wave's shuffles company) and reports move -1
+    const bool live = valid && !done;
+    if (!live) r0 = c0 = r1 = c1 = 1;                               // any in-range cell: nothing is used from it
 
     // actions 1..4 = UP, RIGHT, DOWN, LEFT (minimax.py:290-297); kept 0-based here
     auto d_row = [](int a) { return a == 0 ? -1 : a == 2 ? 1 : 0; };
@@ -222,8 +230,8 @@ __global__ __launch_bounds__(MM_BLOCK) void k_minimax(MinimaxSrc src, int n, int
 #pragma unroll 1
     for (int a = 0; a < 4; ++a) {
         const int tr = r0 + d_row(a), tc = c0 + d_col(a);
-        if (tile[tr * S + tc] != 1) continue;                    // get_blocked at the root (minimax.py:170-205)
-        expanded |= 1u << a;
+        const bool root_ok = live && tile[tr * S + tc] == 1;     // get_blocked at the root (minimax.py:170-205)
+        if (root_ok) expanded |= 1u << a;
         // the opponent's options on the map after my move: 2 bits per move (0 free, 1 blocked, 2 crash)
         uint32_t blocked = 0u;
         bool any_free = false;
@@ -234,31 +242,37 @@ __global__ __launch_bounds__(MM_BLOCK) void k_minimax(MinimaxSrc src, int n, int
             blocked |= ((v == 1) ? 0u : (v == 10) ? 2u : 1u) << (2 * b);
             any_free |= v == 1;
         }
-        if (!any_free) continue;                                  // all_blocked: the child keeps value 0
+        const bool child_ok = root_ok && any_free;                // all_blocked: the child keeps value 0
+        if (!__ballot(child_ok)) continue;
         int best = 0;
         bool first = true;
 #pragma unroll 1
         for (int b = 0; b < 4; ++b) {
             const uint32_t bl = (blocked >> (2 * b)) & 3u;
-            if (bl == 1u) continue;
+            const bool act = child_ok && bl != 1u;
+            if (!__ballot(act)) continue;
             const int ur = r1 + d_row(b), uc = c1 + d_col(b);
-            const M open = E & ~bit_at<M>(lane, tr, tc) & ~bit_at<M>(lane, ur, uc);
+            const M open = E & ~bit_at<M>(row, tr, tc) & ~bit_at<M>(row, ur, uc);
             Leaf L{tr, tc, ur, uc};
+            const uint32_t k = first_colmajor<M, GROUP>(open, row);
             if (bl == 2u) {                                       // crash: no 10 left, argmax = first 1, else the corner wall
-                const uint32_t k = first_colmajor<M>(open, lane);
                 L.s1r = (k == 0xFFFFFFFFu) ? 0 : (int)(k & 0xFFu);
                 L.s1c = (k == 0xFFFFFFFFu) ? 0 : (int)(k >> 8);
             }
             int v;
             if (mode == TRON_MINIMAX_DISTWALL)
-                v = distance_walls<M>(open, lane, L.s1r, L.s1c) - distance_walls<M>(open, lane, L.s2r, L.s2c);
+                v = distance_walls<M, GROUP>(open, gbase, L.s1r, L.s1c) - distance_walls<M, GROUP>(open, gbase, L.s2r, L.s2c);
             else
-                v = voronoi<M>(open, X3, lane, L);
-            if (first || v < best) best = v;
-            first = false;
+                v = voronoi<M, GROUP>(open, X3, row, L, act);
+            if (act) {
+                if (first || v < best) best = v;
+                first = false;
+            }
         }
+        if (child_ok) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) values[k] = (k == a) ? best : values[k];
+            for (int k = 0; k < 4; ++k) values[k] = (k == a) ? best : values[k];
+        }
     }
 
     int action;
@@ -290,11 +304,11 @@ __global__ __launch_bounds__(MM_BLOCK) void k_minimax(MinimaxSrc src, int n, int
                 --pick;
             }
     }
-    if (lane == 0) {
-        out_actions[board] = (int8_t)action;
-        if (out_expanded) out_expanded[board] = (int8_t)expanded;
+    if (have && row == 0) {
+        out_actions[board] = (int8_t)(live ? action : -1);
+        if (out_expanded) out_expanded[board] = (int8_t)(live ? expanded : 0u);
         if (out_values)
-            for (int a = 0; a < 4; ++a) out_values[(size_t)board * 4 + a] = values[a];
+            for (int a = 0; a < 4; ++a) out_values[(size_t)board * 4 + a] = live ? values[a] : 0;
     }
 }
 
@@ -304,13 +318,18 @@ int launch_minimax(const MinimaxSrc &src, int n, int S, int mode, int8_t *out_ac
                    int8_t *out_expanded, hipStream_t stream)
 {
     if (n <= 0) return TRON_OK;
-    const size_t smem = (size_t)MM_WAVES * (size_t)((S * S + 15) & ~15);
-    const dim3 grid((unsigned)((n + MM_WAVES - 1) / MM_WAVES)), block(MM_BLOCK);
-    if (S <= 32)
-        hipLaunchKernelGGL((k_minimax<uint32_t>), grid, block, smem, stream, src, n, S, mode, out_actions, out_values,
+    const int group = S <= 16 ? 16 : S <= 32 ? 32 : 64;               // lanes per board: one per row
+    const int per_block = MM_WAVES * (64 / group);
+    const size_t smem = (size_t)per_block * (size_t)((S * S + 15) & ~15);
+    const dim3 grid((unsigned)((n + per_block - 1) / per_block)), block(MM_BLOCK);
+    if (group == 16)
+        hipLaunchKernelGGL((k_minimax<uint32_t, 16>), grid, block, smem, stream, src, n, S, mode, out_actions, out_values,
+                           out_expanded);
+    else if (group == 32)
+        hipLaunchKernelGGL((k_minimax<uint32_t, 32>), grid, block, smem, stream, src, n, S, mode, out_actions, out_values,
                            out_expanded);
     else
-        hipLaunchKernelGGL((k_minimax<uint64_t>), grid, block, smem, stream, src, n, S, mode, out_actions, out_values,
+        hipLaunchKernelGGL((k_minimax<uint64_t, 64>), grid, block, smem, stream, src, n, S, mode, out_actions, out_values,
                            out_expanded);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
