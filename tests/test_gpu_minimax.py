@@ -86,7 +86,7 @@ def maze(W, flip):
     return img
 
 
-@pytest.mark.parametrize("W", [3, 8, 10, 24, 30, 31, 32, 33, 47, 62])
+@pytest.mark.parametrize("W", [3, 8, 10, 14, 15, 24, 30, 31, 32, 33, 47, 62])      # 16 / 32 / 64 lanes per board: S <= 16, 32, 64
 def test_minimax_random_boards_vs_oracle(T, W):
     tv, oracle = T
     rng = np.random.default_rng(1000 + W)
