@@ -105,6 +105,33 @@ def test_minimax_random_boards_vs_oracle(T, W):
             assert int(act[i]) + 1 == move, (W, mode, i)
 
 
+def test_minimax_fuzz_mixed_batches(T):
+    """Property test: batches whose boards differ wildly in fill and head distance share wavefronts (2 or
+    4 boards per wave) — each board's result must not depend on its neighbours in the batch."""
+    pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    tv, oracle = T
+
+    @settings(max_examples=20, deadline=None, derandomize=True)
+    @given(W=st.integers(3, 34), n=st.integers(1, 9), seed=st.integers(0, 2 ** 31 - 1), mode_id=st.integers(0, 1))
+    def run(W, n, seed, mode_id):
+        rng = np.random.default_rng(seed)
+        imgs = np.stack([soup(rng, W, rng.choice([0.0, 0.2, 0.6, 0.9]), bool(rng.integers(2))) for _ in range(n)])
+        if n > 2:
+            imgs[1] = -1                                       # a board without heads in the middle of a wave
+        draws = rng.integers(0, 2 ** 32, n, dtype=np.int64)
+        act, values, expanded = tv.minimax_codes(torch.from_numpy(imgs).cuda(), torch.from_numpy(draws).cuda(), MODES[mode_id])
+        act, values, expanded = np_(act), np_(values), bits(np_(expanded))
+        for i in range(n):
+            if n > 2 and i == 1:
+                assert act[i] == -1 and not expanded[i].any()
+                continue
+            move, ov, oe, _ = oracle.minimax_move(imgs[i], 2, mode_id, np.full(8, draws[i], np.uint32))
+            assert np.array_equal(expanded[i], oe) and np.array_equal(values[i], ov) and int(act[i]) + 1 == move, (W, n, i)
+
+    run()
+
+
 @pytest.mark.parametrize("kw", [dict(mode=None), dict(mode=None, obs_is_state=False), dict(mode="ice", slide=0.3)],
                          ids=["obs-state", "grid", "ice"])
 def test_minimax_env_actions(T, kw):
