@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from config import MAP_WIDTH
 from Net.DQNNet import conv7_side
+from Net.activations import mish as _mish
 
 
 class Net(nn.Module):
@@ -48,8 +49,8 @@ class Net(nn.Module):
         return value, action_log_probs, entropy
 
     @staticmethod
-    def mish(x):                                            # ACNet.py:56-57, fused (see DQNNet.Net.mish)
-        return F.mish(x)
+    def mish(x):                                            # ACNet.py:56-57, fused (Net/activations.py)
+        return _mish(x)
 
     # ---- the trunk every net shares (e.g. ACNet.py:97-116) -------------------------------
     def _build_trunk(self, in_channels, width):

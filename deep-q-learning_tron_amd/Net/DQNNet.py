@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from config import MAP_WIDTH
+from Net.activations import mish as _mish
 
 
 def conv7_side(side):
@@ -42,9 +43,9 @@ class Net(nn.Module):
 
     @staticmethod
     def mish(x):
-        """x * tanh(softplus(x)) (ACNet.py:56-57) as ONE kernel forward and one backward: the composed
-        form is three elementwise launches per activation and was 26 % of the trainer's GPU time."""
-        return F.mish(x)
+        """x * tanh(softplus(x)) (ACNet.py:56-57) as ONE kernel forward and one backward (Net/activations.py);
+        the composed form is three elementwise launches per activation."""
+        return _mish(x)
 
     def forward(self, x):                         # DQNNet.py:33-63
         x = x.to(self.conv1.weight.device)

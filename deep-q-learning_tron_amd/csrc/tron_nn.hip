@@ -1,0 +1,88 @@
+// tron_nn.hip — the activation of every net in the reference, mish(x) = x * tanh(softplus(x))
+// (Net/ACNet.py:56-57), as one memory-bound pass forward and one backward.
+//
+// torch's composed form is three elementwise launches; its fused F.mish is one, but spends ~86 us on a
+// 4096 x 32 x 12 x 12 tensor (75 MB in + out: ~15 us of traffic) evaluating exp, log1p and tanh in turn —
+// 14 % of the DDQN trainer's GPU time (rocprofv3, profiles/r01_dqn_kernel_stats.csv).  With e = exp(x):
+//     tanh(log1p(e)) = ((1+e)^2 - 1) / ((1+e)^2 + 1) = n / (n + 2),   n = e * (e + 2)
+// so one exp and one division give the forward value, with no cancellation anywhere (for x -> -inf,
+// n -> 2e and the quotient -> e; for x > 20 the result is x to fp32 precision — the same cut-over as
+// F.softplus's threshold — which also keeps e*e from overflowing).  Backward:
+//     d/dx = t + x * (1 - t^2) * e / (1 + e),   t = n / (n + 2),   1 - t^2 = (2 / (n + 2)) (1 + t).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tron_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float mish1(float x)
+{
+    if (x > 20.0f) return x;
+    const float e = expf(x);
+    const float n = e * (e + 2.0f);
+    return x * (n / (n + 2.0f));
+}
+__device__ __forceinline__ float mish_grad1(float x, float gy)
+{
+    if (x > 20.0f) return gy;
+    const float e = expf(x);
+    const float n = e * (e + 2.0f);
+    const float t = n / (n + 2.0f), u = 2.0f / (n + 2.0f);       // u = 1 - t without the cancellation
+    return gy * (t + x * (u * (1.0f + t)) * (e / (1.0f + e)));   // sech^2 = 1 - t^2 = (1 - t)(1 + t)
+}
+
+__global__ void k_mish_fwd(const float *__restrict__ x, float *__restrict__ y, size_t n4, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        reinterpret_cast<float4 *>(y)[i] = make_float4(mish1(v.x), mish1(v.y), mish1(v.z), mish1(v.w));
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = mish1(x[i]);
+}
+__global__ void k_mish_bwd(const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ gx, size_t n4,
+                           size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i], g = reinterpret_cast<const float4 *>(gy)[i];
+        reinterpret_cast<float4 *>(gx)[i] =
+            make_float4(mish_grad1(v.x, g.x), mish_grad1(v.y, g.y), mish_grad1(v.z, g.z), mish_grad1(v.w, g.w));
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        gx[i] = mish_grad1(x[i], gy[i]);
+}
+
+inline unsigned grid_for(size_t n4)
+{
+    size_t b = (n4 + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;      // 16 workgroups per CU, grid-stride beyond
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int tron_mish_fwd(const float *x, float *y, int64_t n, void *stream)
+{
+    if (n < 0 || (n > 0 && (!x || !y))) return TRON_ERR_BAD_ARG;
+    if (n == 0) return TRON_OK;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) return TRON_ERR_BAD_ARG;
+    const size_t n4 = (size_t)n / 4;
+    hipLaunchKernelGGL(k_mish_fwd, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, n4,
+                       (size_t)n);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int tron_mish_bwd(const float *x, const float *grad_y, float *grad_x, int64_t n, void *stream)
+{
+    if (n < 0 || (n > 0 && (!x || !grad_y || !grad_x))) return TRON_ERR_BAD_ARG;
+    if (n == 0) return TRON_OK;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(grad_x)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    const size_t n4 = (size_t)n / 4;
+    hipLaunchKernelGGL(k_mish_bwd, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, grad_y,
+                       grad_x, n4, (size_t)n);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}

@@ -220,6 +220,12 @@ int tron_minimax_codes(const int8_t *codes, int64_t n, int32_t side, int32_t dep
 int tron_extract_patches(const float *x, int64_t batch, int32_t channels, int32_t height, int32_t width,
                          int32_t kh, int32_t kw, int32_t pad, int32_t stride, float *out, void *stream);
 
+/* ---- the nets' activation (Net/ACNet.py:56-57: x * tanh(softplus(x))) as one pass each way --------- */
+/* y[i] = mish(x[i]); f32, 16-byte aligned buffers, n elements.                                        */
+int tron_mish_fwd(const float *x, float *y, int64_t n, void *stream);
+/* grad_x[i] = grad_y[i] * mish'(x[i]).                                                                 */
+int tron_mish_bwd(const float *x, const float *grad_y, float *grad_x, int64_t n, void *stream);
+
 const char *tron_strerror(int status);
 int tron_abi_version(void);
 

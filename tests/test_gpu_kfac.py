@@ -69,3 +69,38 @@ def test_cov_inputs_gpu_matches_cpu(C, side, k, pad, stride):
     assert torch.allclose(got.cpu(), want, rtol=1e-4, atol=1e-6)
     parts = sum(cov_inputs(a[i:i + 8].cuda(), conv, 24) for i in range(0, 24, 8))
     assert torch.allclose(parts.cpu(), want, rtol=1e-4, atol=1e-6)
+
+
+def test_mish_kernels_match_the_composed_form():
+    """csrc/tron_nn.hip: mish forward / backward against x * tanh(softplus(x)) and its autograd gradient
+    evaluated in float64, over the whole input range (incl. the > 20 cut-over and deep negatives)."""
+    import torch.nn.functional as F
+    from Net.activations import mish
+    torch.manual_seed(0)
+    x = torch.cat([torch.randn(100003) * 3, torch.linspace(-110, 110, 4001), torch.tensor([0.0, 20.0, 20.000002, -0.0, 88.0, -104.0])])
+    xg = x.cuda().requires_grad_(True)
+    y = mish(xg)
+    gy = torch.randn_like(x).cuda()
+    (gx,) = torch.autograd.grad(y, xg, gy)
+    x64 = x.double().requires_grad_(True)
+    y64 = x64 * torch.tanh(F.softplus(x64))
+    (gx64,) = torch.autograd.grad(y64, x64, gy.cpu().double())
+    err_y = ((y.cpu().double() - y64.detach()).abs() / y64.detach().abs().clamp_min(1e-30)).max().item()
+    err_g = ((gx.cpu().double() - gx64).abs() / (gx64.abs() + 0.1)).max().item()     # the derivative crosses zero near -1.19
+    assert err_y < 1e-6 and err_g < 2e-6, (err_y, err_g)          # a few fp32 ulps
+    # no-grad, non-contiguous and odd-length inputs
+    with torch.no_grad():
+        z = torch.randn(7, 5, 3, device="cuda").transpose(0, 2)
+        assert torch.allclose(mish(z), z * torch.tanh(F.softplus(z)), rtol=1e-6, atol=1e-7)
+
+
+def test_dqn_net_on_gpu_matches_cpu():
+    """The net with the HIP activation (GPU) against the same weights with F.mish (CPU): Q within 1e-5."""
+    from Net.DQNNet import Net
+    torch.manual_seed(3)
+    net = Net(3, 10).eval()
+    x = torch.randn(64, 3, 12, 12)
+    with torch.no_grad():
+        q_cpu = net(x)
+        q_gpu = net.cuda()(x.cuda()).cpu()
+    assert torch.allclose(q_cpu, q_gpu, rtol=1e-5, atol=1e-5)
