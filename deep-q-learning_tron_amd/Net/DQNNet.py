@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from config import MAP_WIDTH
-from Net.activations import mish as _mish
+from Net.activations import mish as _mish, conv_bias_mish as _conv_bias_mish
 
 
 def conv7_side(side):
@@ -49,6 +49,24 @@ class Net(nn.Module):
 
     def forward(self, x):                         # DQNNet.py:33-63
         x = x.to(self.conv1.weight.device)
+        if self.activation is not Net.mish and self.activation is not self.mish:   # a caller swapped the activation
+            return self._forward_plain(x)
+        x = _conv_bias_mish(self.conv1, x)
+        idx = x
+        x = _conv_bias_mish(self.conv2, x)
+        x = _conv_bias_mish(self.conv3, x, idx)
+        x = _conv_bias_mish(self.conv4, x)
+        idx = x
+        x = _conv_bias_mish(self.conv5, x)
+        x = _conv_bias_mish(self.conv6, x, idx)
+        x = self.pool(x)
+        x = _conv_bias_mish(self.conv7, x)
+        x = x.reshape(-1, self.flat)
+        x = self.dropout(self.activation(self.fc1(x)))
+        x = self.dropout(self.activation(self.fc2(x)))
+        return self.actor2(self.activation(self.actor1(x)))
+
+    def _forward_plain(self, x):
         x = self.activation(self.conv1(x))
         idx = x
         x = self.activation(self.conv2(x))

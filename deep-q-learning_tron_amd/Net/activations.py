@@ -35,3 +35,45 @@ def mish(x):
     if x.is_cuda and x.dtype == torch.float32 and x.numel() > 0:
         return _Mish.apply(x)
     return F.mish(x)
+
+
+class _BiasMish(torch.autograd.Function):
+    """mish(y + bias[c] (+ residual)) for a bias-free convolution output y [N, C, H, W]."""
+
+    @staticmethod
+    def forward(ctx, y, bias, residual):
+        from tron import _native as nat
+        pre = y.contiguous()                      # overwritten with y + bias (+ residual): saved for backward
+        res = None if residual is None else residual.contiguous()
+        out = torch.empty_like(pre)
+        N, C, H, W = pre.shape
+        with torch.cuda.device(pre.device):
+            nat.check(nat.lib().tron_bias_mish_fwd(nat.ptr(pre), nat.ptr(bias), nat.ptr(res), nat.ptr(out), N, C, H * W,
+                                                   nat.stream_ptr()), "tron_bias_mish_fwd")
+        ctx.save_for_backward(pre)
+        ctx.has_res = residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from tron import _native as nat
+        (pre,) = ctx.saved_tensors
+        g = grad_out.contiguous()
+        gp = torch.empty_like(pre)
+        with torch.cuda.device(pre.device):
+            nat.check(nat.lib().tron_mish_bwd(nat.ptr(pre), nat.ptr(g), nat.ptr(gp), pre.numel(), nat.stream_ptr()),
+                      "tron_mish_bwd")
+        return gp, gp.sum((0, 2, 3)), (gp if ctx.has_res else None)
+
+
+def conv_bias_mish(conv, x, residual=None):
+    """mish(conv(x) + residual) with the bias add, the residual add and the activation fused behind the
+    (bias-free) MIOpen convolution when the tensors allow it; otherwise the plain composition."""
+    if (x.is_cuda and x.dtype == torch.float32 and conv.bias is not None and isinstance(conv, torch.nn.Conv2d)):
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if (y.shape[2] * y.shape[3]) % 4 == 0 and y.numel() < 2 ** 32:
+            return _BiasMish.apply(y, conv.bias, residual)
+        y = y + conv.bias.view(1, -1, 1, 1)
+        return mish(y if residual is None else y + residual)
+    y = conv(x)
+    return mish(y if residual is None else y + residual)

@@ -54,6 +54,26 @@ __global__ void k_mish_bwd(const float *__restrict__ x, const float *__restrict_
         gx[i] = mish_grad1(x[i], gy[i]);
 }
 
+// pre = y + bias[c] (+ residual), out = mish(pre): what follows every convolution of the DQN net
+// (Net/DQNNet.py:33-63) in one pass instead of a broadcast add, a residual add and the activation.
+// y is overwritten with pre (backward needs it; nobody else needs y).  [N][C][HW] layout, HW % 4 == 0.
+__global__ void k_bias_mish_fwd(float *__restrict__ y, const float *__restrict__ bias, const float *__restrict__ res,
+                                float *__restrict__ out, uint32_t n4, uint32_t hw4, uint32_t C)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float b = bias[(i / hw4) % C];
+        float4 v = reinterpret_cast<const float4 *>(y)[i];
+        v.x += b; v.y += b; v.z += b; v.w += b;
+        if (res) {
+            const float4 r = reinterpret_cast<const float4 *>(res)[i];
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        reinterpret_cast<float4 *>(y)[i] = v;
+        reinterpret_cast<float4 *>(out)[i] = make_float4(mish1(v.x), mish1(v.y), mish1(v.z), mish1(v.w));
+    }
+}
+
 inline unsigned grid_for(size_t n4)
 {
     size_t b = (n4 + 255) / 256;
@@ -84,5 +104,20 @@ extern "C" int tron_mish_bwd(const float *x, const float *grad_y, float *grad_x,
     const size_t n4 = (size_t)n / 4;
     hipLaunchKernelGGL(k_mish_bwd, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, grad_y,
                        grad_x, n4, (size_t)n);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int tron_bias_mish_fwd(float *y_pre, const float *bias, const float *residual, float *out, int64_t batch,
+                                  int32_t channels, int32_t hw, void *stream)
+{
+    if (batch < 0 || channels < 1 || hw < 1 || !y_pre || !bias || !out) return TRON_ERR_BAD_ARG;
+    const int64_t n = batch * channels * hw;
+    if (n == 0) return TRON_OK;
+    if ((hw & 3) || n > 0xFFFFFFFFll) return TRON_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(y_pre) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(residual)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    const uint32_t n4 = (uint32_t)(n / 4);
+    hipLaunchKernelGGL(k_bias_mish_fwd, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y_pre, bias,
+                       residual, out, n4, (uint32_t)(hw / 4), (uint32_t)channels);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }

@@ -226,6 +226,11 @@ int tron_mish_fwd(const float *x, float *y, int64_t n, void *stream);
 /* grad_x[i] = grad_y[i] * mish'(x[i]).                                                                 */
 int tron_mish_bwd(const float *x, const float *grad_y, float *grad_x, int64_t n, void *stream);
 
+/* y_pre[n][c][i] += bias[c] (+ residual[n][c][i]); out = mish(y_pre): the bias add, residual add and
+ * activation after a convolution (Net/DQNNet.py:33-63) in one pass.  hw % 4 == 0, else UNSUPPORTED.     */
+int tron_bias_mish_fwd(float *y_pre, const float *bias, const float *residual, float *out, int64_t batch,
+                       int32_t channels, int32_t hw, void *stream);
+
 const char *tron_strerror(int status);
 int tron_abi_version(void);
 

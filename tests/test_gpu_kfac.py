@@ -104,3 +104,28 @@ def test_dqn_net_on_gpu_matches_cpu():
         q_cpu = net(x)
         q_gpu = net.cuda()(x.cuda()).cpu()
     assert torch.allclose(q_cpu, q_gpu, rtol=1e-5, atol=1e-5)
+
+
+def test_fused_bias_mish_path_matches_plain_forward_and_gradients():
+    """Net.forward with the fused bias + residual + mish pass behind each convolution against the plain
+    composition of the same ops on the same device: outputs and every parameter gradient."""
+    from Net.DQNNet import Net
+    torch.manual_seed(5)
+    net = Net(3, 10).cuda()
+    net.dropout.p = 0.0
+    x = torch.randn(48, 3, 12, 12, device="cuda")
+    w = torch.randn(48, 4, device="cuda")
+    (net(x) * w).sum().backward()
+    fused = [p.grad.clone() for p in net.parameters()]
+    q_fused = net(x).detach()
+    net.zero_grad()
+    (net._forward_plain(x) * w).sum().backward()
+    q_plain = net._forward_plain(x).detach()
+    assert torch.allclose(q_fused, q_plain, rtol=1e-5, atol=1e-6)
+    for (name, p), g in zip(net.named_parameters(), fused):
+        assert torch.allclose(p.grad, g, rtol=2e-4, atol=2e-5), name
+    # a 26x26 board (HW = 676) and the 9-cell conv7 output (HW % 4 != 0: falls back to the unfused ops)
+    big = Net(3, 24).cuda().eval()
+    xb = torch.randn(8, 3, 26, 26, device="cuda")
+    with torch.no_grad():
+        assert torch.allclose(big(xb), big._forward_plain(xb), rtol=1e-5, atol=1e-6)
