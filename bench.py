@@ -202,8 +202,8 @@ def main():
                 for _ in range(k):
                     step()
         else:
-            def run(k):
-                env.rollout_random(k, nonreversing=args.actions == "nonreversing")
+            def run(k, per_step=False):
+                env.rollout_random(k, nonreversing=args.actions == "nonreversing", per_step_launches=per_step)
         run(args.warmup)
         barrier()
         t0 = time.perf_counter()
@@ -212,6 +212,17 @@ def main():
         ev1.record()
         barrier()
         wall = time.perf_counter() - t0
+        # for reference, outside the measured job: the same K steps as one launch per step (what a caller
+        # that supplies actions every step gets)
+        per_step_ms = None
+        if not args.incremental and not os.environ.get("TRON_ROLL_PER_STEP"):
+            ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            run(min(args.warmup, 16), True)
+            ev2.record()
+            run(args.steps, True)
+            ev3.record()
+            torch.cuda.synchronize()
+            per_step_ms = ev2.elapsed_time(ev3) / args.steps
     # launches in the timed region: the rollout is persistent (<= 64 steps per launch of k_obs_roll / k_tile_roll,
     # include/tron_hip.h TRON_ROLLOUT_CHUNK); the incremental variant launches once per step
     persistent = not args.incremental and args.steps > 1 and not os.environ.get("TRON_ROLL_PER_STEP")
@@ -273,6 +284,10 @@ def main():
                          "alg_bytes_per_env_step": b_alg,
                          "alg_bytes_per_launch": b_alg * args.envs * args.steps / n_launches},
         }
+        if per_step_ms is not None:
+            out["per_step_launches"] = {"ms_per_step": per_step_ms, "value": args.envs * world / (per_step_ms * 1e-3),
+                                        "frac": b_alg * args.envs / (per_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "note": "same K steps, one kernel launch per step (k_obs / k_tile), this rank"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.width)
         print(json.dumps(out), flush=True)

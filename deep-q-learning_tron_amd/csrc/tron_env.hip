@@ -1549,7 +1549,9 @@ int rollout_persistent(tron_env *h, int32_t k_steps, uint32_t flags, StepOut out
 int rollout_launches(tron_env *h, int32_t k_steps, uint32_t flags, int32_t obs_fmt, void *obs, StepOut out,
                      hipStream_t st)
 {
-    static const bool per_step = getenv("TRON_ROLL_PER_STEP") != nullptr;       // A/B switch: one launch per step
+    static const bool env_per_step = getenv("TRON_ROLL_PER_STEP") != nullptr;   // A/B switch: one launch per step
+    const bool per_step = env_per_step || (flags & TRON_ROLLOUT_PER_STEP) != 0u;
+    flags &= ~TRON_ROLLOUT_PER_STEP;
     if (h->P.obs_state && !per_step && k_steps > 1) {
         const int rc = rollout_persistent(h, k_steps, flags, out, st);
         if (rc != TRON_OK) return rc;
@@ -1581,7 +1583,7 @@ int tron_rollout_random(tron_handle h, int32_t k_steps, uint32_t flags, int32_t 
 {
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
     if (k_steps < 0 || (obs_fmt != TRON_OBS_NONE) != (obs != nullptr)) return TRON_ERR_BAD_ARG;
-    if (flags & ~TRON_STEP_NONREVERSING) return TRON_ERR_BAD_ARG;        // autoreset is implied
+    if (flags & ~(TRON_STEP_NONREVERSING | TRON_ROLLOUT_PER_STEP)) return TRON_ERR_BAD_ARG;   // autoreset is implied
     StepOut out{nullptr, nullptr, nullptr, totals};
     if (h->P.obs_state && obs_fmt == TRON_OBS_CODES_I8 && obs != h->P.obs_state) return TRON_ERR_BAD_ARG;
     return rollout_launches(h, k_steps, flags | TRON_STEP_AUTORESET, obs_fmt, obs, out, S_(stream));

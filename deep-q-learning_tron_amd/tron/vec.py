@@ -159,10 +159,12 @@ class VecTron:
             nat.check(self._lib.tron_encode(self._h, fmt, nat.ptr(out), nat.stream_ptr()), "tron_encode")
         return out
 
-    def rollout_random(self, k_steps, totals=None, nonreversing=False):
-        """k_steps random-action steps with autoreset (the BASELINE synthetic rollout)."""
+    def rollout_random(self, k_steps, totals=None, nonreversing=False, per_step_launches=False):
+        """k_steps random-action steps with autoreset (the BASELINE synthetic rollout): persistent launches of
+        up to 64 steps each, or — per_step_launches=True — one launch per step (same results)."""
+        flags = (nat.STEP_NONREVERSING if nonreversing else 0) | (nat.ROLLOUT_PER_STEP if per_step_launches else 0)
         with torch.cuda.device(self.device):
-            nat.check(self._lib.tron_rollout_random(self._h, int(k_steps), nat.STEP_NONREVERSING if nonreversing else 0,
+            nat.check(self._lib.tron_rollout_random(self._h, int(k_steps), flags,
                                                     self._fmt, nat.ptr(self.obs),
                                                     nat.ptr(totals), nat.stream_ptr()), "tron_rollout_random")
 

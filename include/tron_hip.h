@@ -62,6 +62,7 @@ enum {
                                    * of from all four — the longer-episode synthetic policy of SURVEY.md §8(d) */
 
 #define TRON_ROLLOUT_CHUNK 64     /* steps per persistent rollout launch (tron_rollout_random) */
+#define TRON_ROLLOUT_PER_STEP 8u  /* tron_rollout_random flag: one launch per step instead (for A/B measurements) */
 
 typedef struct tron_env *tron_handle;
 
