@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py — env-steps/s of the HIP TRON env path on MI355X.
+"""bench.py — env-steps/s of the HIP TRON env path on MI355X (+ DQN transitions/s beside it).
 
-One "step" = one launch of the fused step + observation-encode + autoreset kernel over
-every env of this rank: both players of each env move once (i.i.d. uniform actions drawn
-in-kernel from Philox-4x32-10, as BASELINE.md §3 specifies), both players' int8 code-plane
-observations are written, finished games are replaced by fresh ones.  Workload =
-BASELINE.json configs[2]'s env side: 65 536 parallel 24x24 envs per GPU, mode=None.
+One "step" = one pass of the fused step + observation-encode + autoreset path over every env of this
+rank: both players of each env move once (i.i.d. uniform actions drawn in-kernel from Philox-4x32-10, as
+BASELINE.md §3 specifies), both players' int8 code-plane observations are written, finished games are
+replaced by fresh ones.  Workload = BASELINE.json configs[2]'s env side: 65 536 parallel 24x24 envs per
+GPU, mode=None.
 
-Multi-GPU: envs are independent, so each rank owns its own 65 536 envs and its own Philox
-stream (weak scaling, no data-path collective).  Launch as the driver does:
+The timed region (K steps, bracketed by barrier + synchronize, MAX over ranks) is repeated R times
+(--repeats, default 5); `value` is the median repeat, min / max are in the line.  Two further records ride
+on the same line: `per_step_launches` (the same K steps as one kernel launch per step — what a caller that
+supplies actions every step gets) and `dqn` (DDQN.train at BASELINE configs[1]: env-steps/s with the
+epsilon-greedy CNN policy in the loop and transitions/s consumed by learn()).
+
+Multi-GPU: envs are independent, so each rank owns its own 65 536 envs and its own Philox stream (weak
+scaling, no data-path collective); the DQN record adds the one real exchange, the gradient all-reduce.
+Launch as the driver does:
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
@@ -16,6 +23,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,6 +36,12 @@ for _p in (ROOT, PKG):
 N_ENVS = 65536          # per GPU (BASELINE.json configs[2] / [3])
 WIDTH = 24
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0   # the same guide's measured float4 copy rate: what a pure stream achieves
+F32_MATRIX_PEAK_TFLOPS = 157.3   # fp32-in MFMA = fp32 vector peak (guide, chip-level parameters)
+# the reference's own Python `Game.step` loop, one thread, survey container (the reference
+# cannot travel to the GPU box, so these are recorded figures, not re-timed here)
+REFERENCE_PYTHON_RECORDED = {"10x10": 3.5e3, "24x24": 0.9e3, "32x32": 0.5e3,
+                             "source": "BASELINE.md §2 (8 vCPU Xeon 2.1 GHz, 1 Python thread, i.i.d. uniform actions)"}
 
 
 def alg_bytes_per_env_step(width):
@@ -37,20 +51,22 @@ def alg_bytes_per_env_step(width):
     return 3 * g + 32
 
 
-def pmc_traffic(envs, width, obs, mode):
+def pmc_traffic(envs, width, obs, mode, kernel_tag, steps_per_launch):
     """HBM bytes per STEP of the step kernel from the committed rocprofv3 PMC passes
     (profiles/r*_summary.json, made by scripts/pmc_summary.py: FETCH_SIZE x2 per the gfx950
-    correction + WRITE_SIZE, KiB -> bytes).  Only valid for the exact workload it was taken on."""
+    correction + WRITE_SIZE, KiB -> bytes).  Only returned for the exact workload AND steps-per-launch
+    the passes were taken on: a persistent launch of a different length has a different L2 / Infinity
+    Cache carry-over between its steps."""
     import glob
     if (envs, width, obs, mode) != (N_ENVS, WIDTH, "codes", "none"):
         return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
-    if not files:
-        return None, None
-    summ = json.load(open(files[-1]))
-    for name, k in summ["kernels"].items():
-        if "k_obs_roll" in name:                   # one launch = steps_per_launch steps of every env
-            return k["hbm_bytes_per_launch"] / summ.get("steps_per_launch", 1), os.path.relpath(files[-1], ROOT)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary*.json")), reverse=True):
+        summ = json.load(open(path))
+        if int(summ.get("steps_per_launch", 1)) != int(steps_per_launch):
+            continue
+        for name, k in summ["kernels"].items():
+            if kernel_tag in name:
+                return k["hbm_bytes_per_launch"] / summ.get("steps_per_launch", 1), os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -96,40 +112,75 @@ def cpu_baseline(width, budget_s=14.0):
     oracle.set_threads(1)
     v, steps, n, dt = rates[cores]
     return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port", "value_1core": rates[1][0],
+            "reference_python_recorded": dict(REFERENCE_PYTHON_RECORDED,
+                                              value=REFERENCE_PYTHON_RECORDED.get(f"{width}x{width}")),
             "sample": f"{steps} steps x {n} envs {width}x{width}, mode=None, autoreset, Philox actions, "
                       f"{dt:.1f} s on {cores} host threads (oracle/libtron_oracle.so, OpenMP over envs); "
                       f"1 core: {rates[1][0] / 1e6:.2f} M env-steps/s over {rates[1][3]:.1f} s"}
 
 
-def dqn_bench(args):
-    """DDQN.train on VecTron + device replay: env-steps/s with the policy in the loop and transitions/s
-    consumed by learn() (SURVEY.md §8(d) metric 2).  One rank per GPU; gradients all-reduced over RCCL."""
+def net_forward_flops(width, in_channels=3):
+    """FLOPs (2 x MACs) of one DQNNet.Net forward per sample (Net/DQNNet.py:33-63): 36.1 MFLOP at 12x12."""
+    from Net.DQNNet import conv7_side
+    s = width + 2
+    px = s * s
+    f = 2 * px * (32 * in_channels * 9 + 2 * 32 * 32 * 9 + 64 * 32 * 9 + 2 * 64 * 64 * 9)
+    o = conv7_side(s)
+    f += 2 * o * o * 64 * 64 * 49
+    f += 2 * (64 * o * o * 256 + 256 * 128 + 128 * 64 + 64 * 4)
+    return f
+
+
+def max_over_ranks(x, world):
+    """MAX of a host float over all ranks (gloo rehearsal: through a CPU tensor)."""
+    if world == 1:
+        return x
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-    if world > 1:
-        dist.init_process_group(os.environ.get("TRON_DIST_BACKEND", "nccl"))
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def dqn_record(envs, width, steps, warmup, batch, repeats, world, rank):
+    """DDQN.train on VecTron + the HBM replay ring (BASELINE configs[1] by default): env-steps/s with the
+    epsilon-greedy policy in the loop and transitions/s consumed by learn() (SURVEY.md §8(d) metric 2).
+    One rank per GPU; every learn step all-reduces the flattened gradient when world > 1."""
+    import torch
+    import torch.distributed as dist
     import DDQN
-    envs, width = args.envs, args.width
-    DDQN.train(n_envs=envs, width=width, steps=max(args.warmup, 4), learn_every=2, batch_size=args.batch,
-               capacity=1 << 20, log_every=0)                                  # warm-up (MIOpen find, allocator)
-    out = DDQN.train(n_envs=envs, width=width, steps=args.steps, learn_every=2, batch_size=args.batch,
-                     capacity=1 << 20, log_every=0)
-    if rank == 0:
-        print(json.dumps({
-            "metric": "dqn-transitions/sec", "value": out["learned_transitions_per_s"], "unit": "transitions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "env_steps_per_s_with_policy": out["env_steps_per_s"],
-            "transitions_pushed_per_s": out["transitions_pushed"] / out["seconds"],
+    out = DDQN.train(n_envs=envs, width=width, steps=max(warmup, 4), learn_every=2, batch_size=batch,
+                     capacity=1 << 20, log_every=0)                            # warm-up (MIOpen find, allocator)
+    brain = out["brain"]
+    runs = []
+    for _ in range(repeats):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        o = DDQN.train(n_envs=envs, width=width, steps=steps, learn_every=2, batch_size=batch, capacity=1 << 20,
+                       log_every=0, brain=brain)
+        runs.append((max_over_ranks(o["seconds"], world), o))
+    runs.sort(key=lambda x: x[0])
+    sec, o = runs[len(runs) // 2]
+    learned = o["learn_steps"] * batch * world
+    f_fwd = net_forward_flops(width)
+    # per iteration of the loop: the policy forward on 2N observations (eval, no grad); per learn step on a
+    # batch B: forward + backward of the local net on s (~3x forward), forward-only local and target on s'
+    flops = f_fwd * (2 * envs * steps + o["learn_steps"] * batch * (3 + 2)) * world
+    return {"metric": "dqn-transitions/sec", "value": learned / sec, "unit": "transitions/s",
+            "env_steps_per_s_with_policy": envs * steps * world / sec,
+            "transitions_pushed_per_s": 2 * envs * steps * world / sec,
+            "steps": steps, "repeats": repeats, "seconds_min_med_max": [runs[0][0], sec, runs[-1][0]],
+            "learn_batch": batch, "learn_every_env_steps": 2, "dtype": "f32",
             "config": {"workload": f"{envs} parallel {width}x{width} self-play envs per GPU, DDQN + target net, "
-                                   f"1M-slot HBM replay, learn batch {args.batch} every 2 env-steps, eps-greedy "
-                                   f"policy = the 7-conv CNN on f32 planes"}}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+                                   f"1M-slot HBM replay, learn batch {batch} every 2 env-steps, eps-greedy policy = "
+                                   f"the 7-conv CNN (Net/DQNNet.py) on the int8 observations",
+                       "parallelism": f"env-shard + replay-shard x{world}, gradient all-reduce per learn step"},
+            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MATRIX_PEAK_TFLOPS,
+                         "achieved": flops / sec / 1e12, "frac": flops / sec / 1e12 / F32_MATRIX_PEAK_TFLOPS,
+                         "flops_forward_per_sample": f_fwd,
+                         "note": "fp32 like the reference (Q within 1e-5); peak = fp32-input MFMA = fp32 vector "
+                                 "rate; whole-loop time incl. env step, replay push/sample, optimizer"}}
 
 
 def main():
@@ -137,11 +188,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=320)     # multiples of the rollout's 64 steps per launch
     ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; value = median")
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65536; --dqn: 4096)")
     ap.add_argument("--width", type=int, default=None, help="board side (default 24; --dqn: 10)")
     ap.add_argument("--obs", default="codes", choices=["codes", "planes3", "planes4"])
     ap.add_argument("--mode", default="none", choices=["none", "ice", "temper"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dqn", action="store_true", help="skip the DQN transitions/s record")
     ap.add_argument("--incremental", action="store_true",
                     help="secondary variant: in-place observation update (only touched cells and restarted boards "
                          "are written); reported under its own label, not comparable with the default line")
@@ -149,20 +202,16 @@ def main():
                     help="synthetic policy: i.i.d. uniform over the 4 headings (headline), or uniform over the 3 "
                          "that do not reverse the last move (longer episodes; secondary line, SURVEY.md 8(d))")
     ap.add_argument("--dqn", action="store_true",
-                    help="secondary metric: DQN transitions/s of the batched DDQN trainer (BASELINE configs[1] by "
-                         "default: 4096 envs 10x10; use --envs/--width for others)")
-    ap.add_argument("--batch", type=int, default=4096, help="--dqn: learn batch")
+                    help="print the DQN record as its own line instead (BASELINE configs[1] by default: 4096 envs "
+                         "10x10; use --envs/--width/--batch/--dqn-steps for others)")
+    ap.add_argument("--batch", type=int, default=4096, help="DQN record: learn batch")
+    ap.add_argument("--dqn-steps", type=int, default=40, help="DQN record: env steps per timed region")
+    ap.add_argument("--dqn-envs", type=int, default=4096)
+    ap.add_argument("--dqn-width", type=int, default=10)
     args = ap.parse_args()
-    if args.dqn:
-        args.envs = 4096 if args.envs is None else args.envs
-        args.width = 10 if args.width is None else args.width
-        return dqn_bench(args)
-    args.envs = N_ENVS if args.envs is None else args.envs
-    args.width = WIDTH if args.width is None else args.width
 
     import torch
     import torch.distributed as dist
-    from tron.vec import VecTron
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -179,62 +228,87 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    env = VecTron(args.envs, args.width, mode=None if args.mode == "none" else args.mode, seed=0x5EED, rank=rank,
-                  obs_format=args.obs, incremental=args.incremental)
-    env.reset()
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The K steps go out through tron_rollout_random: K dependent launches of the fused kernel (in-kernel
-    # Philox actions, autoreset) on a side stream — the launch loop is native, not Python.
+    if args.dqn:
+        rec = dqn_record(args.envs or args.dqn_envs, args.width or args.dqn_width, args.dqn_steps if args.steps == 320
+                         else args.steps, min(args.warmup, 8), args.batch, max(1, min(args.repeats, 3)), world, rank)
+        if rank == 0:
+            rec.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                        "data": "synthetic"})
+            print(json.dumps(rec), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    args.envs = N_ENVS if args.envs is None else args.envs
+    args.width = WIDTH if args.width is None else args.width
+    from tron.vec import VecTron
+
+    env = VecTron(args.envs, args.width, mode=None if args.mode == "none" else args.mode, seed=0x5EED, rank=rank,
+                  obs_format=args.obs, incremental=args.incremental)
+    env.reset()
+
+    # The K steps go out through tron_rollout_random on a side stream — the launch loop is native, not Python.
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())  # the reset above ran on the current stream; torch's side streams
     torch.cuda.synchronize()                       # do not order themselves behind it
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nonrev = args.actions == "nonreversing"
+    walls, dev_ms = [], []
+    per_step_ms = []
     with torch.cuda.stream(side):
         if args.incremental:                       # the in-place variant has no rollout entry point: launch loop
-            step = env.step_fn(autoreset=True, nonreversing=args.actions == "nonreversing")
+            step = env.step_fn(autoreset=True, nonreversing=nonrev)
 
-            def run(k):
+            def run(k, per_step=False):
                 for _ in range(k):
                     step()
         else:
             def run(k, per_step=False):
-                env.rollout_random(k, nonreversing=args.actions == "nonreversing", per_step_launches=per_step)
+                env.rollout_random(k, nonreversing=nonrev, per_step_launches=per_step)
         run(args.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        ev0.record()                               # same stream the kernels are launched on
-        run(args.steps)
-        ev1.record()
-        barrier()
-        wall = time.perf_counter() - t0
-        # for reference, outside the measured job: the same K steps as one launch per step (what a caller
-        # that supplies actions every step gets)
-        per_step_ms = None
+        for _ in range(max(1, args.repeats)):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            t0 = time.perf_counter()
+            ev0.record()                           # same stream the kernels are launched on
+            run(args.steps)
+            ev1.record()
+            barrier()
+            walls.append(max_over_ranks(time.perf_counter() - t0, world))
+            dev_ms.append(ev0.elapsed_time(ev1))
+        # the same K steps as one launch per step (what a caller that supplies actions every step gets)
         if not args.incremental and not os.environ.get("TRON_ROLL_PER_STEP"):
-            ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             run(min(args.warmup, 16), True)
-            ev2.record()
-            run(args.steps, True)
-            ev3.record()
-            torch.cuda.synchronize()
-            per_step_ms = ev2.elapsed_time(ev3) / args.steps
+            for _ in range(max(1, args.repeats)):
+                ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev2.record()
+                run(args.steps, True)
+                ev3.record()
+                torch.cuda.synchronize()
+                per_step_ms.append(ev2.elapsed_time(ev3) / args.steps)
     # launches in the timed region: the rollout is persistent (<= 64 steps per launch of k_obs_roll / k_tile_roll,
     # include/tron_hip.h TRON_ROLLOUT_CHUNK); the incremental variant launches once per step
     persistent = not args.incremental and args.steps > 1 and not os.environ.get("TRON_ROLL_PER_STEP")
     chunk = int(os.environ.get("TRON_ROLL_CHUNK", "64")) if persistent else 1
     n_launches = (args.steps + chunk - 1) // chunk
-    step_ms = ev0.elapsed_time(ev1) / args.steps   # per step, HIP events on the launch stream
-    kern_ms = ev0.elapsed_time(ev1) / n_launches   # avg launch of the step kernel
+    wall = statistics.median(walls)
+    ev_ms = statistics.median(dev_ms)              # HIP events on the launch stream, median repeat
+    step_ms = ev_ms / args.steps
+    kern_ms = ev_ms / n_launches                   # avg launch of the step kernel
 
-    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall = float(t.item())
+    dqn = None
+    if not args.no_dqn and not args.incremental:
+        env.close()
+        del env
+        env = None
+        try:
+            dqn = dqn_record(args.dqn_envs, args.dqn_width, args.dqn_steps, 6, args.batch, 3, world, rank)
+        except Exception as e:                     # the headline must survive a trainer-side failure
+            dqn = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         total_env_steps = args.envs * world * args.steps
@@ -242,19 +316,19 @@ def main():
         if args.obs != "codes":                    # f32 planes: 2 players x C planes x 4 B per cell
             g = (args.width + 2) ** 2
             b_alg = g + 32 + 2 * (3 if args.obs == "planes3" else 4) * g * 4
-        achieved = b_alg * args.envs / (step_ms * 1e-3) / 1e9
-        hbm_bytes, hbm_src = (pmc_traffic(args.envs, args.width, args.obs, args.mode)
-                              if persistent and env.obs_is_state else (None, None))
+        obs_is_state = args.mode == "none" and args.obs == "codes" and args.width % 2 == 0
         if args.incremental:
             # bytes this variant needs per env-step: state words + outputs (~70 B), 2 cells read, 8 written,
             # and both planes (2G) for the ~36 % of envs that restart under random play
             g = (args.width + 2) ** 2
             b_alg = 80 + int(0.36 * 2 * g)
-            achieved = b_alg * args.envs / (step_ms * 1e-3) / 1e9
-            hbm_bytes = hbm_src = None
+        achieved = b_alg * args.envs / (step_ms * 1e-3) / 1e9
+        kernel_tag = "k_obs_roll" if obs_is_state else "k_tile_roll"
+        hbm_bytes, hbm_src = (pmc_traffic(args.envs, args.width, args.obs, args.mode, kernel_tag, args.steps / n_launches)
+                              if persistent else (None, None))
         out = {
             "metric": "env-steps/sec" + (" (incremental observation update)" if args.incremental else "") +
-                      (" (non-reversing uniform actions)" if args.actions == "nonreversing" else ""),
+                      (" (non-reversing uniform actions)" if nonrev else ""),
             "value": total_env_steps / wall,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -266,28 +340,47 @@ def main():
             "vs_baseline": None,
             "dtype": "i8",
             "data": "synthetic",
+            "repeats": len(walls),
+            "value_min_med_max": [total_env_steps / max(walls), total_env_steps / wall, total_env_steps / min(walls)],
             "config": {"workload": f"{args.envs} parallel {args.width}x{args.width} TRON envs per GPU, "
-                                   f"mode={args.mode}, {'non-reversing ' if args.actions == 'nonreversing' else ''}random actions "
-                                   f"(in-kernel Philox), autoreset, "
-                                   f"obs={args.obs} for both players",
+                                   f"mode={args.mode}, {'non-reversing ' if nonrev else ''}random actions "
+                                   f"(in-kernel Philox), autoreset, obs={args.obs} for both players; synthetic "
+                                   f"persistent rollout (no consumer reads the intermediate observations)",
                        "envs_per_gpu": args.envs, "grid": f"{args.width}x{args.width}",
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         "achievable_peak": HBM_COPY_GBS, "frac_of_achievable": achieved / HBM_COPY_GBS,
                          "traffic": None if hbm_bytes is None else hbm_bytes / (step_ms * 1e-3) / 1e9,
                          "traffic_bytes_per_step": hbm_bytes, "traffic_source": hbm_src,
+                         "traffic_note": ("PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs) of this "
+                                          "workload at this steps-per-launch, committed under profiles/"
+                                          if hbm_bytes is not None else
+                                          "no committed PMC pass for this workload / steps-per-launch"),
                          "kernel": ("k_inc (in-place update: touched cells + restarted boards only)" if args.incremental
                                     else "k_obs / k_tile (one launch per step)" if not persistent
                                     else "k_obs_roll (persistent rollout of the observation-is-state step, int8 codes)"
-                                    if env.obs_is_state else "k_tile_roll (persistent rollout, board-owning layout)"),
-                         "kernel_ms": kern_ms, "launches": n_launches, "steps_per_launch": args.steps / n_launches,
+                                    if obs_is_state else "k_tile_roll (persistent rollout, board-owning layout)"),
+                         "kernel_ms": kern_ms, "kernel_ms_min_max": [min(dev_ms) / n_launches, max(dev_ms) / n_launches],
+                         "launches": n_launches, "steps_per_launch": args.steps / n_launches,
                          "alg_bytes_per_env_step": b_alg,
                          "alg_bytes_per_launch": b_alg * args.envs * args.steps / n_launches},
         }
-        if per_step_ms is not None:
-            out["per_step_launches"] = {"ms_per_step": per_step_ms, "value": args.envs * world / (per_step_ms * 1e-3),
-                                        "frac": b_alg * args.envs / (per_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "note": "same K steps, one kernel launch per step (k_obs / k_tile), this rank"}
+        if per_step_ms:
+            ps = statistics.median(per_step_ms)
+            ps_ach = b_alg * args.envs / (ps * 1e-3) / 1e9
+            out["per_step_launches"] = {
+                "metric": "env-steps/sec, one kernel launch per step (policy-in-the-loop callers)",
+                "ms_per_step": ps, "ms_per_step_min_max": [min(per_step_ms), max(per_step_ms)],
+                "value": args.envs * world / (ps * 1e-3),
+                "roofline": {"bound": "hbm", "achieved": ps_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ps_ach / HBM_PEAK_GBS, "achievable_peak": HBM_COPY_GBS,
+                             "frac_of_achievable": ps_ach / HBM_COPY_GBS,
+                             "kernel": "k_obs (observation-is-state step)" if obs_is_state else "k_tile"},
+                "frac": ps_ach / HBM_PEAK_GBS,
+                "note": "same K steps, this rank's HIP events, after the measured job"}
+        if dqn is not None:
+            out["dqn"] = dqn
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.width)
         print(json.dumps(out), flush=True)

@@ -84,7 +84,13 @@ def average_gradients(model, group=None):
         return
     grads = [p.grad for p in model.parameters() if p.grad is not None]
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if dist.get_backend(group) == "gloo" and flat.is_cuda:
+        # the CPU rehearsal backend (several ranks sharing one GPU): reduce through host memory
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat /= dist.get_world_size(group)
     off = 0
     for g in grads:
@@ -194,58 +200,94 @@ def load_checkpoint(path, brain):
     return ck["epsilon"], ck["counters"]
 
 
+def _decays_left(epsilon):
+    """How many more times the reference's rule `if eps * DECAY_RATE > ESPILON_END: eps *= DECAY_RATE`
+    (DDQN.py:313-315) fires from `epsilon` on: the rule is monotone, so it is a count."""
+    k = 0
+    while epsilon * DECAY_RATE > ESPILON_END:
+        epsilon *= DECAY_RATE
+        k += 1
+    return k
+
+
 def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BATCH_SIZE, capacity=1 << 20,
-          in_channels=3, seed=0x5EED, log_every=50, save_path=None, log_dir=None, resume=None):
+          in_channels=3, seed=0x5EED, log_every=50, save_path=None, log_dir=None, resume=None,
+          terminal_next_state=True, brain=None):
     """Batched self-play DDQN: the loop of DDQN.py:225-346 with N envs per launch.
     Honours the reference's cadence as defaults (App. A #12): one learn step per 2 env-steps
     (UPDATE_EVERY=4 counted in per-player `brain.step` calls), epsilon x0.999 per 20 finished
-    games, target net saved.  Returns a dict of counters."""
+    games, target net saved.  Returns a dict of counters.
+
+    Nothing in the loop reads the device back: the finished-game counter, the 20-game cycle count and
+    epsilon live in device tensors (epsilon = eps0 * DECAY_RATE ** decays, the closed form of the
+    reference's repeated multiply); the host reads them at log time and at the end only.
+
+    terminal_next_state=True stores what the reference stores for a finished game (DDQN.py:265-308: the
+    terminal board as next_state) by stepping without autoreset and restarting the finished envs with a
+    masked reset; False uses the env's autoreset (ACKTR.py:307-310 convention: next_state of a terminal
+    transition is the new game's first observation — irrelevant to the (1 - done) target, one launch fewer)."""
     import time
     import torch.distributed as dist
     from tron.vec import VecTron, pop_up_planes
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    torch.manual_seed(seed)                        # same initial weights on every rank
-    brain = Agent(width, in_channels, buffer_size=capacity, batch_size=batch_size, seed=seed, rank=rank,
-                  make_memory=True)
+    if brain is None:
+        torch.manual_seed(seed)                    # same initial weights on every rank ...
+        brain = Agent(width, in_channels, buffer_size=capacity, batch_size=batch_size, seed=seed, rank=rank,
+                      make_memory=True)
+    torch.manual_seed(seed + 0x9E3779B1 * (rank + 1))   # ... but rank-own exploration and dropout draws
+    dev = brain.device
     env = VecTron(n_envs, width, mode=None, seed=seed, rank=rank, obs_format="codes", reward="ddqn")
     S = width + 2
     codes = env.reset().reshape(2 * n_envs, S, S).clone()
-    epsilon, games, learn_steps, transitions = float(EPSILON_START), 0, 0, 0
+    eps0 = float(EPSILON_START)
     if resume:
-        epsilon, _ = load_checkpoint(resume, brain)
+        eps0, _ = load_checkpoint(resume, brain)
+    # device-side bookkeeping (no per-step host sync)
+    games_d = torch.zeros((), dtype=torch.int64, device=dev)
+    cycles_d = torch.zeros((), dtype=torch.int64, device=dev)
+    decays_d = torch.zeros((), dtype=torch.int64, device=dev)
+    decays_max = torch.tensor(_decays_left(eps0), dtype=torch.int64, device=dev)
+    eps_d = torch.tensor(eps0, dtype=torch.float64, device=dev)
+    decay_d = torch.tensor(DECAY_RATE, dtype=torch.float64, device=dev)
+    learn_steps, transitions, games_seen = 0, 0, 0
     writer = None
     if log_dir and rank == 0:
         from tron.scalars import ScalarWriter
         writer = ScalarWriter(log_dir)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(steps):
         planes = pop_up_planes(codes)                                             # [2N,3,S,S] for the CNN
-        actions = brain.act_batch(planes, epsilon).reshape(n_envs, 2)
-        obs, reward, done, _ = env.step(actions, autoreset=True)
+        actions = brain.act_batch(planes, eps_d.to(torch.float32)).reshape(n_envs, 2)
+        obs, reward, done, _ = env.step(actions, autoreset=not terminal_next_state)
         next_codes = obs.reshape(2 * n_envs, S, S)
         brain.memory.add_batch(codes, actions.reshape(-1), reward.reshape(-1), next_codes,
                                done.repeat_interleave(2))
         transitions += 2 * n_envs
-        codes = next_codes.clone()
-        finished = int(done.sum())
-        games += finished
-        if it % learn_every == learn_every - 1 and len(brain.memory) > batch_size:
+        if terminal_next_state:
+            env.reset(mask=done)                   # finished games restart; obs now holds the new first states
+        codes = env.obs.reshape(2 * n_envs, S, S).clone()
+        games_d += done.sum()
+        if it % learn_every == learn_every - 1 and len(brain.memory) > batch_size:    # len(): a host counter
             brain.steps += 1
             brain.learn(brain.memory.sample(), GAMMA)
             learn_steps += 1
-        for _ in range(games // GAME_CYCLE - (games - finished) // GAME_CYCLE):   # DDQN.py:313-315
-            if epsilon * DECAY_RATE > ESPILON_END:
-                epsilon *= DECAY_RATE
+        # DDQN.py:313-315, once per finished 20-game cycle
+        new_cycles = torch.div(games_d, GAME_CYCLE, rounding_mode="floor")
+        decays_d = torch.minimum(decays_d + (new_cycles - cycles_d), decays_max)
+        cycles_d = new_cycles
+        eps_d = eps0 * torch.pow(decay_d, decays_d)
         if log_every and rank == 0 and it % log_every == log_every - 1:
-            loss = float(brain.get_loss())
-            print(f"step {it + 1}: games {games} eps {epsilon:.4f} loss {loss:.4f}", flush=True)
+            loss, games_seen, epsilon = float(brain.get_loss()), int(games_d), float(eps_d)
+            print(f"step {it + 1}: games {games_seen} eps {epsilon:.4f} loss {loss:.4f}", flush=True)
             if writer:                                                            # DDQN.py:342-344
-                writer.add_scalar('Training loss', loss, games)
-                writer.add_scalar('Duration', n_envs * (it + 1) / max(games, 1), games)
-                writer.add_scalar('Epsilon', epsilon, games)
+                writer.add_scalar('Training loss', loss, games_seen)
+                writer.add_scalar('Duration', n_envs * (it + 1) / max(games_seen, 1), games_seen)
+                writer.add_scalar('Epsilon', epsilon, games_seen)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    games, epsilon = int(games_d), float(eps_d)
     if writer:
         writer.close()
     if save_path and rank == 0:
@@ -254,7 +296,7 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
     return dict(env_steps=n_envs * steps * world, transitions_pushed=transitions * world,
                 transitions_learned=learn_steps * batch_size * world, learn_steps=learn_steps, games=games * world,
                 seconds=dt, env_steps_per_s=n_envs * steps * world / dt,
-                learned_transitions_per_s=learn_steps * batch_size * world / dt, brain=brain)
+                learned_transitions_per_s=learn_steps * batch_size * world / dt, epsilon=epsilon, brain=brain)
 
 
 def main():

@@ -24,6 +24,8 @@ class _Mish(torch.autograd.Function):
         from tron import _native as nat
         (x,) = ctx.saved_tensors
         g = grad_y.contiguous()
+        if not _aligned16(g):
+            g = g.clone(memory_format=torch.contiguous_format)
         gx = torch.empty_like(x)
         with torch.cuda.device(x.device):
             nat.check(nat.lib().tron_mish_bwd(nat.ptr(x), nat.ptr(g), nat.ptr(gx), x.numel(), nat.stream_ptr()),
@@ -31,8 +33,13 @@ class _Mish(torch.autograd.Function):
         return gx
 
 
+def _aligned16(*tensors):
+    """The HIP passes use 16-byte accesses: a contiguous view at an odd storage offset (t[1:]) is not eligible."""
+    return all(t is None or (t.is_contiguous() and t.data_ptr() % 16 == 0) for t in tensors)
+
+
 def mish(x):
-    if x.is_cuda and x.dtype == torch.float32 and x.numel() > 0:
+    if x.is_cuda and x.dtype == torch.float32 and x.numel() > 0 and _aligned16(x):
         return _Mish.apply(x)
     return F.mish(x)
 
@@ -59,6 +66,8 @@ class _BiasMish(torch.autograd.Function):
         from tron import _native as nat
         (pre,) = ctx.saved_tensors
         g = grad_out.contiguous()
+        if not _aligned16(g):
+            g = g.clone(memory_format=torch.contiguous_format)
         gp = torch.empty_like(pre)
         with torch.cuda.device(pre.device):
             nat.check(nat.lib().tron_mish_bwd(nat.ptr(pre), nat.ptr(g), nat.ptr(gp), pre.numel(), nat.stream_ptr()),
@@ -71,7 +80,7 @@ def conv_bias_mish(conv, x, residual=None):
     (bias-free) MIOpen convolution when the tensors allow it; otherwise the plain composition."""
     if (x.is_cuda and x.dtype == torch.float32 and conv.bias is not None and isinstance(conv, torch.nn.Conv2d)):
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
-        if (y.shape[2] * y.shape[3]) % 4 == 0 and y.numel() < 2 ** 32:
+        if (y.shape[2] * y.shape[3]) % 4 == 0 and y.numel() < 2 ** 32 and _aligned16(y, residual):
             return _BiasMish.apply(y, conv.bias, residual)
         y = y + conv.bias.view(1, -1, 1, 1)
         return mish(y if residual is None else y + residual)

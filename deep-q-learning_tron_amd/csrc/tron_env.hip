@@ -1185,18 +1185,24 @@ inline int launch_status()
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
+// hipFuncSetAttribute acts on the current device only: remember, per kernel, which devices it was
+// prepared on (one bit per device ordinal) instead of a per-process flag.
+inline void allow_big_lds(const void *kern, int device, uint64_t &prepared)
+{
+    const uint64_t bit = 1ull << ((unsigned)device & 63u);
+    if (prepared & bit) return;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        (void)hipGetLastError();
+    prepared |= bit;
+}
+
 template <int FMT, bool DO_STEP, bool ALIGNED>
 int launch_one(tron_env *h, const int8_t *actions, const float *uniforms, uint32_t flags, void *obs, StepOut out,
                hipStream_t st)
 {
     auto kern = k_tile<FMT, DO_STEP, ALIGNED>;
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            (void)hipGetLastError();
-        attr_done = true;
-    }
+    static uint64_t prepared = 0;    // per instantiation, one bit per device
+    allow_big_lds(reinterpret_cast<const void *>(kern), h->device, prepared);
     const int blocks = (h->P.N + h->E - 1) / h->E;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), h->smem, st, h->P, h->E, h->cpe, h->cpe_magic, actions,
                        uniforms, flags, obs, out);
@@ -1207,13 +1213,8 @@ template <int FMT, bool ALIGNED>
 int launch_roll_one(tron_env *h, int k_steps, uint32_t flags, void *obs, StepOut out, hipStream_t st)
 {
     auto kern = k_tile_roll<FMT, ALIGNED>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            (void)hipGetLastError();
-        attr_done = true;
-    }
+    static uint64_t prepared = 0;    // per instantiation, one bit per device
+    allow_big_lds(reinterpret_cast<const void *>(kern), h->device, prepared);
     const int ntiles = (h->P.N + h->E - 1) / h->E;
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(BLOCK), h->smem, st, h->P, h->E, h->cpe, h->cpe_magic, flags, obs, out,
                        k_steps, ntiles);
@@ -1260,13 +1261,8 @@ template <bool DO_STEP>
 int launch_obs(tron_env *h, const int8_t *actions, uint32_t flags, StepOut out, hipStream_t st)
 {
     auto kern = k_obs<DO_STEP>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            (void)hipGetLastError();
-        attr_done = true;
-    }
+    static uint64_t prepared = 0;    // per instantiation, one bit per device
+    allow_big_lds(reinterpret_cast<const void *>(kern), h->device, prepared);
     const int blocks = (h->P.N + h->E - 1) / h->E;
     const size_t smem = ((size_t)h->E + 1u) * h->cpe * 16u + 4u * (size_t)h->E * 16u;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, h->P, h->E, h->cpe, h->cpe_magic, actions, flags, out);
@@ -1304,6 +1300,14 @@ const char *tron_strerror(int status)
     case TRON_ERR_UNSUPPORTED: return "not supported by this build";
     default: return "unknown status";
     }
+}
+
+int tron_synchronize(void *stream)
+{
+    const hipError_t e = hipStreamSynchronize(S_(stream));
+    if (e == hipSuccess) return TRON_OK;
+    (void)hipGetLastError();
+    return TRON_ERR_LAUNCH;
 }
 
 int tron_create(int32_t n_envs, int32_t W, int32_t mode, int32_t fair, uint32_t seed, uint32_t rng_stream,
@@ -1528,11 +1532,10 @@ int rollout_persistent(tron_env *h, int32_t k_steps, uint32_t flags, StepOut out
         if (const char *v = getenv("TRON_ROLL_E")) env_e = atoi(v);
         if (const char *v = getenv("TRON_ROLL_GRID")) env_grid = atoi(v);
         if (const char *v = getenv("TRON_ROLL_CHUNK")) chunk = atoi(v) > 0 ? atoi(v) : TRON_ROLLOUT_CHUNK;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_obs_roll), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            (void)hipGetLastError();
         probed = true;
     }
+    static uint64_t prepared = 0;
+    allow_big_lds(reinterpret_cast<const void *>(k_obs_roll), h->device, prepared);
     const int E = env_e > 0 ? env_e : h->E;
     const size_t smem = ((size_t)E + 1u) * h->cpe * 16u + 4u * (size_t)E * 16u;
     if (smem > 160u * 1024u) return TRON_ERR_BAD_ARG;

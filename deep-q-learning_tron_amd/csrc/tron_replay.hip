@@ -1,8 +1,8 @@
 // Device-resident replay memory (include/tron_hip.h, tron_replay_*).
 //
 // Replaces DDQN.ReplayBuffer (DDQN.py:167-203): deque(maxlen) -> a ring in HBM,
-// random.sample -> distinct uniform slots drawn in-kernel (Philox + rejection of
-// duplicates), np.vstack + .to(device) -> one gather kernel that also expands
+// random.sample -> distinct uniform slots drawn in-kernel (a Philox-keyed permutation
+// of the filled slots, any batch size), np.vstack + .to(device) -> one gather kernel that also expands
 // the stored int8 code planes (map.py:67-84) into the f32 pop_up planes
 // (util.py:11-37) the CNN reads.  Nothing crosses PCIe.
 #include "tron_device.hpp"
@@ -28,8 +28,8 @@ struct tron_replay {
 
 namespace {
 
-constexpr int MAX_DISTINCT_BATCH = 1024;   // above this, slots are drawn with replacement
 constexpr int MAX_BATCH = 1 << 20;
+constexpr int64_t MAX_CAPACITY = 1ll << 32;   // the sampler's permutation works on <= 32 bits
 
 inline hipStream_t S_(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline int launch_status() { return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH; }
@@ -59,48 +59,48 @@ __global__ void k_push_scalars(int64_t n, const int8_t *__restrict__ action, con
     dones[i] = done[i];
 }
 
-// random.sample(memory, k): k distinct uniform slots.  One workgroup; thread j owns
-// draw j; a draw that collides with a lower-numbered one is redrawn until none collide
-// (rejection keeps the joint distribution uniform over distinct tuples).
-__global__ __launch_bounds__(256) void k_sample_indices(int64_t size, int batch, uint32_t seed, uint32_t stream,
-                                                        uint32_t call, int distinct, int64_t *__restrict__ out)
+// random.sample(memory, k) (DDQN.py:191-200): k DISTINCT uniform slots, for any k <= size.
+// Draw j is pi(j) for a keyed pseudo-random permutation pi of [0, size): the first k images of a random
+// permutation are a uniform sample without replacement.  pi is a balanced Feistel network on 2h bits
+// (4^h >= size, h minimal, so the domain is < 4 * size) with cycle-walking: an image >= size is pushed
+// through the network again until it lands inside — a permutation restricted to the orbit of a subset
+// is a permutation of the subset, so the draws are distinct by construction, and the walk ends because
+// it started inside.  O(k) work, one thread per draw, any number of workgroups; the round keys come
+// from Philox keyed (seed, stream) at counter (call), so every sample() call has its own permutation.
+constexpr int FEISTEL_ROUNDS = 8;
+
+__device__ __forceinline__ uint32_t feistel_f(uint32_t x, uint32_t k)
 {
-    extern __shared__ int64_t sidx[];   // [batch] when distinct
-    __shared__ int any_dup;
-    const int tid = threadIdx.x;
-    auto draw = [&](int j, uint32_t attempt) -> int64_t {
-        uint32_t x[4];
-        philox4x32_10((uint32_t)j, call, attempt, 0x5A4D504Cu /* "SMPL" */, seed, stream, x);
-        const uint64_t u = ((uint64_t)x[0] << 32) | x[1];
-        return (int64_t)__umul64hi(u, (uint64_t)size);
-    };
-    if (!distinct) {
-        for (int j = blockIdx.x * blockDim.x + tid; j < batch; j += gridDim.x * blockDim.x) out[j] = draw(j, 0u);
-        return;
-    }
-    for (int j = tid; j < batch; j += 256) sidx[j] = draw(j, 0u);
-    __syncthreads();
-    for (uint32_t attempt = 1; attempt < 64u; ++attempt) {
-        if (tid == 0) any_dup = 0;
-        __syncthreads();
-        // decide first, redraw after a barrier so every thread judged the same snapshot
-        bool dup[(MAX_DISTINCT_BATCH + 255) / 256];
-        int k = 0;
-        for (int j = tid; j < batch; j += 256, ++k) {
-            const int64_t v = sidx[j];
-            bool d = false;
-            for (int i = 0; i < j; ++i) d |= (sidx[i] == v);
-            dup[k] = d;
-            if (d) any_dup = 1;
+    x = (x ^ k) * 0x9E3779B1u;
+    x ^= x >> 15;
+    x *= 0x85EBCA77u;
+    x ^= x >> 13;
+    x *= 0xC2B2AE3Du;
+    return x ^ (x >> 16);
+}
+
+__global__ __launch_bounds__(256) void k_sample_indices(uint64_t size, int batch, int half_bits, uint32_t seed,
+                                                        uint32_t stream, uint32_t call, int64_t *__restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= batch) return;
+    uint32_t key[FEISTEL_ROUNDS];
+#pragma unroll
+    for (int b = 0; b < FEISTEL_ROUNDS / 4; ++b)
+        philox4x32_10(call, (uint32_t)b, 0u, 0x5A4D504Cu /* "SMPL" */, seed, stream, key + 4 * b);
+    const uint32_t mask = (1u << half_bits) - 1u;
+    uint64_t x = (uint64_t)j;
+    do {
+        uint32_t l = (uint32_t)(x >> half_bits) & mask, r = (uint32_t)x & mask;
+#pragma unroll
+        for (int t = 0; t < FEISTEL_ROUNDS; ++t) {
+            const uint32_t n = l ^ (feistel_f(r, key[t]) & mask);
+            l = r;
+            r = n;
         }
-        __syncthreads();
-        if (!any_dup) break;
-        k = 0;
-        for (int j = tid; j < batch; j += 256, ++k)
-            if (dup[k]) sidx[j] = draw(j, attempt);
-        __syncthreads();
-    }
-    for (int j = tid; j < batch; j += 256) out[j] = sidx[j];
+        x = ((uint64_t)l << half_bits) | r;
+    } while (x >= size);
+    out[j] = (int64_t)x;
 }
 
 // gather + expand: codes int8[cells] -> planes f32[channels][cells]
@@ -176,6 +176,7 @@ int tron_replay_create(int64_t capacity, int32_t cells, uint32_t seed, uint32_t 
     if (!out) return TRON_ERR_BAD_ARG;
     *out = nullptr;
     if (capacity < 1 || cells < 1 || cells > 98 * 98) return TRON_ERR_BAD_ARG;
+    if (capacity > MAX_CAPACITY) return TRON_ERR_UNSUPPORTED;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
     tron_replay *r = new (std::nothrow) tron_replay();
@@ -256,14 +257,11 @@ int tron_replay_sample(tron_replay_handle r, int32_t batch, int32_t channels, fl
     if (batch < 1 || batch > r->max_batch || (channels != 3 && channels != 4)) return TRON_ERR_BAD_ARG;
     if (!states || !actions || !rewards || !next_states || !dones) return TRON_ERR_BAD_ARG;
     if (r->size < batch) return TRON_ERR_BAD_ARG;       // random.sample raises ValueError likewise
-    const int distinct = batch <= MAX_DISTINCT_BATCH;
     const uint32_t call = r->calls++;
-    if (distinct)
-        hipLaunchKernelGGL(k_sample_indices, dim3(1), dim3(256), (size_t)batch * sizeof(int64_t), S_(stream), r->size,
-                           batch, r->seed, r->stream, call, 1, r->indices);
-    else
-        hipLaunchKernelGGL(k_sample_indices, dim3((batch + 255) / 256), dim3(256), 0, S_(stream), r->size, batch,
-                           r->seed, r->stream, call, 0, r->indices);
+    int half_bits = 1;                                   // smallest h with 4^h >= size
+    while (half_bits < 16 && (1ull << (2 * half_bits)) < (uint64_t)r->size) ++half_bits;
+    hipLaunchKernelGGL(k_sample_indices, dim3((batch + 255) / 256), dim3(256), 0, S_(stream), (uint64_t)r->size, batch,
+                       half_bits, r->seed, r->stream, call, r->indices);
     hipLaunchKernelGGL(k_sample_gather, dim3(2 * batch), dim3(256), 0, S_(stream), r->indices, batch, r->cells,
                        channels, plane4, r->states, r->next_states, r->actions, r->rewards, r->dones, states, actions,
                        rewards, next_states, dones);

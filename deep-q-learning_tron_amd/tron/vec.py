@@ -284,15 +284,20 @@ class DeviceReplay:
         """Batched ReplayBuffer.add: state/next_state int8 [n, cells...] codes, action int8 [n],
         reward f32 [n], done int8 [n]."""
         n = state.shape[0]
-        s = state.reshape(n, -1)
-        s2 = next_state.reshape(n, -1)
-        assert s.shape[1] == self.cells and s2.shape[1] == self.cells
+        # every converted tensor stays bound to a local until the call returns: a temporary freed
+        # right after nat.ptr() could be handed to the next conversion by the caching allocator
+        # before the push kernel has read it
+        s = state.reshape(n, -1).to(torch.int8).contiguous()
+        s2 = next_state.reshape(n, -1).to(torch.int8).contiguous()
+        a = action.reshape(n).to(torch.int8).contiguous()
+        r = reward.reshape(n).to(torch.float32).contiguous()
+        d = done.reshape(n).to(torch.int8).contiguous()
+        if s.shape[1] != self.cells or s2.shape[1] != self.cells:
+            raise ValueError(f"states must have {self.cells} cells per row, got {s.shape[1]} / {s2.shape[1]}")
         with torch.cuda.device(self.device):
-            nat.check(self._lib.tron_replay_push(self._h, n, nat.ptr(s.contiguous()),
-                                                 nat.ptr(action.to(torch.int8).contiguous()),
-                                                 nat.ptr(reward.to(torch.float32).contiguous()),
-                                                 nat.ptr(s2.contiguous()), nat.ptr(done.to(torch.int8).contiguous()),
-                                                 nat.stream_ptr()), "tron_replay_push")
+            nat.check(self._lib.tron_replay_push(self._h, n, nat.ptr(s), nat.ptr(a), nat.ptr(r), nat.ptr(s2),
+                                                 nat.ptr(d), nat.stream_ptr()), "tron_replay_push")
+        del s, s2, a, r, d
 
     def sample(self, batch, channels=3, plane4=0.0, side=None):
         """ReplayBuffer.sample(): (states, actions, rewards, next_states, dones) on the device,

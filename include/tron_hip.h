@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TRON_ABI_VERSION 2
+#define TRON_ABI_VERSION 3
 
 typedef enum {
     TRON_OK = 0,
@@ -181,8 +181,9 @@ int tron_replay_destroy(tron_replay_handle r);
 int tron_replay_push(tron_replay_handle r, int64_t n, const int8_t *state, const int8_t *action,
                      const float *reward, const int8_t *next_state, const int8_t *done,
                      void *stream);
-/* Uniform sample of `batch` distinct slots (random.sample, DDQN.py:191-200),
- * written as pop_up planes: states/next_states f32[batch][channels][cells]
+/* Uniform sample of `batch` DISTINCT slots (random.sample, DDQN.py:191-200) at any
+ * batch <= size: slot j = pi(j) for a Philox-keyed permutation pi of the filled slots,
+ * a fresh one per call.  Written as pop_up planes: states/next_states f32[batch][channels][cells]
  * (channels 3, or 4 with the constant `plane4` value), actions i64[batch],
  * rewards f32[batch], dones f32[batch].  Needs size >= batch.                  */
 int tron_replay_sample(tron_replay_handle r, int32_t batch, int32_t channels, float plane4,
@@ -231,6 +232,11 @@ int tron_mish_bwd(const float *x, const float *grad_y, float *grad_x, int64_t n,
  * activation after a convolution (Net/DQNNet.py:33-63) in one pass.  hw % 4 == 0, else UNSUPPORTED.     */
 int tron_bias_mish_fwd(float *y_pre, const float *bias, const float *residual, float *out, int64_t batch,
                        int32_t channels, int32_t hw, void *stream);
+
+/* Wait for `stream` and report what the kernels queued on it did: launch_status-style calls above only
+ * see a REJECTED launch; a fault inside a kernel surfaces at the next synchronisation.  Returns TRON_OK
+ * or TRON_ERR_LAUNCH (the HIP error is consumed).  The one blocking call of this ABI.               */
+int tron_synchronize(void *stream);
 
 const char *tron_strerror(int status);
 int tron_abi_version(void);

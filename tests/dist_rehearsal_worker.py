@@ -1,0 +1,61 @@
+"""One rank of the multi-GPU rehearsal (started by tests/test_gpu_dist.py as a fresh child process with
+RANK / WORLD_SIZE / MASTER_* set, before anything touches the GPU).  TEST INFRASTRUCTURE: it imports the
+oracle to check this rank's env shard.
+
+What a rank does — exactly what it does on an 8-GPU node, except that TRON_DIST_BACKEND=gloo lets the
+ranks share one GPU:
+  1. joins the process group;
+  2. builds its env shard VecTron(seed, rank=RANK), steps it with in-kernel Philox actions and checks it
+     against the oracle on Philox key (seed, stream=RANK) — rank-own random streams;
+  3. runs DDQN.train (own envs, own replay shard, gradients averaged across ranks each learn step);
+  4. writes its observations and its network weights to <out>/rank<r>.npz for the parent to compare.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "deep-q-learning_tron_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def main(out_dir):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    backend = os.environ.get("TRON_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+    dist.init_process_group(backend)
+    import oracle
+    import DDQN
+    from tron.vec import VecTron
+
+    N, W, K, seed = 512, 10, 6, 0x5EED
+    env = VecTron(N, W, seed=seed, rank=rank, obs_format="codes")
+    ref = oracle.VecOracle(N, W, seed=seed, stream=rank)
+    env.reset()
+    ref.reset_all()
+    same = True
+    for _ in range(K):
+        obs, r, d, w = env.step()
+        o, dd, ww, rr = ref.step(autoreset=True)
+        same &= bool(np.array_equal(obs.cpu().numpy().reshape(N, 2, -1), o) and np.array_equal(d.cpu().numpy(), dd))
+    obs_np = env.obs.cpu().numpy().copy()
+    env.close()
+
+    out = DDQN.train(n_envs=N, width=W, steps=12, learn_every=2, batch_size=64, capacity=1 << 14, log_every=0, seed=seed)
+    brain = out["brain"]
+    flat = torch.cat([p.detach().reshape(-1) for p in brain.qnetwork_local.parameters()]).cpu().numpy()
+    tflat = torch.cat([p.detach().reshape(-1) for p in brain.qnetwork_target.parameters()]).cpu().numpy()
+    # each rank's replay shard holds its own transitions
+    brain.memory.sample()
+    idx = brain.memory.memory.last_indices(64).cpu().numpy()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), obs=obs_np, oracle_equal=same, local=flat, target=tflat,
+             learn_steps=out["learn_steps"], games=out["games"], env_steps=out["env_steps"], world=world, idx=idx)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

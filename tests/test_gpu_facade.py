@@ -158,10 +158,10 @@ def test_device_replay_ring_and_sampling():
     s = torch.from_numpy(vals[rs.randint(0, 6, (3000, cells))]).cuda()
     z = torch.zeros(3000, device="cuda")
     rb2.add(s, z.to(torch.int8), z, s, z.to(torch.int8))
-    big = rb2.sample(2048, channels=3, side=12)                      # > 1024: slots drawn with replacement
+    big = rb2.sample(2048, channels=3, side=12)                      # any batch <= size: still distinct slots
     assert big[0].shape == (2048, 3, 12, 12)
     idx = rb2.last_indices(2048)
-    assert int(idx.min()) >= 0 and int(idx.max()) < 3000
+    assert int(idx.min()) >= 0 and int(idx.max()) < 3000 and idx.unique().numel() == 2048
     assert torch.equal(big[0], pop_up_planes(s[idx].reshape(2048, 12, 12)))
 
 
