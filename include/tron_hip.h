@@ -233,6 +233,23 @@ int tron_mish_bwd(const float *x, const float *grad_y, float *grad_x, int64_t n,
 int tron_bias_mish_fwd(float *y_pre, const float *bias, const float *residual, float *out, int64_t batch,
                        int32_t channels, int32_t hw, void *stream);
 
+/* ---- the CNN's 3x3 convolutions on the fp32 matrix cores (Net/DQNNet.py:10-17,33-50 conv1..conv6; the same
+ * stacks in Net/ACNet.py) ------------------------------------------------------------------------------ */
+/* out[b][co][y][x] = act(bias[co] + residual[b][co][y][x] + sum_{ci,ky,kx} W[co][ci][ky][kx] *
+ * in[b][ci][y+ky-1][x+kx-1]) for a batch of side x side images, NCHW f32, exact fp32 arithmetic
+ * (v_mfma_f32_16x16x4_f32): F.conv2d(padding=1) + bias + optional residual + optional mish in one launch.
+ * in_is_codes != 0: `in` is int8 observation codes [batch][side*side] (Map.state_for_player, map.py:67-84)
+ * and the input channels are util.pop_up's planes (wall, my, enemy; util.py:11-37) built on the fly, plus the
+ * constant `plane4` (Game.prob_map, game.py:124-132) when cin == 4 — conv1 straight from the env's output.
+ * Otherwise `in` is f32[batch][cin][side][side], cin a multiple of 8.  weight is the nn.Conv2d parameter as it
+ * is, f32[cout][cin][3][3] (the kernel reorders it while staging: no packed copy that could go stale).  pre_out (may be NULL) receives the
+ * value before the activation (what a backward pass needs).  bias / residual may be NULL.
+ * Supported: side 12 or 26 (10x10 / 24x24 boards), cout 32 or 64; anything else TRON_ERR_UNSUPPORTED.
+ * All buffers 16-byte aligned.                                                                             */
+int tron_conv3x3_fwd(const void *in, int32_t in_is_codes, const float *weight, const float *bias,
+                     const float *residual, float *out, float *pre_out, int64_t batch, int32_t cin,
+                     int32_t cout, int32_t side, float plane4, int32_t apply_mish, void *stream);
+
 /* Wait for `stream` and report what the kernels queued on it did: launch_status-style calls above only
  * see a REJECTED launch; a fault inside a kernel surfaces at the next synchronisation.  Returns TRON_OK
  * or TRON_ERR_LAUNCH (the HIP error is consumed).  The one blocking call of this ABI.               */

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""GPU check + timing of csrc/tron_conv.hip against torch (MIOpen) F.conv2d.
+Usage: python scripts/conv_check.py [batch12 batch26]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "deep-q-learning_tron_amd")]
+import config  # noqa: F401,E402  (MIOpen env defaults)
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+from Net import fused  # noqa: E402
+from tron.vec import pop_up_planes  # noqa: E402
+
+torch.manual_seed(0)
+dev = "cuda"
+B12 = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+B26 = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+
+
+def timeit(fn, n=10):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+for S, B in ((12, B12), (26, B26), (12, 5), (26, 3)):
+    for cin, cout in ((32, 32), (32, 64), (64, 64)):
+        conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(dev)
+        x = torch.randn(B, cin, S, S, device=dev)
+        res = torch.randn(B, cout, S, S, device=dev)
+        got, pre = fused.conv3x3(x, conv, residual=res, want_pre=True)
+        ref64 = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1) + res.double()
+        ref32 = F.conv2d(x, conv.weight, conv.bias, padding=1) + res
+        e_pre = (pre.double() - ref64).abs().max().item()
+        e_mi = (ref32.double() - ref64).abs().max().item()
+        e_out = (got.double() - F.mish(ref64)).abs().max().item()
+        line = f"S={S} B={B} {cin}->{cout}: |hip-f64| {e_pre:.2e} (MIOpen f32 {e_mi:.2e}) out {e_out:.2e}"
+        if B >= 1024:
+            t_h = timeit(lambda: fused.conv3x3(x, conv, residual=res))
+            t_m = timeit(lambda: F.mish(F.conv2d(x, conv.weight, conv.bias, padding=1) + res))
+            fl = 2 * B * S * S * cout * cin * 9
+            line += f" | hip {t_h * 1e3:.3f} ms = {fl / t_h / 1e12:.1f} TF/s, torch {t_m * 1e3:.3f} ms = {fl / t_m / 1e12:.1f} TF/s"
+        print(line, flush=True)
+        assert e_pre < 5e-5 and e_out < 5e-5
+    # conv1 from codes
+    for cin in (3, 4):
+        conv = torch.nn.Conv2d(cin, 32, 3, padding=1).to(dev)
+        vals = torch.tensor([1, -1, -2, -3, 10, -10], dtype=torch.int8, device=dev)
+        codes = vals[torch.randint(0, 6, (B, S, S), device=dev)]
+        planes = pop_up_planes(codes)
+        if cin == 4:
+            planes = torch.cat([planes, torch.full((B, 1, S, S), 5.0, device=dev)], 1)
+        got = fused.conv3x3(codes, conv, codes=True, plane4=5.0)
+        ref = F.mish(F.conv2d(planes.double(), conv.weight.double(), conv.bias.double(), padding=1))
+        e = (got.double() - ref).abs().max().item()
+        print(f"S={S} B={B} conv1 from codes, cin={cin}: err {e:.2e}", flush=True)
+        assert e < 5e-5
+print("conv check ok")
