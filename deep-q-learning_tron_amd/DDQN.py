@@ -141,23 +141,19 @@ class Agent():
             return int(np.argmax(action_values.cpu().data.numpy()))
         return int(random.choice(np.arange(self.action_size)))
 
-    def act_batch(self, obs, epsilon):
-        """Batched epsilon-greedy on the device: obs [B,C,S,S] -> int8 actions [B]."""
-        self.qnetwork_local.eval()
-        with torch.no_grad():
-            greedy = self.qnetwork_local(obs).argmax(1)
-        self.qnetwork_local.train()
+    def act_batch(self, obs, epsilon, codes=False):
+        """Batched epsilon-greedy on the device: obs f32 planes [B,C,S,S] — or, codes=True, the env's int8
+        observation codes [B,S,S] — -> int8 actions [B].  The greedy forward runs on Net.infer (HIP conv kernels)."""
+        greedy = self.qnetwork_local.infer(obs, codes=codes).argmax(1)
         rnd = torch.randint(0, self.action_size, greedy.shape, device=greedy.device)
         explore = torch.rand(greedy.shape, device=greedy.device) <= epsilon
         return torch.where(explore, rnd, greedy).to(torch.int8)
 
     def targets(self, rewards, next_state, dones, gamma):
-        """Double-DQN labels (DDQN.py:129-142): a* = argmax Q_local(s'), y = r + g Q_target(s', a*)(1-done)."""
-        self.qnetwork_local.eval()
-        with torch.no_grad():
-            actions_q_local = self.qnetwork_local(next_state).detach().max(1)[1].unsqueeze(1).long()
-            labels_next = self.qnetwork_target(next_state).gather(1, actions_q_local)
-        self.qnetwork_local.train()
+        """Double-DQN labels (DDQN.py:129-142): a* = argmax Q_local(s'), y = r + g Q_target(s', a*)(1-done).
+        Both forwards are gradient-free and in eval mode: Net.infer."""
+        actions_q_local = self.qnetwork_local.infer(next_state).max(1)[1].unsqueeze(1).long()
+        labels_next = self.qnetwork_target.infer(next_state).gather(1, actions_q_local)
         return rewards + (gamma * labels_next * (1 - dones))
 
     def learn(self, experiences, gamma):           # DDQN.py:115-151
@@ -258,8 +254,7 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(steps):
-        planes = pop_up_planes(codes)                                             # [2N,3,S,S] for the CNN
-        actions = brain.act_batch(planes, eps_d.to(torch.float32)).reshape(n_envs, 2)
+        actions = brain.act_batch(codes, eps_d.to(torch.float32), codes=True).reshape(n_envs, 2)   # conv1 reads the codes
         obs, reward, done, _ = env.step(actions, autoreset=not terminal_next_state)
         next_codes = obs.reshape(2 * n_envs, S, S)
         brain.memory.add_batch(codes, actions.reshape(-1), reward.reshape(-1), next_codes,

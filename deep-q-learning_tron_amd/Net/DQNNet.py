@@ -84,3 +84,33 @@ class Net(nn.Module):
 
     def act(self, x, env_prob=None):              # DQNNet.py:64-66 (env_prob accepted for Game.main_loop)
         return torch.argmax(self(x), dim=1)
+
+    def infer(self, x, codes=False, plane4=0.0):
+        """Q-values without autograd and without dropout (what `eval()` + `no_grad()` give, DDQN.py:90-110,129-142)
+        on the hand-written HIP path: the six 3x3 convolutions are csrc/tron_conv.hip launches (fp32 matrix cores,
+        bias + residual + mish fused, conv1 straight from the env's int8 observation codes when codes=True);
+        pooling, conv7 and the four small linear layers stay on the libraries.  Falls back to the module's own
+        forward for shapes the kernel does not cover (odd sides, CPU tensors)."""
+        from Net import fused
+        side = x.shape[-1]
+        with torch.no_grad():
+            if not (x.is_cuda and fused.supported(self.conv1, side) and fused.supported(self.conv6, side)
+                    and (codes or x.dtype == torch.float32)):
+                if codes:
+                    from tron.vec import pop_up_planes
+                    x = pop_up_planes(x.reshape(-1, side, side))
+                    if self.in_channels == 4:
+                        x = torch.cat([x, torch.full_like(x[:, :1], plane4)], 1)
+                was_training = self.training
+                self.eval()
+                try:
+                    return self(x)
+                finally:
+                    self.train(was_training)
+            x = fused.trunk(self, x.reshape(-1, side, side) if codes else x, codes=codes, plane4=plane4)
+            x = self.pool(x)
+            x = _conv_bias_mish(self.conv7, x)
+            x = x.reshape(-1, self.flat)
+            x = _mish(self.fc1(x))
+            x = _mish(self.fc2(x))
+            return self.actor2(_mish(self.actor1(x)))

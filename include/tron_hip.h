@@ -241,7 +241,7 @@ int tron_bias_mish_fwd(float *y_pre, const float *bias, const float *residual, f
  * in_is_codes != 0: `in` is int8 observation codes [batch][side*side] (Map.state_for_player, map.py:67-84)
  * and the input channels are util.pop_up's planes (wall, my, enemy; util.py:11-37) built on the fly, plus the
  * constant `plane4` (Game.prob_map, game.py:124-132) when cin == 4 — conv1 straight from the env's output.
- * Otherwise `in` is f32[batch][cin][side][side], cin a multiple of 8.  weight is the nn.Conv2d parameter as it
+ * Otherwise `in` is f32[batch][cin][side][side], cin 3 or 4 (conv1 on its planes) or a multiple of 8.  weight is the nn.Conv2d parameter as it
  * is, f32[cout][cin][3][3] (the kernel reorders it while staging: no packed copy that could go stale).  pre_out (may be NULL) receives the
  * value before the activation (what a backward pass needs).  bias / residual may be NULL.
  * Supported: side 12 or 26 (10x10 / 24x24 boards), cout 32 or 64; anything else TRON_ERR_UNSUPPORTED.

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Diagnostic (-DTRON_CONV_STAMPS build): per-workgroup shader-clock / real-time stamps of the conv kernel."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "deep-q-learning_tron_amd")]
+import config, torch  # noqa
+import numpy as np
+from tron import _native as nat
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+cin, cout, S = 32, 32, 12
+conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
+x = torch.randn(B, cin, S, S, device="cuda"); r = torch.randn(B, cout, S, S, device="cuda")
+out = torch.empty(B, cout, S, S, device="cuda")
+blocks = B // 4
+st = torch.zeros(blocks, 6, dtype=torch.int64, device="cuda")
+L = nat.lib()
+for rep in range(30):          # warm the clocks up: the stamps of the last launch are read
+    nat.check(L.tron_conv3x3_fwd(nat.ptr(x), 0, nat.ptr(conv.weight.detach()), nat.ptr(conv.bias.detach()), nat.ptr(r), nat.ptr(out),
+                                 nat.ptr(st), B, cin, cout, S, 0.0, 1, nat.stream_ptr()))
+torch.cuda.synchronize()
+s = st.cpu().numpy().astype(np.float64)
+main_cyc, main_rt = s[:, 2] - s[:, 0], (s[:, 3] - s[:, 1]) * 10.0          # realtime ticks are 10 ns
+epi_cyc, epi_rt = s[:, 4] - s[:, 2], (s[:, 5] - s[:, 3]) * 10.0
+clk = main_cyc / main_rt           # cycles per ns = GHz
+t0 = s[:, 1].min()
+print(f"B={B} blocks={blocks}: main phase median {np.median(main_rt) / 1e3:.2f} us, {np.median(main_cyc):.0f} cycles, clock {np.median(clk):.3f} GHz "
+      f"(p10 {np.percentile(clk, 10):.3f}, p90 {np.percentile(clk, 90):.3f}); epilogue median {np.median(epi_rt) / 1e3:.2f} us {np.median(epi_cyc):.0f} cycles; "
+      f"kernel span {(s[:, 5].max() - t0) * 10 / 1e3:.1f} us; ideal MFMA cycles {cin // 8 * 18 * 18 * 32}")
+starts = np.sort((s[:, 1] - t0) * 10 / 1e3)
+print("start times us (sorted) at block 0,255,256,511,512,1023:", [round(float(starts[min(i, blocks - 1)]), 1) for i in (0, 255, 256, 511, 512, 1023)])

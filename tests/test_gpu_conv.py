@@ -1,0 +1,124 @@
+"""csrc/tron_conv.hip — the CNN's 3x3 convolutions on the fp32 matrix cores — against a float64 torch reference
+of the same op (tolerance 1e-5, the north star's bound for Q-values), and the whole inference path
+(Net.infer: HIP convolutions + library tail) against the Q-values recorded from the reference network
+(tests/golden/net.npz, DQNNet.py:33-63)."""
+import collections
+import json
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+F = torch.nn.functional
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def fused():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import config  # noqa: F401
+    from Net import fused
+    return fused
+
+
+def _ref(x, conv, res, act):
+    y = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+    if res is not None:
+        y = y + res.double()
+    return y, (F.mish(y) if act else y)
+
+
+@pytest.mark.parametrize("S,B", [(12, 1), (12, 7), (12, 260), (26, 1), (26, 3), (26, 130)])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64), (64, 32)])
+def test_conv3x3_matches_float64_reference(fused, S, B, cin, cout):
+    torch.manual_seed(S * 1000 + B + cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
+    x = torch.randn(B, cin, S, S, device="cuda")
+    res = torch.randn(B, cout, S, S, device="cuda")
+    for r, act in ((res, True), (None, True), (res, False)):
+        got, pre = fused.conv3x3(x, conv, residual=r, act=act, want_pre=True)
+        ref_pre, ref = _ref(x, conv, r, act)
+        assert (pre.double() - ref_pre).abs().max().item() < TOL
+        assert (got.double() - ref).abs().max().item() < TOL
+    # asymmetric weights / one-hot inputs: a transposed tap or a swapped row/column cannot hide
+    with torch.no_grad():
+        conv.weight.copy_(torch.arange(conv.weight.numel(), device="cuda").reshape(conv.weight.shape).float() % 17 - 8)
+        conv.bias.zero_()
+    x = torch.zeros(B, cin, S, S, device="cuda")
+    x[:, 1, 2, 3] = 1.0
+    x[:, cin - 1, S - 1, 0] = 2.0
+    got = fused.conv3x3(x, conv, act=False)
+    assert torch.equal(got, F.conv2d(x, conv.weight, None, padding=1))       # small integers: exact
+
+
+@pytest.mark.parametrize("S,B", [(12, 5), (12, 1030), (26, 2), (26, 300)])
+@pytest.mark.parametrize("cin", [3, 4])
+def test_conv1_from_codes_and_from_planes(fused, S, B, cin):
+    """conv1 reads the env's int8 observation codes (map.py:67-84) and builds util.pop_up's planes
+    (util.py:11-37) (+ the constant prob_map plane, game.py:124-132) on the fly."""
+    from tron.vec import pop_up_planes
+    torch.manual_seed(S + B + cin)
+    conv = torch.nn.Conv2d(cin, 32, 3, padding=1).cuda()
+    vals = torch.tensor([1, -1, -2, -3, 10, -10], dtype=torch.int8, device="cuda")
+    codes = vals[torch.randint(0, 6, (B, S, S), device="cuda")]
+    planes = pop_up_planes(codes)
+    if cin == 4:
+        planes = torch.cat([planes, torch.full((B, 1, S, S), 5.0, device="cuda")], 1)
+    _, ref = _ref(planes, conv, None, True)
+    got_c = fused.conv3x3(codes, conv, codes=True, plane4=5.0)
+    got_p = fused.conv3x3(planes, conv)
+    assert (got_c.double() - ref).abs().max().item() < TOL
+    assert torch.equal(got_c, got_p)                       # same arithmetic, two ways of staging the input
+
+
+def test_unsupported_shapes_are_reported(fused):
+    from tron import _native as nat
+    conv = torch.nn.Conv2d(32, 32, 3, padding=1).cuda()
+    assert fused.supported(conv, 12) and fused.supported(conv, 26) and not fused.supported(conv, 13)
+    assert not fused.supported(torch.nn.Conv2d(32, 48, 3, padding=1).cuda(), 12)
+    with pytest.raises(nat.TronNativeError):
+        fused.conv3x3(torch.randn(2, 32, 14, 14, device="cuda"), conv)
+
+
+def test_infer_matches_reference_q_values(fused):
+    """Net.infer (HIP trunk) on the recorded inputs: Q within 1e-5 of the reference network's."""
+    sys.path.insert(0, GOLDEN)
+    from netgen import det_state_dict
+    from Net.DQNNet import Net
+    g = load_golden("net")
+    shapes = collections.OrderedDict((k, tuple(v)) for k, v in json.loads(str(g["shapes_json"])).items())
+    net = Net(4, 10).cuda()
+    net.load_state_dict(det_state_dict(shapes, salt=0))
+    x = torch.from_numpy(g["x"]).cuda()
+    q = net.infer(x).cpu().numpy()
+    assert np.allclose(q, g["q"], rtol=TOL, atol=TOL), np.abs(q - g["q"]).max()
+    assert np.array_equal(q.argmax(1), g["q"].argmax(1))
+    assert net.training                                     # infer() leaves the module's mode alone
+
+
+@pytest.mark.parametrize("W,B,cin", [(10, 513, 3), (10, 64, 4), (24, 37, 3)])
+def test_infer_equals_module_forward_and_codes_path(fused, W, B, cin):
+    from Net.DQNNet import Net
+    from tron.vec import pop_up_planes
+    torch.manual_seed(W + B)
+    S = W + 2
+    net = Net(cin, W).cuda()
+    vals = torch.tensor([1, -1, -2, -3, 10, -10], dtype=torch.int8, device="cuda")
+    codes = vals[torch.randint(0, 6, (B, S, S), device="cuda")]
+    planes = pop_up_planes(codes)
+    if cin == 4:
+        planes = torch.cat([planes, torch.full((B, 1, S, S), 5.0, device="cuda")], 1)
+    net.eval()
+    with torch.no_grad():
+        ref = net.double()(planes.double())
+    net.float().train()
+    q_p = net.infer(planes)
+    q_c = net.infer(codes, codes=True, plane4=5.0)
+    assert (q_p.double() - ref).abs().max().item() < TOL
+    assert torch.equal(q_p, q_c)
