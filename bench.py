@@ -162,6 +162,26 @@ def dqn_record(envs, width, steps, warmup, batch, repeats, world, rank):
         runs.append((max_over_ranks(o["seconds"], world), o))
     runs.sort(key=lambda x: x[0])
     sec, o = runs[len(runs) // 2]
+    # the policy alone: greedy CNN forward over 2N observations + env step, no learning (what evaluation /
+    # rating sweeps run, play.py:72-98) — csrc/tron_conv.hip trunk, conv1 straight from the int8 codes
+    from tron.vec import VecTron
+    env = VecTron(envs, width, seed=0x5EED, rank=rank, obs_format="codes")
+    S = width + 2
+    codes = env.reset().reshape(2 * envs, S, S)
+    pol = []
+    for rep in range(repeats + 1):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            a = brain.qnetwork_local.infer(codes, codes=True).argmax(1).to(torch.int8).reshape(envs, 2)
+            codes = env.step(a)[0].reshape(2 * envs, S, S)
+        torch.cuda.synchronize()
+        if rep:
+            pol.append(max_over_ranks(time.perf_counter() - t0, world))
+    env.close()
+    pol_s = statistics.median(pol)
     learned = o["learn_steps"] * batch * world
     f_fwd = net_forward_flops(width)
     # per iteration of the loop: the policy forward on 2N observations (eval, no grad); per learn step on a
@@ -170,6 +190,10 @@ def dqn_record(envs, width, steps, warmup, batch, repeats, world, rank):
     return {"metric": "dqn-transitions/sec", "value": learned / sec, "unit": "transitions/s",
             "env_steps_per_s_with_policy": envs * steps * world / sec,
             "transitions_pushed_per_s": 2 * envs * steps * world / sec,
+            "policy_rollout": {"metric": "env-steps/sec with the greedy CNN policy in the loop, no learning",
+                               "value": envs * steps * world / pol_s,
+                               "tflops": f_fwd * 2 * envs * steps * world / pol_s / 1e12,
+                               "frac_of_f32_matrix_peak": f_fwd * 2 * envs * steps * world / pol_s / 1e12 / F32_MATRIX_PEAK_TFLOPS},
             "steps": steps, "repeats": repeats, "seconds_min_med_max": [runs[0][0], sec, runs[-1][0]],
             "learn_batch": batch, "learn_every_env_steps": 2, "dtype": "f32",
             "config": {"workload": f"{envs} parallel {width}x{width} self-play envs per GPU, DDQN + target net, "
@@ -258,7 +282,7 @@ def main():
     torch.cuda.synchronize()                       # do not order themselves behind it
     nonrev = args.actions == "nonreversing"
     walls, dev_ms = [], []
-    per_step_ms = []
+    per_step_ms, two_stream_ms = [], []
     with torch.cuda.stream(side):
         if args.incremental:                       # the in-place variant has no rollout entry point: launch loop
             step = env.step_fn(autoreset=True, nonreversing=nonrev)
@@ -267,8 +291,8 @@ def main():
                 for _ in range(k):
                     step()
         else:
-            def run(k, per_step=False):
-                env.rollout_random(k, nonreversing=nonrev, per_step_launches=per_step)
+            def run(k, per_step=False, two=False):
+                env.rollout_random(k, nonreversing=nonrev, per_step_launches=per_step, two_streams=two)
         run(args.warmup)
         for _ in range(max(1, args.repeats)):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -290,6 +314,15 @@ def main():
                 ev3.record()
                 torch.cuda.synchronize()
                 per_step_ms.append(ev2.elapsed_time(ev3) / args.steps)
+            # ... and as two half-batches on two streams (a caller that pipelines the halves against its policy)
+            run(min(args.warmup, 16), False, True)
+            for _ in range(max(1, args.repeats)):
+                ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev2.record()
+                run(args.steps, False, True)
+                ev3.record()
+                torch.cuda.synchronize()
+                two_stream_ms.append(ev2.elapsed_time(ev3) / args.steps)
     # launches in the timed region: the rollout is persistent (<= 64 steps per launch of k_obs_roll / k_tile_roll,
     # include/tron_hip.h TRON_ROLLOUT_CHUNK); the incremental variant launches once per step
     persistent = not args.incremental and args.steps > 1 and not os.environ.get("TRON_ROLL_PER_STEP")
@@ -379,6 +412,14 @@ def main():
                              "kernel": "k_obs (observation-is-state step)" if obs_is_state else "k_tile"},
                 "frac": ps_ach / HBM_PEAK_GBS,
                 "note": "same K steps, this rank's HIP events, after the measured job"}
+            if two_stream_ms:
+                ts = statistics.median(two_stream_ms)
+                ts_ach = b_alg * args.envs / (ts * 1e-3) / 1e9
+                out["per_step_launches"]["two_streams"] = {
+                    "metric": "env-steps/sec, one launch per step and per half of the envs, halves on two streams",
+                    "ms_per_step": ts, "ms_per_step_min_max": [min(two_stream_ms), max(two_stream_ms)],
+                    "value": args.envs * world / (ts * 1e-3), "achieved": ts_ach, "frac": ts_ach / HBM_PEAK_GBS,
+                    "frac_of_achievable": ts_ach / HBM_COPY_GBS}
         if dqn is not None:
             out["dqn"] = dqn
         if world == 1 and not args.no_cpu_baseline:

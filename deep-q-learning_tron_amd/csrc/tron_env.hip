@@ -514,10 +514,10 @@ template <int FMT, bool DO_STEP, bool ALIGNED>
 __global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, uint32_t cpe_magic,
                                                 const int8_t *__restrict__ actions,
                                                 const float *__restrict__ uniforms, uint32_t flags,
-                                                void *__restrict__ obs, StepOut out)
+                                                void *__restrict__ obs, StepOut out, int tile0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    tile_step<FMT, DO_STEP, ALIGNED>(P, E, cpe, cpe_magic, actions, uniforms, flags, obs, out, (int)blockIdx.x, smem);
+    tile_step<FMT, DO_STEP, ALIGNED>(P, E, cpe, cpe_magic, actions, uniforms, flags, obs, out, (int)blockIdx.x + tile0, smem);
 }
 
 // persistent rollout on the board-owning layout (every mode / format / side): see k_obs_roll
@@ -792,10 +792,11 @@ __device__ __forceinline__ void obs_tile(const Params &P, int E, uint32_t cpe, u
 
 template <bool DO_STEP>
 __global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, uint32_t cpe_magic,
-                                               const int8_t *__restrict__ actions, uint32_t flags, StepOut out)
+                                               const int8_t *__restrict__ actions, uint32_t flags, StepOut out,
+                                               int tile0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    obs_tile<DO_STEP>(P, E, cpe, cpe_magic, actions, flags, out, (int)blockIdx.x, smem);
+    obs_tile<DO_STEP>(P, E, cpe, cpe_magic, actions, flags, out, (int)blockIdx.x + tile0, smem);
 }
 
 // The random-action rollout as ONE launch for k_steps steps (tron_rollout_random): envs never interact,
@@ -1174,6 +1175,9 @@ struct tron_env {
     size_t smem;              // dynamic LDS bytes
     bool aligned;             // G % 4 == 0: 16-byte global accesses
     void *blob;               // one allocation behind all state arrays
+    hipStream_t side;         // TRON_ROLLOUT_TWO_STREAMS: second launch stream + fork/join events, created on first use
+    hipEvent_t fork, join;
+    int part0, nparts;        // slice of the tiles the next launch covers (0, 1 = all of them)
 };
 
 namespace {
@@ -1196,6 +1200,15 @@ inline void allow_big_lds(const void *kern, int device, uint64_t &prepared)
     prepared |= bit;
 }
 
+// tiles [tile0, tile0 + blocks) of the handle's current part (all tiles unless a *_part entry point set one)
+inline void part_tiles(const tron_env *h, int &tile0, int &blocks)
+{
+    const int ntiles = (h->P.N + h->E - 1) / h->E;
+    const int np = h->nparts > 0 ? h->nparts : 1;
+    tile0 = (int)((long long)ntiles * h->part0 / np);
+    blocks = (int)((long long)ntiles * (h->part0 + 1) / np) - tile0;
+}
+
 template <int FMT, bool DO_STEP, bool ALIGNED>
 int launch_one(tron_env *h, const int8_t *actions, const float *uniforms, uint32_t flags, void *obs, StepOut out,
                hipStream_t st)
@@ -1203,9 +1216,11 @@ int launch_one(tron_env *h, const int8_t *actions, const float *uniforms, uint32
     auto kern = k_tile<FMT, DO_STEP, ALIGNED>;
     static uint64_t prepared = 0;    // per instantiation, one bit per device
     allow_big_lds(reinterpret_cast<const void *>(kern), h->device, prepared);
-    const int blocks = (h->P.N + h->E - 1) / h->E;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), h->smem, st, h->P, h->E, h->cpe, h->cpe_magic, actions,
-                       uniforms, flags, obs, out);
+    int tile0, blocks;
+    part_tiles(h, tile0, blocks);
+    if (blocks > 0)
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), h->smem, st, h->P, h->E, h->cpe, h->cpe_magic, actions,
+                           uniforms, flags, obs, out, tile0);
     return launch_status();
 }
 
@@ -1263,9 +1278,12 @@ int launch_obs(tron_env *h, const int8_t *actions, uint32_t flags, StepOut out, 
     auto kern = k_obs<DO_STEP>;
     static uint64_t prepared = 0;    // per instantiation, one bit per device
     allow_big_lds(reinterpret_cast<const void *>(kern), h->device, prepared);
-    const int blocks = (h->P.N + h->E - 1) / h->E;
+    int tile0, blocks;
+    part_tiles(h, tile0, blocks);
     const size_t smem = ((size_t)h->E + 1u) * h->cpe * 16u + 4u * (size_t)h->E * 16u;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, h->P, h->E, h->cpe, h->cpe_magic, actions, flags, out);
+    if (blocks > 0)
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, h->P, h->E, h->cpe, h->cpe_magic, actions, flags, out,
+                           tile0);
     return launch_status();
 }
 
@@ -1326,6 +1344,7 @@ int tron_create(int32_t n_envs, int32_t W, int32_t mode, int32_t fair, uint32_t 
     P.seed = seed; P.stream = rng_stream;
     P.r_step = -1.0f; P.r_win = 100.0f; P.r_lose = -100.0f; P.r_draw = 0.0f; P.r_index = 0;   // DDQN.py:289-305
     h->device = dev;
+    h->side = nullptr; h->fork = nullptr; h->join = nullptr; h->part0 = 0; h->nparts = 1;
     h->aligned = (P.G % 4) == 0;
     h->cpe = ((uint32_t)P.G + 15u) / 16u;
     h->cpe_magic = (uint32_t)((0x100000000ull + h->cpe - 1) / h->cpe);   // exact i / cpe for i < 2^32 / cpe
@@ -1376,6 +1395,9 @@ int tron_create(int32_t n_envs, int32_t W, int32_t mode, int32_t fair, uint32_t 
 int tron_destroy(tron_handle h)
 {
     if (!h) return TRON_ERR_BAD_ARG;
+    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    if (h->fork) (void)hipEventDestroy(h->fork);
+    if (h->join) (void)hipEventDestroy(h->join);
     (void)hipFree(h->blob);
     delete h;
     return TRON_OK;
@@ -1470,6 +1492,33 @@ int tron_step(tron_handle h, const int8_t *actions, const float *uniforms, uint3
                             stream);
 }
 
+int tron_part_range(tron_handle h, int32_t part, int32_t nparts, int32_t *first_env, int32_t *n_envs)
+{
+    if (!h || nparts < 1 || part < 0 || part >= nparts) return TRON_ERR_BAD_ARG;
+    const int ntiles = (h->P.N + h->E - 1) / h->E;
+    const long long t0 = (long long)ntiles * part / nparts, t1 = (long long)ntiles * (part + 1) / nparts;
+    const long long e0 = t0 * h->E, e1 = t1 * h->E < h->P.N ? t1 * h->E : h->P.N;
+    if (first_env) *first_env = (int32_t)e0;
+    if (n_envs) *n_envs = (int32_t)(e1 - e0);
+    return TRON_OK;
+}
+
+int tron_step_encode_part(tron_handle h, int32_t part, int32_t nparts, const int8_t *actions, const float *uniforms,
+                          uint32_t flags, int32_t obs_fmt, void *obs, int8_t *out_done, int8_t *out_winner,
+                          float *out_reward, void *stream)
+{
+    if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
+    if (nparts < 1 || part < 0 || part >= nparts) return TRON_ERR_BAD_ARG;
+    if (flags & TRON_STEP_INCREMENTAL) return TRON_ERR_UNSUPPORTED;
+    if (h->P.obs_state && (obs_fmt == TRON_OBS_PLANES3_F32 || obs_fmt == TRON_OBS_PLANES4_F32)) return TRON_ERR_UNSUPPORTED;
+    h->part0 = part;
+    h->nparts = nparts;
+    const int rc = tron_step_encode(h, actions, uniforms, flags, obs_fmt, obs, out_done, out_winner, out_reward, stream);
+    h->part0 = 0;
+    h->nparts = 1;
+    return rc;
+}
+
 int tron_encode(tron_handle h, int32_t obs_fmt, void *obs, void *stream)
 {
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
@@ -1553,8 +1602,9 @@ int rollout_launches(tron_env *h, int32_t k_steps, uint32_t flags, int32_t obs_f
                      hipStream_t st)
 {
     static const bool env_per_step = getenv("TRON_ROLL_PER_STEP") != nullptr;   // A/B switch: one launch per step
-    const bool per_step = env_per_step || (flags & TRON_ROLLOUT_PER_STEP) != 0u;
-    flags &= ~TRON_ROLLOUT_PER_STEP;
+    const bool two_streams = (flags & TRON_ROLLOUT_TWO_STREAMS) != 0u;
+    const bool per_step = env_per_step || two_streams || (flags & TRON_ROLLOUT_PER_STEP) != 0u;
+    flags &= ~(TRON_ROLLOUT_PER_STEP | TRON_ROLLOUT_TWO_STREAMS);
     if (h->P.obs_state && !per_step && k_steps > 1) {
         const int rc = rollout_persistent(h, k_steps, flags, out, st);
         if (rc != TRON_OK) return rc;
@@ -1569,10 +1619,44 @@ int rollout_launches(tron_env *h, int32_t k_steps, uint32_t flags, int32_t obs_f
         }
         return TRON_OK;
     }
-    for (int k = 0; k < k_steps; ++k) {
-        const int rc = h->P.obs_state ? launch_obs<true>(h, nullptr, flags, out, st)
-                                      : launch_fmt<true>(h, obs_fmt, nullptr, nullptr, flags, obs, out, st);
+    if (two_streams && k_steps > 0) {
+        // The env batch as two independent halves, each a launch sequence of its own on its own stream: a half's
+        // step s+1 only depends on its own step s, so the drain of one half's launch overlaps the ramp-up of the
+        // other's.  Fork / join events order both against what came before and comes after on `st`.
+        if (!h->side) {
+            if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&h->join, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                return TRON_ERR_ALLOC;
+            }
+        }
+        if (hipEventRecord(h->fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->fork, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return TRON_ERR_LAUNCH;
+        }
+        h->nparts = 2;
+        int rc = TRON_OK;
+        for (int k = 0; k < k_steps && rc == TRON_OK; ++k)
+            for (int part = 0; part < 2 && rc == TRON_OK; ++part) {
+                h->part0 = part;
+                hipStream_t s2 = part ? h->side : st;
+                rc = h->P.obs_state ? launch_obs<true>(h, nullptr, flags, out, s2)
+                                    : launch_fmt<true>(h, obs_fmt, nullptr, nullptr, flags, obs, out, s2);
+            }
+        h->part0 = 0;
+        h->nparts = 1;
+        if (hipEventRecord(h->join, h->side) != hipSuccess || hipStreamWaitEvent(st, h->join, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return TRON_ERR_LAUNCH;
+        }
         if (rc != TRON_OK) return rc;
+    } else {
+        for (int k = 0; k < k_steps; ++k) {
+            const int rc = h->P.obs_state ? launch_obs<true>(h, nullptr, flags, out, st)
+                                          : launch_fmt<true>(h, obs_fmt, nullptr, nullptr, flags, obs, out, st);
+            if (rc != TRON_OK) return rc;
+        }
     }
     if (h->P.obs_state && (obs_fmt == TRON_OBS_PLANES3_F32 || obs_fmt == TRON_OBS_PLANES4_F32) && k_steps > 0)
         return obs_planes(h, obs_fmt, obs, st);
@@ -1586,7 +1670,7 @@ int tron_rollout_random(tron_handle h, int32_t k_steps, uint32_t flags, int32_t 
 {
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
     if (k_steps < 0 || (obs_fmt != TRON_OBS_NONE) != (obs != nullptr)) return TRON_ERR_BAD_ARG;
-    if (flags & ~(TRON_STEP_NONREVERSING | TRON_ROLLOUT_PER_STEP)) return TRON_ERR_BAD_ARG;   // autoreset is implied
+    if (flags & ~(TRON_STEP_NONREVERSING | TRON_ROLLOUT_PER_STEP | TRON_ROLLOUT_TWO_STREAMS)) return TRON_ERR_BAD_ARG;   // autoreset is implied
     StepOut out{nullptr, nullptr, nullptr, totals};
     if (h->P.obs_state && obs_fmt == TRON_OBS_CODES_I8 && obs != h->P.obs_state) return TRON_ERR_BAD_ARG;
     return rollout_launches(h, k_steps, flags | TRON_STEP_AUTORESET, obs_fmt, obs, out, S_(stream));

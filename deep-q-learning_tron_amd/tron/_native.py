@@ -19,6 +19,7 @@ STEP_AUTORESET = 1
 STEP_INCREMENTAL = 2
 STEP_NONREVERSING = 4
 ROLLOUT_PER_STEP = 8
+ROLLOUT_TWO_STREAMS = 16
 
 _vp, _i32, _i64, _u32, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_double
 
@@ -35,6 +36,8 @@ SIGNATURES = {
     "tron_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "tron_attach_obs_state": (C.c_int, [_vp, _vp, _vp]),
     "tron_step_encode": (C.c_int, [_vp, _vp, _vp, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "tron_step_encode_part": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _u32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "tron_part_range": (C.c_int, [_vp, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "tron_step": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "tron_encode": (C.c_int, [_vp, _i32, _vp, _vp]),
     "tron_rollout_random": (C.c_int, [_vp, _i32, _u32, _i32, _vp, _vp, _vp]),

@@ -135,6 +135,27 @@ class VecTron:
                                                  nat.ptr(self.reward), nat.stream_ptr()), "tron_step_encode")
         return self.obs, self.reward, self.done, self.winner
 
+    def part_range(self, part, nparts):
+        """(first_env, n_envs) of slice `part` of `nparts` (whole tiles of consecutive envs, split evenly)."""
+        a, b = C.c_int32(), C.c_int32()
+        nat.check(self._lib.tron_part_range(self._h, int(part), int(nparts), C.byref(a), C.byref(b)), "tron_part_range")
+        return a.value, b.value
+
+    def step_part(self, part, nparts, actions=None, uniforms=None, autoreset=True, nonreversing=False):
+        """step() for one slice of the envs, on torch's current stream: run the slices as independent pipelines
+        (one stream each) so that the policy forward of one slice overlaps the env kernel of another.  `actions`
+        / `uniforms` and the returned tensors are the FULL [N, ...] buffers; only the slice's rows are read and
+        written (part_range tells which)."""
+        a = self._dev_arg(actions, torch.int8, (self.N, 2))
+        u = self._dev_arg(uniforms, torch.float32, (self.N, 2))
+        flags = (nat.STEP_AUTORESET if autoreset else 0) | (nat.STEP_NONREVERSING if nonreversing else 0)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_step_encode_part(self._h, int(part), int(nparts), nat.ptr(a), nat.ptr(u), flags,
+                                                      self._fmt, nat.ptr(self.obs), nat.ptr(self.done),
+                                                      nat.ptr(self.winner), nat.ptr(self.reward), nat.stream_ptr()),
+                      "tron_step_encode_part")
+        return self.obs, self.reward, self.done, self.winner
+
     def step_fn(self, autoreset=True, nonreversing=False):
         """A zero-argument callable that launches one random-action step (Philox actions) with all
         ctypes arguments bound once — for launch loops where Python argument handling per call
@@ -159,10 +180,12 @@ class VecTron:
             nat.check(self._lib.tron_encode(self._h, fmt, nat.ptr(out), nat.stream_ptr()), "tron_encode")
         return out
 
-    def rollout_random(self, k_steps, totals=None, nonreversing=False, per_step_launches=False):
+    def rollout_random(self, k_steps, totals=None, nonreversing=False, per_step_launches=False, two_streams=False):
         """k_steps random-action steps with autoreset (the BASELINE synthetic rollout): persistent launches of
-        up to 64 steps each, or — per_step_launches=True — one launch per step (same results)."""
-        flags = (nat.STEP_NONREVERSING if nonreversing else 0) | (nat.ROLLOUT_PER_STEP if per_step_launches else 0)
+        up to 64 steps each, or — per_step_launches=True — one launch per step, or — two_streams=True — one launch
+        per step and per half of the envs on two streams (same results every way)."""
+        flags = ((nat.STEP_NONREVERSING if nonreversing else 0) | (nat.ROLLOUT_PER_STEP if per_step_launches else 0) |
+                 (nat.ROLLOUT_TWO_STREAMS if two_streams else 0))
         with torch.cuda.device(self.device):
             nat.check(self._lib.tron_rollout_random(self._h, int(k_steps), flags,
                                                     self._fmt, nat.ptr(self.obs),

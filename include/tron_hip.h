@@ -63,6 +63,10 @@ enum {
 
 #define TRON_ROLLOUT_CHUNK 64     /* steps per persistent rollout launch (tron_rollout_random) */
 #define TRON_ROLLOUT_PER_STEP 8u  /* tron_rollout_random flag: one launch per step instead (for A/B measurements) */
+#define TRON_ROLLOUT_TWO_STREAMS 16u /* tron_rollout_random flag: one launch per step and per HALF of the envs, the two
+                                      * halves on two streams (the handle owns the second one), so one half's launch
+                                      * drains while the other's ramps up — the launch pattern of a caller that pipelines
+                                      * two env halves against its policy with tron_step_encode_part */
 
 typedef struct tron_env *tron_handle;
 
@@ -127,6 +131,15 @@ int tron_attach_obs_state(tron_handle h, int8_t *obs_codes, void *stream);
 int tron_step_encode(tron_handle h, const int8_t *actions, const float *uniforms, uint32_t flags,
                      int32_t obs_fmt, void *obs, int8_t *out_done, int8_t *out_winner,
                      float *out_reward, void *stream);
+/* The same step for ONE SLICE of the envs: part `part` of `nparts` equal slices of the handle's env tiles
+ * (tron_part_range gives the env range).  All buffers stay full-size and are indexed by the global env
+ * number, so a caller can run slices as independent pipelines on different streams: while slice A is in the
+ * env kernel, the policy network evaluates slice B's observations (envs never interact: ACKTR.py:183,285-289).
+ * Not with TRON_STEP_INCREMENTAL, nor with f32 planes on an attached observation buffer.                    */
+int tron_step_encode_part(tron_handle h, int32_t part, int32_t nparts, const int8_t *actions,
+                          const float *uniforms, uint32_t flags, int32_t obs_fmt, void *obs, int8_t *out_done,
+                          int8_t *out_winner, float *out_reward, void *stream);
+int tron_part_range(tron_handle h, int32_t part, int32_t nparts, int32_t *first_env, int32_t *n_envs);
 /* Same without an observation (Game.next_frame, game.py:149-252).            */
 int tron_step(tron_handle h, const int8_t *actions, const float *uniforms, uint32_t flags,
               int8_t *out_done, int8_t *out_winner, float *out_reward, void *stream);

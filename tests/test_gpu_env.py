@@ -348,6 +348,55 @@ def test_persistent_rollout_equals_stepwise(T, N, W, K):
     _compare_state(env, ref, "step after rollout")
 
 
+@pytest.mark.parametrize("N,W,mode,nparts", [(300, 10, None, 2), (5000, 24, None, 3), (700, 10, "temper", 2), (97, 7, "ice", 4)])
+def test_step_in_slices_equals_whole_step(T, N, W, mode, nparts):
+    """tron_step_encode_part: the env tiles stepped slice by slice — each slice on a stream of its own, as a caller
+    pipelining the slices against its policy would — leave the same state and outputs as one whole step."""
+    tv, oracle = T
+    env = tv.VecTron(N, W, mode=mode, seed=31, rank=5, obs_format="codes")
+    ref = oracle.VecOracle(N, W, mode=mode, seed=31, stream=5)
+    env.reset()
+    ref.reset_all()
+    ranges = [env.part_range(p, nparts) for p in range(nparts)]
+    assert ranges[0][0] == 0 and sum(n for _, n in ranges) == N
+    assert all(ranges[i][0] + ranges[i][1] == ranges[i + 1][0] for i in range(nparts - 1))
+    streams = [torch.cuda.Stream() for _ in range(nparts)]
+    torch.cuda.synchronize()
+    rs = np.random.RandomState(3)
+    for t in range(6):
+        acts = None if t % 2 else torch.from_numpy(rs.randint(0, 4, (N, 2)).astype(np.int8)).cuda()
+        torch.cuda.synchronize()
+        for p in reversed(range(nparts)):                       # any order, any stream
+            with torch.cuda.stream(streams[p]):
+                env.step_part(p, nparts, acts)
+        torch.cuda.synchronize()
+        o, d, w, r = ref.step(None if acts is None else np_(acts), autoreset=True)
+        assert np.array_equal(np_(env.obs).reshape(N, 2, -1), o), t
+        assert np.array_equal(np_(env.done), d) and np.array_equal(np_(env.winner), w) and np.array_equal(np_(env.reward), r)
+    _compare_state(env, ref, "sliced steps")
+
+
+@pytest.mark.parametrize("N,W,mode,K", [(65536, 24, None, 9), (4096, 10, None, 20), (2000, 10, "temper", 11)])
+def test_two_stream_rollout_equals_oracle(T, N, W, mode, K):
+    """TRON_ROLLOUT_TWO_STREAMS: one launch per step and per half of the envs, the halves on two streams."""
+    tv, oracle = T
+    import os
+    oracle.set_threads(min(16, len(os.sched_getaffinity(0))))
+    env = tv.VecTron(N, W, mode=mode, seed=8, rank=1, obs_format="codes")
+    ref = oracle.VecOracle(N, W, mode=mode, seed=8, stream=1)
+    env.reset()
+    ref.reset_all()
+    totals = torch.zeros(4, dtype=torch.int64, device="cuda")
+    env.rollout_random(K, totals, two_streams=True)
+    torch.cuda.synchronize()
+    for k in range(K):
+        o, _, _, _ = ref.step(autoreset=True, want_obs=(k == K - 1))
+    oracle.set_threads(1)
+    assert int(totals[0]) == N * K
+    assert np.array_equal(np_(env.obs).reshape(N, 2, -1), o)
+    _compare_state(env, ref, "two-stream rollout")
+
+
 @pytest.mark.parametrize("N,W,K,kw", [(260, 10, 70, dict(mode="temper")), (90, 7, 33, dict(mode="ice", slide=0.4)),
                                       (150, 9, 20, dict(obs_format="planes3")), (64, 12, 65, dict(obs_format="planes4", mode="temper")),
                                       (100, 10, 40, dict(obs_is_state=False))])
