@@ -39,7 +39,7 @@ def rating(model, model2=None, n_games=10000, slides=None, width=10, gamemode="i
     # what main_loop feeds beside the planes: get_multy(0) to player 1, [get_rate()] to player 2
     degree = st["degree"].to(torch.float32)
     env1 = torch.stack([degree, st["weight"][:, 0].to(torch.float32)], 1)
-    env2 = (-((degree - 30) * 0.6) / 100).unsqueeze(1)
+    env2 = -((degree - 30) * 0.6) / 100           # [n]: main_loop hands player 2 torch.tensor([get_rate()]) per game
     prob_plane = ((-slide_t * 100) * (10 / 6) + 30).to(torch.float32).view(n, 1, 1, 1).expand(n, 1, S, S)
     for _ in range(max_steps or width * width):
         planes = pop_up_planes(obs.reshape(2 * n, S, S)).view(n, 2, 3, S, S)
@@ -59,21 +59,49 @@ def rating(model, model2=None, n_games=10000, slides=None, width=10, gamemode="i
     return out
 
 
-def main(args):
-    from Net.DQNNet import Net
+ARCHS = ("dqn", "map", "test", "net3", "net4", "mul")
+
+
+def load_player(path=None, arch="dqn", width=None, device=None):
+    """A player network from a `.bak` state_dict, the way play.py:53-61 builds its two: the reference wraps the net
+    in Brain(net, args, acktr=True) first — KFACOptimizer splits every bias into an AddBias layer (kfac.py:80-96,145) —
+    so an ACKTR checkpoint's keys read `conv1.module.weight` / `conv1.add_bias._bias`; A2C / DQN checkpoints keep
+    `conv1.weight` / `conv1.bias`.  Both layouts are recognised from the keys.  arch: "map" = MapNet
+    (ACKTR_player3map_*.bak), "test" = TestNet (ACKTR_player2make_dyna_model.bak), "net3" / "net4" / "mul" the other
+    ACNet classes, "dqn" = Net/DQNNet.Net (DDQN.bak).  Files are read with weights_only=True."""
     from config import MAP_WIDTH
-    nets = []
-    for path in (args.p1, args.p2):
-        net = Net(3, MAP_WIDTH).to("cuda").eval()
-        if path:
-            net.load_state_dict(torch.load(path, map_location="cuda", weights_only=True))
-        nets.append(net)
+    import Net.ACNet as A
+    from Net.DQNNet import Net as DQNNet
+    from Net.kfac import split_biases
+    width = MAP_WIDTH if width is None else width
+    device = torch.device(device or ("cuda" if torch.cuda.is_available() else "cpu"))
+    sd = None
+    if path:
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        if isinstance(sd, dict) and "local" in sd and "target" in sd:      # DDQN.save_checkpoint's full file
+            sd = sd["target"]
+    if arch == "dqn":
+        in_ch = 3 if sd is None else int(sd["conv1.module.weight" if "conv1.module.weight" in sd else "conv1.weight"].shape[1])
+        net = DQNNet(in_ch, width)
+    else:
+        net = {"map": A.MapNet, "test": A.TestNet, "net3": A.Net3, "net4": A.Net4, "mul": A.Mulnet}[arch](width)
+    if sd is not None:
+        if any(k.endswith(".add_bias._bias") for k in sd):
+            split_biases(net)                                              # the checkpoint was saved under K-FAC
+        net.load_state_dict(sd)
+    return net.to(device).eval()
+
+
+def main(args):
+    nets = [load_player(args.p1, args.arch1), load_player(args.p2, args.arch2)]
     rating(nets[0], nets[1], n_games=args.games)
 
 
 if __name__ == '__main__':
     parser = argparse.ArgumentParser()
-    parser.add_argument('--p1', required=False, help='state_dict (.bak) of player 1\'s DQN net')
-    parser.add_argument('--p2', required=False, help='state_dict (.bak) of player 2\'s DQN net')
+    parser.add_argument('--p1', required=False, help="state_dict (.bak) of player 1's net")
+    parser.add_argument('--p2', required=False, help="state_dict (.bak) of player 2's net")
+    parser.add_argument('--arch1', default="map", choices=ARCHS, help="play.py:53 seats a MapNet as player 1")
+    parser.add_argument('--arch2', default="test", choices=ARCHS, help="play.py:58 seats a TestNet as player 2")
     parser.add_argument('--games', type=int, default=10000)
     main(parser.parse_args())

@@ -641,7 +641,72 @@ def gen_minimax():
     print("minimax:", "; ".join(summary))
 
 
+# --------------------------------------------------------------------------
+# G-main-loop: Game.main_loop (game.py:279-328) driven by a scripted deterministic "network"
+# --------------------------------------------------------------------------
+def gen_main_loop():
+    """Both branches of game.py:296-304: a plain model gets (planes[1,3,S,S], env scalars) — get_multy(0) for
+    player 1, [get_rate()] for player 2 — and a MapNet-typed model gets the planes + the constant prob_map
+    plane [1,4,S,S].  The reference tests `type(model) == maptype`, so the MapNet branch is exercised with a real
+    reference MapNet whose `act` is replaced on the instance (its weights are never used).  Only player 1 can be
+    a MapNet there: for model2 the branch assigns action1 (game.py:301-302) and crashes.
+    Modes whose outcome does not depend on the slide uniform: None, ice with slide 1.0 (u <= 1 always) and
+    ice with slide -1.0 (never)."""
+    from scripted import ScriptedModel
+    from Net.ACNet import MapNet
+    rng = np.random.RandomState(77)
+    cases = []
+    for k in range(24):
+        W = 10
+        mode, slide = [(None, None), ("ice", 1.0), ("ice", -1.0)][k % 3]
+        branch = "map" if k % 2 else "plain"
+        while True:
+            starts = rng.randint(0, W, 4)
+            if (starts[0], starts[1]) != (starts[2], starts[3]):
+                break
+        weight, degree = rng.randint(40, 102, 2), int(rng.randint(-30, 31))
+        # the reference sizes prob_map by config.MAP_WIDTH (=10), which is this board
+        g = new_game(W, starts, mode, slide, weight, degree)
+        log1, log2 = [], []
+        m2 = ScriptedModel(salt=k + 1, log=log2)
+        if branch == "map":
+            m1 = MapNet()
+            s1 = ScriptedModel(salt=k, log=log1)
+            m1.act = s1.act                                  # instance attribute: type(m1) stays MapNet
+        else:
+            m1 = ScriptedModel(salt=k, log=log1)
+        g.main_loop(m1, pop=RU.pop_up, window=None, model2=m2)
+        pos, alive = snapshot(g)
+        cases.append(dict(W=W, mode=mode or "none", slide=-999.0 if slide is None else slide, branch=branch,
+                          starts=starts, weight=weight, degree=degree, salt=k, n_steps=len(log1),
+                          winner=0 if g.winner is None else g.winner, grid=raw_grid(g), pos=pos, alive=alive,
+                          history=len(g.history), log1=log1, log2=log2))
+    out = {"n": len(cases)}
+    for i, c in enumerate(cases):
+        pre = "c%d_" % i
+        out[pre + "mode"] = np.array(c["mode"])
+        out[pre + "branch"] = np.array(c["branch"])
+        out[pre + "scalars"] = np.array([c["W"], c["salt"], c["n_steps"], c["winner"], c["history"], c["degree"]], np.int64)
+        out[pre + "slide"] = np.array(c["slide"], np.float64)
+        out[pre + "starts"] = np.array(c["starts"], np.int8)
+        out[pre + "weight"] = np.array(c["weight"], np.int16)
+        out[pre + "grid"] = c["grid"]
+        out[pre + "pos"] = np.array(c["pos"], np.int8)
+        out[pre + "alive"] = np.array(c["alive"], np.int8)
+        for who, log in (("p1", c["log1"]), ("p2", c["log2"])):
+            out[pre + who + "_action"] = np.array([e["action"] for e in log], np.int8)
+            out[pre + who + "_channels"] = np.array([e["channels"] for e in log], np.int8)
+            out[pre + who + "_checksum"] = np.array([e["checksum"] for e in log], np.float64).reshape(len(log), 3)
+            out[pre + who + "_plane4"] = np.array([e["plane4"] for e in log], np.float64)
+            out[pre + who + "_env"] = np.array([e["env"] for e in log], np.float64).reshape(len(log), -1)
+    np.savez_compressed(os.path.join(OUT, "main_loop.npz"), **out)
+    print("main_loop:", len(cases), "games, steps", [c["n_steps"] for c in cases])
+
+
 def main():
+    if "--main-loop-only" in sys.argv:
+        gen_main_loop()
+        return
     if "--net-only" in sys.argv:
         gen_net()
         return
@@ -670,6 +735,7 @@ def main():
     gen_minimax()
     gen_net()
     gen_acktr()
+    gen_main_loop()
 
 
 if __name__ == "__main__":

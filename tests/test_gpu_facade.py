@@ -118,6 +118,52 @@ def test_main_loop_with_stub_model_and_ai_action():
     assert isinstance(ai.action(game.map(), 1), Direction)
 
 
+def test_main_loop_replays_reference_fixture():
+    """tests/golden/main_loop.npz: the reference's Game.main_loop (game.py:279-328) driven by the scripted model of
+    tests/golden/scripted.py — plain branch (planes + env scalars: get_multy(0) / [get_rate()], game.py:299,304) and
+    MapNet branch (planes + prob_map plane, game.py:297) — replayed through this repo's Game.main_loop on the GPU:
+    every model input, every action, the final board, positions, winner and history length are the reference's."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from scripted import ScriptedModel
+    from tron.game import Game, PositionPlayer
+    from tron.player import ACPlayer
+    from tron.util import pop_up
+    g = load_golden("main_loop")
+    branches = set()
+    for i in range(int(g["n"])):
+        pre = "c%d_" % i
+        W, salt, n_steps, winner, hist, degree = (int(v) for v in g[pre + "scalars"])
+        mode = None if str(g[pre + "mode"]) == "none" else str(g[pre + "mode"])
+        slide = None if float(g[pre + "slide"]) == -999.0 else float(g[pre + "slide"])
+        st = g[pre + "starts"]
+        game = Game(W, W, [PositionPlayer(1, ACPlayer(), [int(st[0]), int(st[1])]),
+                           PositionPlayer(2, ACPlayer(), [int(st[2]), int(st[3])])], mode, slide)
+        game.weight = [int(v) for v in g[pre + "weight"]]
+        game.degree = degree
+        m1, m2 = ScriptedModel(salt=salt), ScriptedModel(salt=salt + 1)
+        branch = str(g[pre + "branch"])
+        branches.add(branch)
+        if branch == "map":
+            m1.wants_prob_plane = True                         # this repo's marker for the MapNet calling convention
+        game.main_loop(m1, pop=pop_up, window=None, model2=m2)
+        for who, m in (("p1", m1), ("p2", m2)):
+            assert len(m.log) == n_steps, (i, who)
+            assert np.array_equal([e["action"] for e in m.log], g[pre + who + "_action"]), (i, who)
+            assert np.array_equal([e["channels"] for e in m.log], g[pre + who + "_channels"]), (i, who)
+            assert np.array_equal(np.array([e["checksum"] for e in m.log]).reshape(n_steps, 3), g[pre + who + "_checksum"]), (i, who)
+            assert np.array_equal(np.array([e["plane4"] for e in m.log]), g[pre + who + "_plane4"], equal_nan=True), (i, who)
+            assert all(e["plane4_uniform"] for e in m.log)
+            assert np.array_equal(np.array([e["env"] for e in m.log]).reshape(n_steps, -1), g[pre + who + "_env"]), (i, who)
+        assert (0 if game.winner is None else game.winner) == winner and game.done, i
+        assert np.array_equal(game._env.grid()[0].cpu().numpy(), g[pre + "grid"]), i
+        pos = [game.pps[0].position[0], game.pps[0].position[1], game.pps[1].position[0], game.pps[1].position[1]]
+        assert np.array_equal(pos, g[pre + "pos"]) and np.array_equal([int(pp.alive) for pp in game.pps], g[pre + "alive"]), i
+        assert len(game.history) == hist, i
+    assert branches == {"plain", "map"}
+
+
 def test_device_replay_ring_and_sampling():
     from tron.vec import DeviceReplay, pop_up_planes
     cells, cap = 144, 1000
@@ -207,6 +253,17 @@ def test_batched_rating_sweep():
     res = play.rating(Rand(), "minimax", n_games=300, slides=[0.0, 0.15], width=10, verbose=False)
     for r in res:
         assert r["p1_win"] + r["p2_win"] + r["draw"] == 300 and r["p1_rate"] < 0.2
+
+
+def test_rating_with_the_reference_player_pair():
+    """play.py:53-61's seating — a MapNet as player 1 (planes + prob_map plane), a TestNet as player 2 (planes +
+    [get_rate()]) — through the batched rating loop, both loaded by play.load_player."""
+    import play
+    torch.manual_seed(1)
+    p1, p2 = play.load_player(None, "map"), play.load_player(None, "test")
+    res = play.rating(p1, p2, n_games=128, slides=[0.0, 0.3], width=10, verbose=False)
+    for r in res:
+        assert r["p1_win"] + r["p2_win"] + r["draw"] == 128
 
 
 def test_acktr_batched_trainer_runs():

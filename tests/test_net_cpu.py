@@ -218,3 +218,38 @@ def test_png_window(tmp_path):
     raw = zlib.decompress(data[41:41 + idat_len])
     rows = np.frombuffer(raw, np.uint8).reshape(50, 1 + 150)
     assert np.all(rows[:, 0] == 0) and np.array_equal(rows[:, 1:].reshape(50, 50, 3), img)
+
+
+@pytest.mark.parametrize("arch", ["dqn", "map", "test", "mul"])
+def test_play_loads_plain_and_kfac_checkpoints(tmp_path, arch):
+    """play.py:53-61 loads `.bak` files saved from Brain(net, args, acktr=True) — K-FAC's bias split renames every
+    key (`conv1.module.weight`, `conv1.add_bias._bias`) — while A2C / DQN runs save the plain layout.  load_player
+    recognises both and gives the same network."""
+    import play
+    import Net.ACNet as A
+    from Net.DQNNet import Net as DQNNet
+    from Net.kfac import split_biases
+    torch.manual_seed(3)
+    src = DQNNet(3, 10) if arch == "dqn" else {"map": A.MapNet, "test": A.TestNet, "mul": A.Mulnet}[arch]()
+    plain = str(tmp_path / "plain.bak")
+    torch.save(src.state_dict(), plain)
+    x = torch.rand(5, 4 if arch == "map" else 3, 12, 12)
+    env = {"dqn": None, "map": None, "test": torch.rand(5), "mul": torch.rand(5, 2)}[arch]
+
+    def run(net):
+        net.eval()
+        with torch.no_grad():
+            out = net(x) if env is None else net(x, env)
+        return out if torch.is_tensor(out) else torch.cat([o.reshape(5, -1) for o in out], 1)
+    want = run(src)
+    a = play.load_player(plain, arch, device="cpu")
+    assert torch.equal(run(a), want)
+    if arch == "dqn":                                       # the DQN net is only ever trained with Adam (DDQN.py:52)
+        return
+    split_biases(src)                                       # what KFACOptimizer.__init__ does to the net (kfac.py:145)
+    kfac = str(tmp_path / "kfac.bak")
+    torch.save(src.state_dict(), kfac)
+    assert any(k.endswith(".add_bias._bias") for k in src.state_dict())
+    b = play.load_player(kfac, arch, device="cpu")
+    assert torch.allclose(run(b), want, rtol=0, atol=1e-6)
+    assert not b.training
