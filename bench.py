@@ -282,7 +282,8 @@ def main():
     torch.cuda.synchronize()                       # do not order themselves behind it
     nonrev = args.actions == "nonreversing"
     walls, dev_ms = [], []
-    per_step_ms, two_stream_ms = [], []
+    per_step_ms, two_stream_ms, resident_ms = [], [], []
+    obs_is_state_cfg = args.mode == "none" and args.obs == "codes" and args.width % 2 == 0
     with torch.cuda.stream(side):
         if args.incremental:                       # the in-place variant has no rollout entry point: launch loop
             step = env.step_fn(autoreset=True, nonreversing=nonrev)
@@ -291,8 +292,8 @@ def main():
                 for _ in range(k):
                     step()
         else:
-            def run(k, per_step=False, two=False):
-                env.rollout_random(k, nonreversing=nonrev, per_step_launches=per_step, two_streams=two)
+            def run(k, per_step=False, two=False, resident=False):
+                env.rollout_random(k, nonreversing=nonrev, per_step_launches=per_step, two_streams=two, resident=resident)
         run(args.warmup)
         for _ in range(max(1, args.repeats)):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -323,6 +324,17 @@ def main():
                 ev3.record()
                 torch.cuda.synchronize()
                 two_stream_ms.append(ev2.elapsed_time(ev3) / args.steps)
+            # ... and the persistent rollout with the boards resident in LDS between steps (a different traffic
+            # contract: 2G + 32 bytes per env-step; reported under its own label)
+            if obs_is_state_cfg:
+                run(args.warmup, False, False, True)
+                for _ in range(max(1, args.repeats)):
+                    ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev2.record()
+                    run(args.steps, False, False, True)
+                    ev3.record()
+                    torch.cuda.synchronize()
+                    resident_ms.append(ev2.elapsed_time(ev3) / args.steps)
     # launches in the timed region: the rollout is persistent (<= 64 steps per launch of k_obs_roll / k_tile_roll,
     # include/tron_hip.h TRON_ROLLOUT_CHUNK); the incremental variant launches once per step
     persistent = not args.incremental and args.steps > 1 and not os.environ.get("TRON_ROLL_PER_STEP")
@@ -420,6 +432,21 @@ def main():
                     "ms_per_step": ts, "ms_per_step_min_max": [min(two_stream_ms), max(two_stream_ms)],
                     "value": args.envs * world / (ts * 1e-3), "achieved": ts_ach, "frac": ts_ach / HBM_PEAK_GBS,
                     "frac_of_achievable": ts_ach / HBM_COPY_GBS}
+        if resident_ms:
+            rs_ms = statistics.median(resident_ms)
+            g = (args.width + 2) ** 2
+            rs_ach = (2 * g + 32) * args.envs / (rs_ms * 1e-3) / 1e9
+            out["resident_rollout"] = {
+                "metric": "env-steps/sec (persistent rollout, boards resident in LDS between the steps of a launch)",
+                "value": args.envs * world / (rs_ms * 1e-3), "ms_per_step": rs_ms,
+                "ms_per_step_min_max": [min(resident_ms), max(resident_ms)],
+                "roofline": {"bound": "hbm", "alg_bytes_per_env_step": 2 * g + 32,
+                             "note": "both observation planes are still written every step (2G + 32 B); the G-byte state "
+                                     "read per step is gone because the state never leaves the chip inside a launch",
+                             "achieved": rs_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rs_ach / HBM_PEAK_GBS,
+                             "achievable_peak": 6100.0, "frac_of_achievable": rs_ach / 6100.0,
+                             "achievable_note": "the guide's plain-store rate 6.0-6.2 TB/s",
+                             "kernel": "k_obs_roll with TRON_ROLLOUT_RESIDENT"}}
         if dqn is not None:
             out["dqn"] = dqn
         if world == 1 and not args.no_cpu_baseline:

@@ -635,10 +635,12 @@ __device__ inline void lane_move_codes(const Params &P, unsigned char *g, const 
 
 // One tile of E envs through one step; `smem` is the workgroup's dynamic LDS.  Shared by k_obs (one
 // tile per workgroup per launch) and k_obs_roll (workgroups that keep stepping their own tiles).
+// keep_tile (persistent rollout, TRON_ROLLOUT_RESIDENT): the tile's LDS copy is left exactly as the next step needs
+// it (restarted boards are written back to it); have_tile: it already is, so the tile is not loaded again.
 template <bool DO_STEP>
 __device__ __forceinline__ void obs_tile(const Params &P, int E, uint32_t cpe, uint32_t cpe_magic,
                                          const int8_t *__restrict__ actions, uint32_t flags, const StepOut &out,
-                                         int tile_idx, unsigned char *smem)
+                                         int tile_idx, unsigned char *smem, bool have_tile = false, bool keep_tile = false)
 {
     const int G = P.G;
     uint4 *tile = reinterpret_cast<uint4 *>(smem);                  // [E*cpe] player-1 codes
@@ -683,7 +685,7 @@ __device__ __forceinline__ void obs_tile(const Params &P, int E, uint32_t cpe, u
             const uint32_t i = base + (uint32_t)tid + (uint32_t)k * BLOCK;
             const uint32_t le = chunk_env(i, cpe, cpe_magic);
             const uint32_t c = (i - le * cpe) * 16u;
-            if (i < nchunks) v[k] = load_chunk<true>(otile + (size_t)le * 2u * G + c);   // player-1 plane
+            if (i < nchunks && !have_tile) v[k] = load_chunk<true>(otile + (size_t)le * 2u * G + c);   // player-1 plane
         }
         if (base == 0u && DO_STEP && mine) {
             // random-number work in the shadow of the tile load: wave 0 the actions, wave 1 the next start
@@ -707,7 +709,7 @@ __device__ __forceinline__ void obs_tile(const Params &P, int E, uint32_t cpe, u
 #pragma unroll
         for (int k = 0; k < DK; ++k) {
             const uint32_t i = base + (uint32_t)tid + (uint32_t)k * BLOCK;
-            if (i < nchunks) tile[i] = v[k];
+            if (i < nchunks && !have_tile) tile[i] = v[k];
         }
     }
     STAMP(1);
@@ -780,6 +782,7 @@ __device__ __forceinline__ void obs_tile(const Params &P, int E, uint32_t cpe, u
             t.y ^= (d1 - 4u < 4u ? v1 : 0u) ^ (d2 - 4u < 4u ? v2 : 0u);
             t.z ^= (d1 - 8u < 4u ? v1 : 0u) ^ (d2 - 8u < 4u ? v2 : 0u);
             t.w ^= (d1 - 12u < 4u ? v1 : 0u) ^ (d2 - 12u < 4u ? v2 : 0u);
+            if (keep_tile) tile[i] = t;
         }
         const uint32_t w1[4] = {t.x, t.y, t.z, t.w};
         const uint32_t w2[4] = {swap_codes4(t.x), swap_codes4(t.y), swap_codes4(t.z), swap_codes4(t.w)};
@@ -819,9 +822,13 @@ __global__ __launch_bounds__(BLOCK) void k_obs_roll(Params P, int E, uint32_t cp
         lo.totals = acc;
         __syncthreads();
     }
+    // TRON_ROLLOUT_RESIDENT (one tile per workgroup): the board never leaves LDS between the steps of a launch — it is
+    // read from memory once, every step still writes both observation planes (which also are the state in memory)
+    const bool resident = (flags & TRON_ROLLOUT_RESIDENT) != 0u && (int)gridDim.x == ntiles;
+    flags &= ~TRON_ROLLOUT_RESIDENT;
     for (int s = 0; s < k_steps; ++s)
         for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
-            obs_tile<true>(P, E, cpe, cpe_magic, nullptr, flags, lo, t, smem);
+            obs_tile<true>(P, E, cpe, cpe_magic, nullptr, flags, lo, t, smem, resident && s > 0, resident);
             __syncthreads();        // the tile's LDS is reused; this step's state words are visible to the next
         }
     if (out.totals && threadIdx.x < 4 && acc[threadIdx.x]) atomicAdd(&out.totals[threadIdx.x], acc[threadIdx.x]);
@@ -1603,6 +1610,7 @@ int rollout_launches(tron_env *h, int32_t k_steps, uint32_t flags, int32_t obs_f
 {
     static const bool env_per_step = getenv("TRON_ROLL_PER_STEP") != nullptr;   // A/B switch: one launch per step
     const bool two_streams = (flags & TRON_ROLLOUT_TWO_STREAMS) != 0u;
+    if (!(h->P.obs_state && !(flags & (TRON_ROLLOUT_PER_STEP | TRON_ROLLOUT_TWO_STREAMS)))) flags &= ~TRON_ROLLOUT_RESIDENT;   // persistent obs-is-state launches only
     const bool per_step = env_per_step || two_streams || (flags & TRON_ROLLOUT_PER_STEP) != 0u;
     flags &= ~(TRON_ROLLOUT_PER_STEP | TRON_ROLLOUT_TWO_STREAMS);
     if (h->P.obs_state && !per_step && k_steps > 1) {
@@ -1612,6 +1620,7 @@ int rollout_launches(tron_env *h, int32_t k_steps, uint32_t flags, int32_t obs_f
         if (obs_fmt == TRON_OBS_PLANES3_F32 || obs_fmt == TRON_OBS_PLANES4_F32) return obs_planes(h, obs_fmt, obs, st);
         return TRON_OK;
     }
+    flags &= ~TRON_ROLLOUT_RESIDENT;                               // only k_obs_roll knows it
     if (!h->P.obs_state && !per_step && k_steps > 1) {             // board-owning layout: same idea, k_tile_roll
         for (int left = k_steps; left > 0; left -= TRON_ROLLOUT_CHUNK) {
             const int rc = launch_roll_fmt(h, obs_fmt, left < TRON_ROLLOUT_CHUNK ? left : TRON_ROLLOUT_CHUNK, flags, obs, out, st);
@@ -1670,7 +1679,8 @@ int tron_rollout_random(tron_handle h, int32_t k_steps, uint32_t flags, int32_t 
 {
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
     if (k_steps < 0 || (obs_fmt != TRON_OBS_NONE) != (obs != nullptr)) return TRON_ERR_BAD_ARG;
-    if (flags & ~(TRON_STEP_NONREVERSING | TRON_ROLLOUT_PER_STEP | TRON_ROLLOUT_TWO_STREAMS)) return TRON_ERR_BAD_ARG;   // autoreset is implied
+    if (flags & ~(TRON_STEP_NONREVERSING | TRON_ROLLOUT_PER_STEP | TRON_ROLLOUT_TWO_STREAMS | TRON_ROLLOUT_RESIDENT))
+        return TRON_ERR_BAD_ARG;   // autoreset is implied
     StepOut out{nullptr, nullptr, nullptr, totals};
     if (h->P.obs_state && obs_fmt == TRON_OBS_CODES_I8 && obs != h->P.obs_state) return TRON_ERR_BAD_ARG;
     return rollout_launches(h, k_steps, flags | TRON_STEP_AUTORESET, obs_fmt, obs, out, S_(stream));

@@ -20,6 +20,7 @@ STEP_INCREMENTAL = 2
 STEP_NONREVERSING = 4
 ROLLOUT_PER_STEP = 8
 ROLLOUT_TWO_STREAMS = 16
+ROLLOUT_RESIDENT = 32
 
 _vp, _i32, _i64, _u32, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_double
 

@@ -19,6 +19,17 @@ def pop_up(map):
     return pop_up_planes(codes[None])[0].cpu().numpy().astype(np.float64)
 
 
+def readme_encoding(codes):
+    """The observation as the reference's README.md:67 words it — "0 for empty space, -1 for a wall, 10 for the
+    player head and -10 for the enemy's head" — from Map.state_for_player's codes, whose only difference is EMPTY = 1
+    (map.py:68-69).  No reference code produces this variant, so it is pinned by nothing but that
+    sentence: bodies keep the code's -2 / -3.  Works on numpy arrays and torch tensors."""
+    if torch.is_tensor(codes):
+        return torch.where(codes == 1, torch.zeros_like(codes), codes)
+    codes = np.asarray(codes)
+    return np.where(codes == 1, 0, codes).astype(codes.dtype)
+
+
 def prob_map(x, width=None, height=None):         # util.py:38-45; size defaults to config like the reference
     import config
     return np.full(((width or config.MAP_WIDTH) + 2, (height or config.MAP_HEIGHT) + 2), float(x))

@@ -63,6 +63,11 @@ enum {
 
 #define TRON_ROLLOUT_CHUNK 64     /* steps per persistent rollout launch (tron_rollout_random) */
 #define TRON_ROLLOUT_PER_STEP 8u  /* tron_rollout_random flag: one launch per step instead (for A/B measurements) */
+#define TRON_ROLLOUT_RESIDENT 32u  /* tron_rollout_random flag, attached observation buffer only: within a persistent launch
+                                    * the boards stay in LDS from step to step instead of being read back from the
+                                    * observation buffer each step — same results; HBM traffic per env-step drops from
+                                    * 3G + 32 to 2G + 32 bytes (the two observation planes are still written every step).
+                                    * Ignored (plain behaviour) where it does not apply.                              */
 #define TRON_ROLLOUT_TWO_STREAMS 16u /* tron_rollout_random flag: one launch per step and per HALF of the envs, the two
                                       * halves on two streams (the handle owns the second one), so one half's launch
                                       * drains while the other's ramps up — the launch pattern of a caller that pipelines

@@ -324,8 +324,9 @@ def test_step_without_obs_and_totals(T):
     _compare_state(env, ref, "rollout")
 
 
-@pytest.mark.parametrize("N,W,K", [(300, 10, 37), (5000, 24, 70), (33, 2, 9)])
-def test_persistent_rollout_equals_stepwise(T, N, W, K):
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("N,W,K", [(300, 10, 37), (5000, 24, 70), (33, 2, 9), (70, 16, 130)])
+def test_persistent_rollout_equals_stepwise(T, N, W, K, resident):
     """tron_rollout_random on the observation-is-state path is ONE launch in which every workgroup steps
     its own tiles K times (k_obs_roll): same state, observations and totals as K oracle steps."""
     tv, oracle = T
@@ -335,7 +336,7 @@ def test_persistent_rollout_equals_stepwise(T, N, W, K):
     env.reset()
     ref.reset_all()
     totals = torch.zeros(4, dtype=torch.int64, device="cuda")
-    env.rollout_random(K, totals)
+    env.rollout_random(K, totals, resident=resident)
     exp = np.zeros(4, np.int64)
     for _ in range(K):
         o, d, w, _ = ref.step(autoreset=True)

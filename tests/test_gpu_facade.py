@@ -255,6 +255,18 @@ def test_batched_rating_sweep():
         assert r["p1_win"] + r["p2_win"] + r["draw"] == 300 and r["p1_rate"] < 0.2
 
 
+def test_readme_encoding_variant():
+    """README.md:67's wording of the observation (EMPTY 0 instead of the code's 1); un-oracled, see the docstring."""
+    from tron.util import make_game, readme_encoding
+    game = make_game(True, True)
+    codes = game.map().state_for_player(1)
+    r = readme_encoding(codes)
+    assert set(np.unique(r).tolist()) <= {0, -1, 10, -10, -2, -3} and (r == 0).sum() == (codes == 1).sum()
+    assert (r == 10).sum() == 1 and (r == -10).sum() == 1 and np.array_equal(r != 0, codes != 1)
+    t = torch.as_tensor(codes).cuda()
+    assert np.array_equal(readme_encoding(t).cpu().numpy(), r)
+
+
 def test_rating_with_the_reference_player_pair():
     """play.py:53-61's seating — a MapNet as player 1 (planes + prob_map plane), a TestNet as player 2 (planes +
     [get_rate()]) — through the batched rating loop, both loaded by play.load_player."""

@@ -43,7 +43,10 @@ def np_(t):
     (16384, 32, "temper", 66),    # BASELINE config 5's env shape
     (65536, 24, "ice", 33),
 ])
-def test_persistent_rollout_at_benchmarked_size(T, N, W, mode, K):
+@pytest.mark.parametrize("resident", [False, True])
+def test_persistent_rollout_at_benchmarked_size(T, N, W, mode, K, resident):
+    """resident=True: TRON_ROLLOUT_RESIDENT, the boards stay in LDS between the steps of a launch (mode None only;
+    the flag is ignored elsewhere)."""
     tv, oracle = T
     env = tv.VecTron(N, W, mode=mode, seed=0x5EED, rank=3, obs_format="codes")
     assert env.obs_is_state == (mode is None)
@@ -51,7 +54,7 @@ def test_persistent_rollout_at_benchmarked_size(T, N, W, mode, K):
     env.reset()
     ref.reset_all()
     totals = torch.zeros(4, dtype=torch.int64, device="cuda")
-    env.rollout_random(K, totals)
+    env.rollout_random(K, totals, resident=resident)
     exp = np.zeros(4, np.int64)
     o = None
     for k in range(K):
