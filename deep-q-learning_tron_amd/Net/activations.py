@@ -44,6 +44,52 @@ def mish(x):
     return F.mish(x)
 
 
+def bias_mish_bwd(pre, g):
+    """(grad_pre, grad_bias) for out = mish(pre), pre = y + bias[c] (+ residual): one pass of csrc/tron_nn.hip."""
+    from tron import _native as nat
+    N, C, H, W = pre.shape
+    gp = torch.empty_like(pre)
+    gb = torch.empty(C, dtype=torch.float32, device=pre.device)
+    scratch = torch.empty(C * 64, dtype=torch.float32, device=pre.device)
+    with torch.cuda.device(pre.device):
+        nat.check(nat.lib().tron_bias_mish_bwd(nat.ptr(pre), nat.ptr(g), nat.ptr(gp), nat.ptr(gb), nat.ptr(scratch), N, C,
+                                               H * W, nat.stream_ptr()), "tron_bias_mish_bwd")
+    return gp, gb
+
+
+class _ConvBiasMishHIP(torch.autograd.Function):
+    """mish(conv3x3(x) + bias (+ residual)) with the forward AND the input gradient on csrc/tron_conv.hip (the data
+    gradient of a stride-1, pad-1 3x3 convolution is the same convolution with the weight's channel axes swapped and
+    its taps flipped), activation + bias gradient in one pass of csrc/tron_nn.hip; only the weight gradient stays on
+    MIOpen (aten.convolution_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        from Net import fused
+        out, pre = fused.conv3x3_raw(x, weight, bias, residual, act=True, want_pre=True)
+        ctx.save_for_backward(x, weight, pre)
+        ctx.has_res = residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from Net import fused
+        x, weight, pre = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if not _aligned16(g):
+            g = g.clone(memory_format=torch.contiguous_format)
+        gp, gb = bias_mish_bwd(pre, g)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()       # [cin][cout][3][3], taps reversed
+            gx = fused.conv3x3_raw(gp, wt, None, None, act=False)
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gp, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return gx, gw, (gb if ctx.needs_input_grad[2] else None), (gp if ctx.has_res else None)
+
+
 class _BiasMish(torch.autograd.Function):
     """mish(y + bias[c] (+ residual)) for a bias-free convolution output y [N, C, H, W]."""
 
@@ -68,17 +114,18 @@ class _BiasMish(torch.autograd.Function):
         g = grad_out.contiguous()
         if not _aligned16(g):
             g = g.clone(memory_format=torch.contiguous_format)
-        gp = torch.empty_like(pre)
-        with torch.cuda.device(pre.device):
-            nat.check(nat.lib().tron_mish_bwd(nat.ptr(pre), nat.ptr(g), nat.ptr(gp), pre.numel(), nat.stream_ptr()),
-                      "tron_mish_bwd")
-        return gp, gp.sum((0, 2, 3)), (gp if ctx.has_res else None)
+        gp, gb = bias_mish_bwd(pre, g)
+        return gp, gb, (gp if ctx.has_res else None)
 
 
 def conv_bias_mish(conv, x, residual=None):
     """mish(conv(x) + residual) with the bias add, the residual add and the activation fused behind the
     (bias-free) MIOpen convolution when the tensors allow it; otherwise the plain composition."""
     if (x.is_cuda and x.dtype == torch.float32 and conv.bias is not None and isinstance(conv, torch.nn.Conv2d)):
+        from Net import fused
+        if (fused.supported(conv, x.shape[-1]) and x.shape[-2] == x.shape[-1] and _aligned16(x, residual)
+                and (conv.in_channels in (3, 4) or (conv.in_channels % 8 == 0 and conv.in_channels in (32, 64)))):
+            return _ConvBiasMishHIP.apply(x, conv.weight, conv.bias, residual)
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if (y.shape[2] * y.shape[3]) % 4 == 0 and y.numel() < 2 ** 32 and _aligned16(y, residual):
             return _BiasMish.apply(y, conv.bias, residual)

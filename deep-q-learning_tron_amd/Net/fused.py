@@ -21,11 +21,12 @@ def supported(conv, side):
             and conv.weight.dtype == torch.float32)
 
 
-def conv3x3(x, conv, residual=None, act=True, codes=False, plane4=0.0, want_pre=False):
-    """act(conv(x) + bias + residual).  x: f32 [B, Cin, S, S] — or, with codes=True, int8 observation codes
-    [B, S, S] that stand for conv.in_channels pop_up planes.  Returns out (and the pre-activation when want_pre)."""
+def conv3x3_raw(x, weight, bias=None, residual=None, act=True, codes=False, plane4=0.0, want_pre=False):
+    """act(conv3x3(x, weight, padding=1) + bias + residual) on tensors: weight f32 [Cout, Cin, 3, 3] as nn.Conv2d keeps
+    it, x f32 [B, Cin, S, S] — or, with codes=True, int8 observation codes [B, S, S] standing for Cin pop_up planes.
+    Returns out (and the pre-activation when want_pre)."""
     B, S = x.shape[0], x.shape[-1]
-    cin, cout = conv.in_channels, conv.out_channels
+    cout, cin = weight.shape[0], weight.shape[1]
     x = x.contiguous()
     if codes:
         if x.dtype != torch.int8:
@@ -35,15 +36,20 @@ def conv3x3(x, conv, residual=None, act=True, codes=False, plane4=0.0, want_pre=
     out = torch.empty(B, cout, S, S, dtype=torch.float32, device=x.device)
     pre = torch.empty_like(out) if want_pre else None
     res = None if residual is None else residual.contiguous()
-    bias = None if conv.bias is None else conv.bias.detach()
-    w = conv.weight.detach()
+    b = None if bias is None else bias.detach()
+    w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
     with torch.cuda.device(x.device):
-        nat.check(nat.lib().tron_conv3x3_fwd(nat.ptr(x), int(codes), nat.ptr(w), nat.ptr(bias), nat.ptr(res),
+        nat.check(nat.lib().tron_conv3x3_fwd(nat.ptr(x), int(codes), nat.ptr(w), nat.ptr(b), nat.ptr(res),
                                              nat.ptr(out), nat.ptr(pre), B, cin, cout, S, float(plane4), int(act),
                                              nat.stream_ptr()), "tron_conv3x3_fwd")
     return (out, pre) if want_pre else out
+
+
+def conv3x3(x, conv, residual=None, act=True, codes=False, plane4=0.0, want_pre=False):
+    """conv3x3_raw on an nn.Conv2d module."""
+    return conv3x3_raw(x, conv.weight, conv.bias, residual, act, codes, plane4, want_pre)
 
 
 def trunk(net, x, codes=False, plane4=0.0):

@@ -52,6 +52,7 @@ SIGNATURES = {
     "tron_mish_fwd": (C.c_int, [_vp, _vp, _i64, _vp]),
     "tron_mish_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "tron_bias_mish_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "tron_bias_mish_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "tron_replay_create": (C.c_int, [_i64, _i32, _u32, _u32, C.POINTER(_vp)]),
     "tron_replay_destroy": (C.c_int, [_vp]),
     "tron_replay_push": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),

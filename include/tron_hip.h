@@ -251,6 +251,11 @@ int tron_mish_bwd(const float *x, const float *grad_y, float *grad_x, int64_t n,
 int tron_bias_mish_fwd(float *y_pre, const float *bias, const float *residual, float *out, int64_t batch,
                        int32_t channels, int32_t hw, void *stream);
 
+/* Backward of that pass: grad_pre = grad_out * mish'(y_pre) and bias_grad[c] = sum over batch and positions of
+ * grad_pre — one launch plus a tiny fixed-order finish (deterministic).  scratch: f32[channels * 64], caller-owned. */
+int tron_bias_mish_bwd(const float *y_pre, const float *grad_out, float *grad_pre, float *bias_grad, float *scratch,
+                       int64_t batch, int32_t channels, int32_t hw, void *stream);
+
 /* ---- the CNN's 3x3 convolutions on the fp32 matrix cores (Net/DQNNet.py:10-17,33-50 conv1..conv6; the same
  * stacks in Net/ACNet.py) ------------------------------------------------------------------------------ */
 /* out[b][co][y][x] = act(bias[co] + residual[b][co][y][x] + sum_{ci,ky,kx} W[co][ci][ky][kx] *

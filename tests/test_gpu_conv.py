@@ -122,3 +122,37 @@ def test_infer_equals_module_forward_and_codes_path(fused, W, B, cin):
     q_c = net.infer(codes, codes=True, plane4=5.0)
     assert (q_p.double() - ref).abs().max().item() < TOL
     assert torch.equal(q_p, q_c)
+
+
+@pytest.mark.parametrize("S,B,cin,cout,with_res", [(12, 33, 32, 32, True), (12, 64, 32, 64, False), (12, 20, 64, 64, True),
+                                                   (26, 9, 32, 32, True), (12, 40, 3, 32, False), (12, 40, 4, 32, False)])
+def test_training_conv_gradients_match_float64(fused, S, B, cin, cout, with_res):
+    """The differentiable path (Net/activations.py::_ConvBiasMishHIP): forward on tron_conv3x3_fwd, input gradient on
+    the same kernel with the transposed, tap-flipped weight, activation + bias gradient in tron_bias_mish_bwd, weight
+    gradient on MIOpen — against autograd through the float64 composition mish(conv2d(x) + residual)."""
+    from Net.activations import conv_bias_mish
+    torch.manual_seed(S + B + cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
+    x = torch.randn(B, cin, S, S, device="cuda", requires_grad=cin >= 8)
+    res = torch.randn(B, cout, S, S, device="cuda", requires_grad=True) if with_res else None
+    gout = torch.randn(B, cout, S, S, device="cuda")
+    out = conv_bias_mish(conv, x, res)
+    assert type(out.grad_fn).__name__ == "_ConvBiasMishHIPBackward"
+    out.backward(gout)
+    xd = x.detach().double().requires_grad_(cin >= 8)
+    rd = res.detach().double().requires_grad_(True) if with_res else None
+    wd, bd = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    y = F.conv2d(xd, wd, bd, padding=1)
+    ref = F.mish(y + rd if with_res else y)
+    ref.backward(gout.double())
+    assert (out.double() - ref).abs().max().item() < TOL
+
+    def close(a, b, what):
+        scale = max(1.0, b.abs().max().item())
+        assert (a.double() - b).abs().max().item() < 2e-5 * scale, (what, (a.double() - b).abs().max().item(), scale)
+    close(conv.weight.grad, wd.grad, "weight")
+    close(conv.bias.grad, bd.grad, "bias")
+    if cin >= 8:
+        close(x.grad, xd.grad, "input")
+    if with_res:
+        close(res.grad, rd.grad, "residual")
