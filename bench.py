@@ -51,12 +51,13 @@ def alg_bytes_per_env_step(width):
     return 3 * g + 32
 
 
-def pmc_traffic(envs, width, obs, mode, kernel_tag, steps_per_launch):
+def pmc_traffic(envs, width, obs, mode, kernel_tag, steps_per_launch, variant="larger-fetch"):
     """HBM bytes per STEP of the step kernel from the committed rocprofv3 PMC passes
-    (profiles/r*_summary.json, made by scripts/pmc_summary.py: FETCH_SIZE x2 per the gfx950
+    (profiles/r*_summary*.json, made by scripts/pmc_summary.py: FETCH_SIZE x2 per the gfx950
     correction + WRITE_SIZE, KiB -> bytes).  Only returned for the exact workload AND steps-per-launch
     the passes were taken on: a persistent launch of a different length has a different L2 / Infinity
-    Cache carry-over between its steps."""
+    Cache carry-over between its steps.  The profiled program launches the rollout kernel in two variants
+    (boards re-read each step / resident in LDS); pmc_summary.py splits them by fetch volume."""
     import glob
     if (envs, width, obs, mode) != (N_ENVS, WIDTH, "codes", "none"):
         return None, None
@@ -64,9 +65,11 @@ def pmc_traffic(envs, width, obs, mode, kernel_tag, steps_per_launch):
         summ = json.load(open(path))
         if int(summ.get("steps_per_launch", 1)) != int(steps_per_launch):
             continue
-        for name, k in summ["kernels"].items():
-            if kernel_tag in name:
-                return k["hbm_bytes_per_launch"] / summ.get("steps_per_launch", 1), os.path.relpath(path, ROOT)
+        names = [n for n in summ["kernels"] if kernel_tag in n]
+        pick = [n for n in names if variant in n] or [n for n in names if "[" not in n]
+        if pick:
+            k = summ["kernels"][pick[0]]
+            return k["hbm_bytes_per_launch"] / summ.get("steps_per_launch", 1), os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -446,6 +449,8 @@ def main():
                              "achieved": rs_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rs_ach / HBM_PEAK_GBS,
                              "achievable_peak": 6100.0, "frac_of_achievable": rs_ach / 6100.0,
                              "achievable_note": "the guide's plain-store rate 6.0-6.2 TB/s",
+                             "traffic_bytes_per_step": pmc_traffic(args.envs, args.width, args.obs, args.mode, "k_obs_roll",
+                                                                   min(args.steps, chunk), "smaller-fetch")[0],
                              "kernel": "k_obs_roll with TRON_ROLLOUT_RESIDENT"}}
         if dqn is not None:
             out["dqn"] = dqn
