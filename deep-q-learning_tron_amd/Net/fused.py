@@ -11,6 +11,11 @@ import torch
 
 from tron import _native as nat
 
+MATH = {"f32": nat.CONV_F32, "f16x3": nat.CONV_F16X3}
+# arithmetic of the convolutions (include/tron_hip.h): "f16x3" = split-f16 matrix cores (12x12 boards; others fall back
+# to the f32 kernel inside the library), "f32" = the exact f32 MFMA.  TRON_CONV_MATH overrides.
+import os as _os
+default_math = _os.environ.get("TRON_CONV_MATH", "f16x3")
 _SIDES = (12, 26)            # boards 10x10 and 24x24 (BASELINE configs 2 / 3); tron_conv3x3_fwd's instantiations
 
 
@@ -21,7 +26,7 @@ def supported(conv, side):
             and conv.weight.dtype == torch.float32)
 
 
-def conv3x3_raw(x, weight, bias=None, residual=None, act=True, codes=False, plane4=0.0, want_pre=False):
+def conv3x3_raw(x, weight, bias=None, residual=None, act=True, codes=False, plane4=0.0, want_pre=False, math=None):
     """act(conv3x3(x, weight, padding=1) + bias + residual) on tensors: weight f32 [Cout, Cin, 3, 3] as nn.Conv2d keeps
     it, x f32 [B, Cin, S, S] — or, with codes=True, int8 observation codes [B, S, S] standing for Cin pop_up planes.
     Returns out (and the pre-activation when want_pre)."""
@@ -43,13 +48,13 @@ def conv3x3_raw(x, weight, bias=None, residual=None, act=True, codes=False, plan
     with torch.cuda.device(x.device):
         nat.check(nat.lib().tron_conv3x3_fwd(nat.ptr(x), int(codes), nat.ptr(w), nat.ptr(b), nat.ptr(res),
                                              nat.ptr(out), nat.ptr(pre), B, cin, cout, S, float(plane4), int(act),
-                                             nat.stream_ptr()), "tron_conv3x3_fwd")
+                                             MATH[math or default_math], nat.stream_ptr()), "tron_conv3x3_fwd")
     return (out, pre) if want_pre else out
 
 
-def conv3x3(x, conv, residual=None, act=True, codes=False, plane4=0.0, want_pre=False):
+def conv3x3(x, conv, residual=None, act=True, codes=False, plane4=0.0, want_pre=False, math=None):
     """conv3x3_raw on an nn.Conv2d module."""
-    return conv3x3_raw(x, conv.weight, conv.bias, residual, act, codes, plane4, want_pre)
+    return conv3x3_raw(x, conv.weight, conv.bias, residual, act, codes, plane4, want_pre, math)
 
 
 def trunk(net, x, codes=False, plane4=0.0):

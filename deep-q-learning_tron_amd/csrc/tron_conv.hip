@@ -27,6 +27,7 @@
 #include <stdint.h>
 
 #include "../../include/tron_hip.h"
+#include "tron_conv.hpp"
 
 namespace {
 
@@ -430,7 +431,7 @@ int launch_conv(const void *in, const float *wgt, const float *bias, const float
 
 extern "C" int tron_conv3x3_fwd(const void *in, int32_t in_is_codes, const float *weight, const float *bias,
                                 const float *residual, float *out, float *pre_out, int64_t batch, int32_t cin,
-                                int32_t cout, int32_t side, float plane4, int32_t apply_mish, void *stream)
+                                int32_t cout, int32_t side, float plane4, int32_t apply_mish, int32_t math, void *stream)
 {
     if (!in || !weight || !out || batch < 0 || cin < 1) return TRON_ERR_BAD_ARG;
     if (batch == 0) return TRON_OK;
@@ -442,7 +443,13 @@ extern "C" int tron_conv3x3_fwd(const void *in, int32_t in_is_codes, const float
     if (in_is_codes && !small) return TRON_ERR_BAD_ARG;
     if (small ? cout != 32 : (cin % CIC != 0)) return TRON_ERR_UNSUPPORTED;
     if (batch > (1ll << 24)) return TRON_ERR_UNSUPPORTED;
+    if (math != TRON_CONV_F32 && math != TRON_CONV_F16X3) return TRON_ERR_BAD_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (math == TRON_CONV_F16X3) {      // shapes the split kernel has no instantiation for take the f32 kernel
+        const int rc = tron_conv3x3_f16x3(in, in_is_codes, weight, bias, residual, out, pre_out, batch, cin, cout, side,
+                                          plane4, apply_mish, st);
+        if (rc != TRON_ERR_UNSUPPORTED) return rc;
+    }
 #define TRON_CONV_CASE(S_)                                                                                                \
     if (side == S_)                                                                                                        \
         return small ? launch_conv<S_, true>(in, weight, bias, residual, out, pre_out, batch, cin, cout, plane4,          \

@@ -1,0 +1,9 @@
+// Internal: the two implementations behind tron_conv3x3_fwd (include/tron_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// tron_conv_f16.hip: split-f16 matrix-core path; TRON_ERR_UNSUPPORTED when it has no instantiation for the shape.
+int tron_conv3x3_f16x3(const void *in, int in_is_codes, const float *weight, const float *bias, const float *residual,
+                       float *out, float *pre_out, int64_t batch, int cin, int cout, int side, float plane4,
+                       int apply_mish, hipStream_t st);
