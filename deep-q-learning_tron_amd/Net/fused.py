@@ -45,10 +45,14 @@ def conv3x3_raw(x, weight, bias=None, residual=None, act=True, codes=False, plan
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
+    m = MATH[math or default_math]
+    ws = None
+    if m == nat.CONV_F16X3:        # scratch for the split weights, rewritten by every call
+        ws = torch.empty(int(nat.lib().tron_conv3x3_workspace(cin, cout)), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         nat.check(nat.lib().tron_conv3x3_fwd(nat.ptr(x), int(codes), nat.ptr(w), nat.ptr(b), nat.ptr(res),
                                              nat.ptr(out), nat.ptr(pre), B, cin, cout, S, float(plane4), int(act),
-                                             MATH[math or default_math], nat.stream_ptr()), "tron_conv3x3_fwd")
+                                             m, nat.ptr(ws), nat.stream_ptr()), "tron_conv3x3_fwd")
     return (out, pre) if want_pre else out
 
 

@@ -431,7 +431,8 @@ int launch_conv(const void *in, const float *wgt, const float *bias, const float
 
 extern "C" int tron_conv3x3_fwd(const void *in, int32_t in_is_codes, const float *weight, const float *bias,
                                 const float *residual, float *out, float *pre_out, int64_t batch, int32_t cin,
-                                int32_t cout, int32_t side, float plane4, int32_t apply_mish, int32_t math, void *stream)
+                                int32_t cout, int32_t side, float plane4, int32_t apply_mish, int32_t math, void *workspace,
+                                void *stream)
 {
     if (!in || !weight || !out || batch < 0 || cin < 1) return TRON_ERR_BAD_ARG;
     if (batch == 0) return TRON_OK;
@@ -446,8 +447,9 @@ extern "C" int tron_conv3x3_fwd(const void *in, int32_t in_is_codes, const float
     if (math != TRON_CONV_F32 && math != TRON_CONV_F16X3) return TRON_ERR_BAD_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (math == TRON_CONV_F16X3) {      // shapes the split kernel has no instantiation for take the f32 kernel
+        if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15u)) return TRON_ERR_BAD_ARG;
         const int rc = tron_conv3x3_f16x3(in, in_is_codes, weight, bias, residual, out, pre_out, batch, cin, cout, side,
-                                          plane4, apply_mish, st);
+                                          plane4, apply_mish, workspace, st);
         if (rc != TRON_ERR_UNSUPPORTED) return rc;
     }
 #define TRON_CONV_CASE(S_)                                                                                                \
@@ -461,3 +463,5 @@ extern "C" int tron_conv3x3_fwd(const void *in, int32_t in_is_codes, const float
 #undef TRON_CONV_CASE
     return TRON_ERR_UNSUPPORTED;
 }
+
+extern "C" int64_t tron_conv3x3_workspace(int32_t cin, int32_t cout) { return tron_conv3x3_f16x3_workspace(cin, cout); }

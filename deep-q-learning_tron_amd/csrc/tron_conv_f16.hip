@@ -7,38 +7,48 @@
 // to within 2^-22 |v|, and a product of two f16 values is exact in f32, so
 //     a * b  =  ah*bh  +  (ah*bl + al*bh) * 2^-11                      (+ al*bl * 2^-22, dropped: 2^-22 relative)
 // is three v_mfma_f32_16x16x32_f16 (32 k-values in 16 cycles each) where the f32 path needs eight 16x16x4 MFMAs of
-// 32 cycles: 5.3x less matrix-pipe time, f32 accumulation throughout, error per product 2^-22 against f32's 2^-24.
+// 32 cycles: 5.3x less matrix-pipe time, f32 accumulation throughout; measured error against float64 is BELOW the
+// f32 MFMA kernel's (the hi*hi products are exact and a 32-deep slab is summed in one instruction).
 // Activations are scaled by 2^-6 before the split (|x| up to 4e6 stays inside f16; tiny values lose nothing
 // because lo picks up what hi's subnormal rounding drops); the scale is undone, exactly, in the epilogue.
 //
 // Mapping (GEMM view: M = pixels, N = output channels, K = taps x input channels).
-//   * A workgroup owns P whole images (4 at 12x12) and 32 or 64 output channels: 4 waves along M (one image each
-//     at 12x12), 1 or 2 along N; a wave holds MT x 2 tiles of 16 px x 16 channels, two f32 accumulators each.
-//   * K is walked in chunks of 16 input channels x all 9 taps (padded to 10: the tenth tap has zero weights), five
+//   * A workgroup of 8 waves owns P whole images (2 at 12x12: 288 pixels = 18 M tiles) and ALL output channels (32
+//     or 64): 4 waves along M x 2 along N; a wave holds up to MT x NT tiles of 16 px x 16 channels, two f32
+//     accumulators each (hi*hi and the cross terms).  The 18 tiles are dealt 5/5/4/4 and the two N halves take the
+//     M slots in opposite order, so the two waves of a SIMD (waves w and w + 4) always carry 9 tiles together.
+//   * K is walked in chunks of 16 input channels x 9 taps (padded to 10: the tenth tap has zero weights), five
 //     32-deep slabs per chunk: lane group g of an MFMA covers (tap 2s + g/2, channel octet g%2).  LDS holds the
 //     chunk's input planes channel-innermost with their zero halo, [pixel][16 ci] f16 twice (hi, lo), and the
 //     weights as [tap][cout][16 ci] f16 twice, so every operand fragment — 8 consecutive k of one row — is ONE
-//     ds_read_b128.  Rows are 48 bytes (32 + 16 pad) to spread the banks.
-//   * The next chunk's global loads are issued before the slabs and converted / written to LDS after them
-//     (registers double-buffer, LDS is single-buffered: 137 KB per workgroup with 64 channels).
+//     ds_read_b128; 32-byte rows keep a tile's 16 rows on 16 different bank quads.
+//   * Weights are split ONCE per call by a small kernel into exactly that LDS image (`workspace`), so staging them
+//     is a linear 16-byte copy.  Activations are split while they are staged.  Both are double-buffered in LDS
+//     (129 KB with 64 channels): the next chunk is loaded from memory at the start of a chunk and written to the
+//     other buffers one piece per tile-step, in the shadow of the chunk's MFMAs; one barrier per chunk.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/tron_hip.h"
 #include "tron_conv.hpp"
 
+#ifndef TRON_F16_ABLATE      // diagnostic builds only: 1 = no staging of the next chunk, 2 = A fragments not re-read (wrong results)
+#define TRON_F16_ABLATE 0
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CIC = 16;           // input channels per K chunk
 constexpr int TAPS_PAD = 10;      // 9 taps + one with zero weights: 5 slabs of 2 taps x 16 channels
 constexpr int SLABS = 5;
-constexpr int PITCH = 48;         // bytes per LDS row: 16 f16 + 16 bytes of padding
-constexpr int NWM = 4;            // waves along M
-constexpr int NT = 2;             // 16-channel N tiles per wave
+constexpr int PITCH = 32;         // bytes per LDS row: 16 f16
+constexpr int NWM = 4, NWN = 2;   // waves along M and N
+constexpr int THREADS = 64 * NWM * NWN;
 constexpr float ACT_SCALE = 1.0f / 64.0f, ACT_UNSCALE = 64.0f, LO_SCALE = 2048.0f, LO_UNSCALE = 1.0f / 2048.0f;
 
 template <int S_>
@@ -47,13 +57,17 @@ struct Cfg {
     static constexpr int SP = S + 2;
     static constexpr int PLANE = SP * SP;
     static constexpr int SS = S * S;
-    static constexpr int P = (S * S <= 144) ? (576 / (S * S)) : 1;
+    static constexpr int P = (S * S <= 144) ? (288 / (S * S)) : 1;     // images per workgroup
     static constexpr int PX = P * SS;
-    static constexpr int PW = ((PX + NWM - 1) / NWM + 3) & ~3;         // pixels per M wave, multiple of 4
-    static constexpr int MT = (PW + 15) / 16;
-    static constexpr int IN_BYTES = P * PLANE * PITCH;                  // one half (hi or lo) of the input tile
-    static_assert(S % 2 == 0, "even sides only");
-    static_assert(MT <= 9, "accumulators: MT x NT x 2 x 4 registers must leave room for two waves per SIMD");
+    static constexpr int TILES = (PX + 15) / 16;                        // 16-pixel M tiles per workgroup
+    static constexpr int MT = (TILES + NWM - 1) / NWM;                  // most tiles a wave gets
+    static constexpr int MT_MIN = TILES / NWM;                          // ... and fewest: staging rides on these steps
+    static constexpr int IN_HALF = P * PLANE * PITCH;                   // hi (or lo) image of one input chunk
+    static constexpr int IN_ITEMS = PX * (CIC / 4);                     // (pixel, channel quad) items of an input chunk
+    static constexpr int IN_LD = (IN_ITEMS + THREADS - 1) / THREADS;
+    static_assert(SS % 4 == 0, "a float4 of pixels must not cross an image (epilogue)");
+    static_assert(PX % 16 == 0, "whole M tiles only");
+    static_assert(MT <= 5, "accumulators: MT x NT x 2 x 4 registers");
 };
 
 __device__ __forceinline__ float mish1(float x)                         // as in tron_conv.hip
@@ -74,43 +88,73 @@ __device__ __forceinline__ void split(float v, f16 &hi, f16 &lo)
     lo = (f16)((v - (float)hi) * LO_SCALE);
 }
 
-// SMALL = the conv1 instantiation (cin 3 or 4, a single chunk whose absent channels stay zero); with in_codes its
-// input is the int8 observation codes, otherwise the f32 planes.  COUT_WG = 32 * NWN output channels per workgroup.
-template <int S, int NWN, bool SMALL>
-__global__ __launch_bounds__(64 * NWM * NWN, NWN == 2 ? 2 : 1) void k_conv3x3_f16(
-    const void *__restrict__ in, const float *__restrict__ wgt, const float *__restrict__ bias,
-    const float *__restrict__ res, float *__restrict__ out, float *__restrict__ pre_out, int B, int cin, int cout,
-    int groups, float plane4, int apply_mish, int in_codes)
+// W[cout][cin][3][3] f32 -> workspace f16 [chunk][half][tap 10][cout][16 ci]: per chunk exactly the LDS weight image
+// (hi image, then lo image; tenth tap and channels >= cin zero)
+__global__ void k_split_weights(const float *__restrict__ w, int cout, int cin, int nchunks, f16 *__restrict__ ws)
+{
+    const int per_half = TAPS_PAD * cout * CIC;
+    const int total = nchunks * per_half;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i / per_half, r = i - c * per_half;
+        const int tap = r / (cout * CIC), r2 = r - tap * (cout * CIC);
+        const int co = r2 / CIC, cl = r2 - co * CIC;
+        const int ci = c * CIC + cl;
+        const float v = (tap < 9 && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.0f;
+        f16 h, l;
+        split(v, h, l);
+        ws[(size_t)c * 2 * per_half + r] = h;
+        ws[(size_t)c * 2 * per_half + per_half + r] = l;
+    }
+}
+
+// SMALL = the conv1 instantiation (cin 3 or 4: one chunk whose absent channels are zero; input = int8 observation
+// codes when in_codes, else the f32 planes).  NT 16-channel tiles per wave: cout = 32 * NT.
+template <int S, int NT, bool SMALL>
+__global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
+    const void *__restrict__ in, const f16 *__restrict__ ws, const float *__restrict__ bias,
+    const float *__restrict__ res, float *__restrict__ out, float *__restrict__ pre_out, int B, int cin, float plane4,
+    int apply_mish, int in_codes)
 {
     using C = Cfg<S>;
-    constexpr int THREADS = 64 * NWM * NWN;
-    constexpr int COUT_WG = 32 * NWN;
-    constexpr int W_BYTES = TAPS_PAD * COUT_WG * PITCH;                 // one half of the weight tile
-    constexpr int IN_Q = C::P * CIC * C::SS / 4;                        // float4s of an input chunk [P][16][SS/4]
-    constexpr int W_Q = COUT_WG * CIC * 9 / 4;                          // float4s of a weight chunk [co][16 x 9]
-    constexpr int IN_LD = (IN_Q + THREADS - 1) / THREADS, W_LD = (W_Q + THREADS - 1) / THREADS;
+    constexpr int COUT = 32 * NT;
+    constexpr int W_HALF = TAPS_PAD * COUT * PITCH;                     // hi (or lo) image of one weight chunk
+    constexpr int IN_BUF = 2 * C::IN_HALF;
+    constexpr int W_Q = 2 * W_HALF / 16;                                // 16-byte pieces of a weight chunk
+    constexpr int W_LD = (W_Q + THREADS - 1) / THREADS;
+    constexpr int W_BUF = 2 * W_HALF;
+    constexpr int STEPS = SLABS * C::MT_MIN;                            // tile-steps every wave runs per chunk
+    // steps that store weight pieces / input float4s: late enough for the loads issued at the chunk's start to have landed
+    constexpr int STAGE_W0 = STEPS - C::IN_LD - W_LD - 2, STAGE_IN0 = STAGE_W0 + W_LD;
+    static_assert(STAGE_W0 >= 6, "give the global loads time");
+    static_assert(STAGE_IN0 + C::IN_LD <= STEPS, "one staged piece per tile-step");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char *in_h = lds, *in_l = lds + C::IN_BYTES, *w_h = lds + 2 * C::IN_BYTES, *w_l = w_h + W_BYTES;
+    // LDS: in[0] (hi|lo) | in[1] (hi|lo) | w[0] (hi|lo) | w[1] (hi|lo)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & (NWM - 1), wn = wave / NWM;
+    // waves w and w + 4 share a SIMD: the second N half walks the M slots backwards, so a SIMD gets 5 + 4 tiles
+    const int wn = wave / NWM, wm = wn ? NWM - 1 - (wave & (NWM - 1)) : (wave & (NWM - 1));
+    const int tile0 = wm * C::MT_MIN + (wm < C::TILES % NWM ? wm : C::TILES % NWM);   // first M tile of this wave
+    const int my_mt = C::MT_MIN + (wm < C::TILES % NWM ? 1 : 0);
     const int li = lane & 15, g = lane >> 4, tsel = g >> 1, oct = g & 1;
-    const int group = blockIdx.x % groups, chalf = blockIdx.x / groups;            // cout > COUT_WG: channel slices
-    const int co0 = chalf * COUT_WG;
-    const int img0 = group * C::P;
+    const int img0 = blockIdx.x * C::P;
     const int nchunks = SMALL ? 1 : cin / CIC;
     const int last_img = B - 1 - img0;
+    const int cout = COUT;
 
-    // zero all of LDS once: halo pixels, padding, absent channels and the tenth tap stay zero for good
-    for (int i = tid; i < (2 * C::IN_BYTES + 2 * W_BYTES) / 16; i += THREADS)
-        reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+#ifdef TRON_CONV_STAMPS     // diagnostic build only: pre_out is a stamp buffer u64[blocks][6], never an output
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(pre_out) + (size_t)blockIdx.x * 6;
+    pre_out = nullptr;
+    if (tid == 0) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    // zero both input buffers once: halo pixels (and, for SMALL, the absent channels) stay zero for good
+    for (int i = tid; i < 2 * IN_BUF / 16; i += THREADS) reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
 
     // per-lane operand bases (bytes)
     int a_base[C::MT];
 #pragma unroll
     for (int t = 0; t < C::MT; ++t) {
-        int px = wm * C::PW + 16 * t + li;
-        px = px < C::PX ? px : C::PX - 1;
+        int px = 16 * (tile0 + t) + li;
+        px = px < C::PX ? px : C::PX - 1;                               // a wave's surplus tile slot: valid address, unused
         const int img = px / C::SS, p = px - img * C::SS;
         const int y = p / S, x = p - y * S;
         a_base[t] = (img * C::PLANE + y * C::SP + x) * PITCH + oct * 16;
@@ -122,10 +166,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWN == 2 ? 2 : 1) void k_conv3x3_f1
         const int o0 = ((t0 / 3) * C::SP + (t0 % 3)) * PITCH, o1 = ((t1 / 3) * C::SP + (t1 % 3)) * PITCH;
         return tsel ? o1 : o0;
     };
-    const int b_base = (tsel * COUT_WG + wn * 32 + li) * PITCH + oct * 16;
+    const int b_base = (tsel * COUT + wn * 16 * NT + li) * PITCH + oct * 16;
 
-    const size_t wg_base = ((size_t)img0 * cout + co0) * C::SS;
-    const float *wgt_wg = wgt + (size_t)co0 * cin * 9;
+    const size_t wg_base = (size_t)img0 * cout * C::SS;
     const float *in_wg = (SMALL && in_codes) ? nullptr : reinterpret_cast<const float *>(in) + (size_t)img0 * cin * C::SS;
 
     f32x4 acc0[C::MT][NT], acc1[C::MT][NT];
@@ -137,202 +180,202 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWN == 2 ? 2 : 1) void k_conv3x3_f1
             acc1[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 
-    f32x4 rin[IN_LD], rw[W_LD];
-    uint32_t rcodes = 0x01010101u;
-    float rw1[5];
+    f32x4 rin[C::IN_LD];
+    uint4 rw[W_LD];
 
-#define TRON_LOAD_CHUNK(c_)                                                                                          \
-    do {                                                                                                              \
-        if (SMALL) {                                                                                                  \
-            if (in_codes) {                                                                                           \
-                const int w_ = tid < C::PX / 4 ? tid : C::PX / 4 - 1;                                                 \
-                const int im_ = (w_ * 4) / C::SS;                                                                     \
-                const int ims_ = im_ < last_img ? im_ : last_img;                                                     \
-                rcodes = reinterpret_cast<const uint32_t *>(in)[(size_t)(img0 + ims_) * (C::SS / 4) + (w_ - im_ * (C::SS / 4))]; \
-            } else {                                                                                                  \
-                _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                       \
-                    int q_ = tid + j * THREADS;                                                                       \
-                    q_ = q_ < C::P * cin * (C::SS / 4) ? q_ : C::P * cin * (C::SS / 4) - 1;                           \
-                    const int im_ = q_ / (cin * (C::SS / 4)), r_ = q_ - im_ * (cin * (C::SS / 4));                    \
-                    const int ims_ = im_ < last_img ? im_ : last_img;                                                 \
-                    rin[j < IN_LD ? j : 0] = *reinterpret_cast<const f32x4 *>(in_wg + (ims_ * cin * C::SS + r_ * 4)); \
-                }                                                                                                     \
-            }                                                                                                         \
-            _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                           \
-                int i_ = tid + j * THREADS;                                                                           \
-                i_ = i_ < COUT_WG * cin * 9 ? i_ : COUT_WG * cin * 9 - 1;                                             \
-                rw1[j] = wgt_wg[i_];                                                                                  \
-            }                                                                                                         \
-        } else {                                                                                                      \
-            int tidl_ = tid;                                                                                          \
-            asm volatile("" : "+v"(tidl_));                                                                           \
-            _Pragma("unroll") for (int j = 0; j < IN_LD; ++j) {                                                       \
-                int q_ = tidl_ + j * THREADS;                                                                         \
-                q_ = q_ < IN_Q ? q_ : IN_Q - 1;                                                                       \
-                const int im_ = q_ / (CIC * C::SS / 4), r_ = q_ - im_ * (CIC * C::SS / 4);                            \
-                const int ims_ = im_ < last_img ? im_ : last_img;                                                     \
-                rin[j] = *reinterpret_cast<const f32x4 *>(in_wg + ((ims_ * cin + (c_) * CIC) * C::SS + r_ * 4));      \
-            }                                                                                                         \
-            _Pragma("unroll") for (int j = 0; j < W_LD; ++j) {                                                        \
-                int q_ = tidl_ + j * THREADS;                                                                         \
-                q_ = q_ < W_Q ? q_ : W_Q - 1;                                                                         \
-                const int co_ = q_ / 36, j4_ = q_ - co_ * 36;                                                         \
-                rw[j] = *reinterpret_cast<const f32x4 *>(wgt_wg + ((co_ * cin + (c_) * CIC) * 9 + j4_ * 4));          \
-            }                                                                                                         \
-        }                                                                                                             \
-    } while (0)
-
-    // one activation -> its (hi, lo) halves at pixel `pix_` (padded index), channel `ci_` of the chunk
-#define TRON_PUT_IN(pix_, ci_, v_)                                                                                   \
+    // ---- staging pieces -------------------------------------------------------------------------------------
+    // one activation -> its (hi, lo) halves at pixel `pix_` (padded index), channel `ci_`, input buffer at `ib_`
+#define TRON_PUT_IN(ib_, pix_, ci_, v_)                                                                              \
     do {                                                                                                              \
         f16 h_, l_;                                                                                                   \
         split((v_) * ACT_SCALE, h_, l_);                                                                              \
-        *reinterpret_cast<f16 *>(in_h + (pix_) * PITCH + (ci_) * 2) = h_;                                             \
-        *reinterpret_cast<f16 *>(in_l + (pix_) * PITCH + (ci_) * 2) = l_;                                             \
+        *reinterpret_cast<f16 *>((ib_) + (pix_) * PITCH + (ci_) * 2) = h_;                                            \
+        *reinterpret_cast<f16 *>((ib_) + C::IN_HALF + (pix_) * PITCH + (ci_) * 2) = l_;                               \
     } while (0)
-#define TRON_PUT_W(tap_, co_, ci_, v_)                                                                               \
+    // Input staging.  An item = (pixel, channel quad): thread i takes items i, i + THREADS, ...; consecutive lanes hold
+    // consecutive quads of a pixel and then the next pixel, so a wave's 8-byte LDS writes are one contiguous 512-byte
+    // run (lane = pixel with the channel fixed would put every lane of a group on the same bank: rows are 32 bytes).
+    // The four values of an item are four dword loads from four channel planes (16 consecutive pixels per plane and
+    // instruction).  Unconditional: indices clamped, surplus dropped at the LDS write.
+#define TRON_LOAD_IN(c_)                                                                                             \
     do {                                                                                                              \
-        f16 h_, l_;                                                                                                   \
-        split((v_), h_, l_);                                                                                          \
-        *reinterpret_cast<f16 *>(w_h + ((tap_) * COUT_WG + (co_)) * PITCH + (ci_) * 2) = h_;                          \
-        *reinterpret_cast<f16 *>(w_l + ((tap_) * COUT_WG + (co_)) * PITCH + (ci_) * 2) = l_;                          \
+        int tidl_ = tid;                                                                                              \
+        asm volatile("" : "+v"(tidl_));                      /* keep the address math out of registers across chunks */ \
+        _Pragma("unroll") for (int j = 0; j < C::IN_LD; ++j) {                                                        \
+            int q_ = tidl_ + j * THREADS;                                                                             \
+            q_ = q_ < C::IN_ITEMS ? q_ : C::IN_ITEMS - 1;                                                             \
+            const int px_ = q_ >> 2, quad_ = q_ & 3;                                                                  \
+            const int im_ = px_ / C::SS, p_ = px_ - im_ * C::SS;                                                      \
+            const int ims_ = im_ < last_img ? im_ : last_img;                                                         \
+            const float *src_ = in_wg + ((ims_ * cin + (c_) * CIC + quad_ * 4) * C::SS + p_);                         \
+            rin[j] = (f32x4){src_[0], src_[C::SS], src_[2 * C::SS], src_[3 * C::SS]};                                 \
+        }                                                                                                             \
+    } while (0)
+    // staged item j_ -> input buffer ib_ (4 hi halves in one 8-byte write, 4 lo halves in another)
+#define TRON_STORE_IN(ib_, j_)                                                                                       \
+    do {                                                                                                              \
+        int tidv_ = tid;                                                                                              \
+        asm volatile("" : "+v"(tidv_));                                                                               \
+        const int q_ = tidv_ + (j_) * THREADS;                                                                        \
+        if (((j_) + 1) * THREADS <= C::IN_ITEMS || q_ < C::IN_ITEMS) {                                                \
+            const int px_ = q_ >> 2, quad_ = q_ & 3;                                                                  \
+            const int im_ = px_ / C::SS, p_ = px_ - im_ * C::SS;                                                      \
+            const int y_ = p_ / S, xx_ = p_ - y_ * S;                                                                 \
+            const int off_ = (im_ * C::PLANE + (y_ + 1) * C::SP + (xx_ + 1)) * PITCH + quad_ * 8;                     \
+            f16x4 h_, l_;                                                                                             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                           \
+                f16 hh_, ll_;                                                                                         \
+                split((im_ <= last_img ? rin[j_][e] : 0.0f) * ACT_SCALE, hh_, ll_);                                   \
+                h_[e] = hh_;                                                                                          \
+                l_[e] = ll_;                                                                                          \
+            }                                                                                                         \
+            *reinterpret_cast<f16x4 *>((ib_) + off_) = h_;                                                            \
+            *reinterpret_cast<f16x4 *>((ib_) + C::IN_HALF + off_) = l_;                                               \
+        }                                                                                                             \
+    } while (0)
+    // weight chunk c_: a linear copy of its pre-split image, piece j_
+#define TRON_LOAD_W(c_)                                                                                              \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < W_LD; ++j) {                                                            \
+            int q_ = tid + j * THREADS;                                                                               \
+            q_ = q_ < W_Q ? q_ : W_Q - 1;                                                                             \
+            rw[j] = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(ws) + (size_t)(c_) * W_BUF)[q_]; \
+        }                                                                                                             \
+    } while (0)
+#define TRON_STORE_W(wb_, j_)                                                                                        \
+    do {                                                                                                              \
+        const int q_ = tid + (j_) * THREADS;                                                                          \
+        if (((j_) + 1) * THREADS <= W_Q || q_ < W_Q) reinterpret_cast<uint4 *>(wb_)[q_] = rw[j_];                     \
     } while (0)
 
-#define TRON_STORE_CHUNK()                                                                                           \
+    // ---- one chunk: 5 slabs x up to MT tile-steps; STAGE_: also bring chunk c+1 into the other buffers ---------------
+#define TRON_CHUNK(STAGE_, c_)                                                                                       \
     do {                                                                                                              \
-        if (SMALL) {                                                                                                  \
-            if (in_codes) {                                                                                           \
-                if (tid < C::PX / 4) {                                                                                \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
-                        const int px_ = tid * 4 + e;                                                                  \
-                        const int im_ = px_ / C::SS, p_ = px_ - im_ * C::SS;                                          \
-                        const int y_ = p_ / S, xx_ = p_ - y_ * S;                                                     \
-                        const int v_ = im_ <= last_img ? (int)(int8_t)(rcodes >> (8 * e)) : 1;                        \
-                        const int pix_ = im_ * C::PLANE + (y_ + 1) * C::SP + (xx_ + 1);                               \
-                        TRON_PUT_IN(pix_, 0, (v_ == -1) ? 1.0f : 0.0f);                         /* util.py:18-19 */  \
-                        TRON_PUT_IN(pix_, 1, (v_ == -2) ? 1.0f : (v_ == 10) ? 10.0f : 0.0f);    /* util.py:20-21,26-27 */ \
-                        TRON_PUT_IN(pix_, 2, (v_ == -3) ? 1.0f : (v_ == -10) ? 10.0f : 0.0f);                         \
-                        if (cin == 4) TRON_PUT_IN(pix_, 3, plane4);                                                   \
-                    }                                                                                                 \
-                }                                                                                                     \
-            } else {                                                                                                  \
-                _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                       \
-                    const int q_ = tid + j * THREADS;                                                                 \
-                    if (q_ < C::P * cin * (C::SS / 4)) {                                                              \
-                        const int im_ = q_ / (cin * (C::SS / 4)), r_ = q_ - im_ * (cin * (C::SS / 4));                \
-                        const int ci_ = r_ / (C::SS / 4), p0_ = (r_ - ci_ * (C::SS / 4)) * 4;                         \
-                        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-                            const int p_ = p0_ + e;                                                                   \
-                            const int y_ = p_ / S, xx_ = p_ - y_ * S;                                                 \
-                            TRON_PUT_IN(im_ * C::PLANE + (y_ + 1) * C::SP + (xx_ + 1), ci_,                           \
-                                        im_ <= last_img ? rin[j < IN_LD ? j : 0][e] : 0.0f);                          \
-                        }                                                                                             \
-                    }                                                                                                 \
-                }                                                                                                     \
+        const unsigned char *in_h = lds + ((c_) & 1) * IN_BUF, *in_l = in_h + C::IN_HALF;                             \
+        const unsigned char *w_h = lds + 2 * IN_BUF + ((c_) & 1) * W_BUF, *w_l = w_h + W_HALF;                        \
+        unsigned char *nxt_in_ = lds + (((c_) + 1) & 1) * IN_BUF;                                                     \
+        unsigned char *nxt_w_ = lds + 2 * IN_BUF + (((c_) + 1) & 1) * W_BUF;                                          \
+        if (STAGE_ && TRON_F16_ABLATE != 1) {                                                                         \
+            TRON_LOAD_W((c_) + 1);                                                                                    \
+            TRON_LOAD_IN((c_) + 1);                                                                                   \
+        }                                                                                                             \
+        _Pragma("unroll") for (int s = 0; s < SLABS; ++s) {                                                           \
+            f16x8 bh[NT], bl[NT];                                                                                     \
+            _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                          \
+                const int bo = b_base + (2 * s * COUT + n * 16) * PITCH;                                              \
+                bh[n] = *reinterpret_cast<const f16x8 *>(w_h + bo);                                                   \
+                bl[n] = *reinterpret_cast<const f16x8 *>(w_l + bo);                                                   \
             }                                                                                                         \
-            _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                           \
-                const int i_ = tid + j * THREADS;                                                                     \
-                if (i_ < COUT_WG * cin * 9) {                                                                         \
-                    const int co_ = i_ / (cin * 9), k_ = i_ - co_ * (cin * 9);                                        \
-                    const int ci_ = k_ / 9, tap_ = k_ - ci_ * 9;                                                      \
-                    TRON_PUT_W(tap_, co_, ci_, rw1[j]);                                                               \
+            /* two-deep register pipeline over the M tiles: tile t+1's fragments are read while tile t's MFMAs issue */ \
+            f16x8 ah[2], al[2];                                                                                       \
+            const int toff = tap_offset(s);                                                                           \
+            ah[0] = *reinterpret_cast<const f16x8 *>(in_h + a_base[0] + toff);                                        \
+            al[0] = *reinterpret_cast<const f16x8 *>(in_l + a_base[0] + toff);                                        \
+            _Pragma("unroll") for (int t = 0; t < C::MT; ++t) {                                                       \
+                if (t + 1 < C::MT && TRON_F16_ABLATE != 2) {                                                          \
+                    ah[(t + 1) & 1] = *reinterpret_cast<const f16x8 *>(in_h + a_base[t + 1] + toff);                  \
+                    al[(t + 1) & 1] = *reinterpret_cast<const f16x8 *>(in_l + a_base[t + 1] + toff);                  \
+                } else if (t + 1 < C::MT) {                                                                           \
+                    ah[(t + 1) & 1] = ah[t & 1];                                                                      \
+                    al[(t + 1) & 1] = al[t & 1];                                                                      \
                 }                                                                                                     \
-            }                                                                                                         \
-        } else {                                                                                                      \
-            /* an opaque copy of tid: the ~40 LDS destinations are recomputed here each chunk; hoisted out of the  */ \
-            /* chunk loop they would sit in registers across the MFMAs, which have none to spare                  */ \
-            int tidv_ = tid;                                                                                          \
-            asm volatile("" : "+v"(tidv_));                                                                           \
-            _Pragma("unroll") for (int j = 0; j < IN_LD; ++j) {                                                       \
-                const int q_ = tidv_ + j * THREADS;                                                                   \
-                if (q_ < IN_Q) {                                                                                      \
-                    const int im_ = q_ / (CIC * C::SS / 4), r_ = q_ - im_ * (CIC * C::SS / 4);                        \
-                    const int ci_ = r_ / (C::SS / 4), p0_ = (r_ - ci_ * (C::SS / 4)) * 4;                             \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
-                        const int p_ = p0_ + e;                                                                       \
-                        const int y_ = p_ / S, xx_ = p_ - y_ * S;                                                     \
-                        TRON_PUT_IN(im_ * C::PLANE + (y_ + 1) * C::SP + (xx_ + 1), ci_, im_ <= last_img ? rin[j][e] : 0.0f); \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
+                if (STAGE_ && t < C::MT_MIN && TRON_F16_ABLATE != 1) { /* staging rides in the shadow of this tile's MFMAs */ \
+                    const int step = s * C::MT_MIN + t;                                                               \
+                    if (step >= STAGE_W0 && step < STAGE_W0 + W_LD) TRON_STORE_W(nxt_w_, step - STAGE_W0);            \
+                    if (step >= STAGE_IN0 && step < STAGE_IN0 + C::IN_LD) TRON_STORE_IN(nxt_in_, step - STAGE_IN0);   \
+                }                                                                                                     \
+                if (t < C::MT_MIN || my_mt > t) {                                                                     \
+                    _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                  \
+                        acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t & 1], bh[n], acc0[t][n], 0, 0, 0);   \
+                        acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t & 1], bl[n], acc1[t][n], 0, 0, 0);   \
+                        acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t & 1], bh[n], acc1[t][n], 0, 0, 0);   \
                     }                                                                                                 \
                 }                                                                                                     \
-            }                                                                                                         \
-            _Pragma("unroll") for (int j = 0; j < W_LD; ++j) {                                                        \
-                const int q_ = tidv_ + j * THREADS;                                                                   \
-                if (q_ < W_Q) {                                                                                       \
-                    const int co_ = q_ / 36, j4_ = q_ - co_ * 36;                                                     \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
-                        const int k_ = j4_ * 4 + e;                                                                   \
-                        const int ci_ = k_ / 9, tap_ = k_ - ci_ * 9;                                                  \
-                        TRON_PUT_W(tap_, co_, ci_, rw[j][e]);                                                         \
-                    }                                                                                                 \
-                }                                                                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
 
-    __syncthreads();
-    TRON_LOAD_CHUNK(0);
-    TRON_STORE_CHUNK();
-    __syncthreads();
-
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more = c + 1 < nchunks;
-        if (more) TRON_LOAD_CHUNK(c + 1);                                // in flight under the MFMAs
+    // ---- prologue: chunk 0 -------------------------------------------------------------------------------------
+    __syncthreads();                                                     // zero fill done
+    if (SMALL) {
+        // conv1: split the input here (27 / 36 k-values per output: nothing to amortise)
+        if (in_codes) {
+            if (tid < C::PX / 4) {
+                const int im0 = (tid * 4) / C::SS;
+                const int ims = im0 < last_img ? im0 : last_img;
+                const uint32_t rc = reinterpret_cast<const uint32_t *>(in)[(size_t)(img0 + ims) * (C::SS / 4) + (tid - im0 * (C::SS / 4))];
 #pragma unroll
-        for (int s = 0; s < SLABS; ++s) {
-            f16x8 bh[NT], bl[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int bo = b_base + (2 * s * COUT_WG + n * 16) * PITCH;
-                bh[n] = *reinterpret_cast<const f16x8 *>(w_h + bo);
-                bl[n] = *reinterpret_cast<const f16x8 *>(w_l + bo);
+                for (int e = 0; e < 4; ++e) {
+                    const int px = tid * 4 + e;
+                    const int im = px / C::SS, p = px - im * C::SS;
+                    const int y = p / S, x = p - y * S;
+                    const int v = im <= last_img ? (int)(int8_t)(rc >> (8 * e)) : 1;
+                    const int pix = im * C::PLANE + (y + 1) * C::SP + (x + 1);
+                    TRON_PUT_IN(lds, pix, 0, (v == -1) ? 1.0f : 0.0f);                          // util.py:18-19
+                    TRON_PUT_IN(lds, pix, 1, (v == -2) ? 1.0f : (v == 10) ? 10.0f : 0.0f);     // util.py:20-21,26-27
+                    TRON_PUT_IN(lds, pix, 2, (v == -3) ? 1.0f : (v == -10) ? 10.0f : 0.0f);
+                    if (cin == 4) TRON_PUT_IN(lds, pix, 3, plane4);
+                }
             }
-            // two-deep register pipeline over the M tiles: tile t+1's fragments are read while tile t's six MFMAs
-            // issue; sched_barrier keeps the compiler from hoisting a whole slab of reads (72 registers) at once
-            f16x8 ah[2], al[2];
-            const int toff = tap_offset(s);
-            ah[0] = *reinterpret_cast<const f16x8 *>(in_h + a_base[0] + toff);
-            al[0] = *reinterpret_cast<const f16x8 *>(in_l + a_base[0] + toff);
+        } else {
+            for (int q = tid; q < C::P * cin * (C::SS / 4); q += THREADS) {
+                const int im = q / (cin * (C::SS / 4)), r = q - im * (cin * (C::SS / 4));
+                const int ci = r / (C::SS / 4), p0 = (r - ci * (C::SS / 4)) * 4;
+                const int ims = im < last_img ? im : last_img;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(in_wg + (ims * cin * C::SS + (r - ci * (C::SS / 4)) * 4 + ci * C::SS));
 #pragma unroll
-            for (int t = 0; t < C::MT; ++t) {
-                if (t + 1 < C::MT) {
-                    ah[(t + 1) & 1] = *reinterpret_cast<const f16x8 *>(in_h + a_base[t + 1] + toff);
-                    al[(t + 1) & 1] = *reinterpret_cast<const f16x8 *>(in_l + a_base[t + 1] + toff);
+                for (int e = 0; e < 4; ++e) {
+                    const int p = p0 + e;
+                    const int y = p / S, x = p - y * S;
+                    TRON_PUT_IN(lds, im * C::PLANE + (y + 1) * C::SP + (x + 1), ci, im <= last_img ? v[e] : 0.0f);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t & 1], bh[n], acc0[t][n], 0, 0, 0);
-                    acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t & 1], bl[n], acc1[t][n], 0, 0, 0);
-                    acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t & 1], bh[n], acc1[t][n], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (more) {
-            __syncthreads();                                             // everyone is done reading this chunk
-            TRON_STORE_CHUNK();
-            __syncthreads();
-        }
+    } else {
+        TRON_LOAD_IN(0);
+#pragma unroll
+        for (int j = 0; j < C::IN_LD; ++j) TRON_STORE_IN(lds, j);
     }
-#undef TRON_LOAD_CHUNK
-#undef TRON_STORE_CHUNK
-#undef TRON_PUT_IN
-#undef TRON_PUT_W
+    TRON_LOAD_W(0);
+#pragma unroll
+    for (int j = 0; j < W_LD; ++j) TRON_STORE_W(lds + 2 * IN_BUF, j);
+    __syncthreads();
 
-    // epilogue (as tron_conv.hip): D row = 4 * (lane >> 4) + r (pixel), column = lane & 15 (channel)
-    const int pxw_end = (wm + 1) * C::PW < C::PX ? (wm + 1) * C::PW : C::PX;
+#ifdef TRON_CONV_STAMPS
+    if (tid == 0) { stamps[2] = __builtin_amdgcn_s_memtime(); stamps[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    // ---- the chunks: one barrier each (next chunk's buffers written, this chunk's buffers free again) ---------------
+    for (int c = 0; c + 1 < nchunks; ++c) {
+        TRON_CHUNK(true, c);
+        __syncthreads();
+    }
+    TRON_CHUNK(false, nchunks - 1);
+
+#undef TRON_CHUNK
+#undef TRON_STORE_W
+#undef TRON_LOAD_W
+#undef TRON_STORE_IN
+#undef TRON_LOAD_IN
+#undef TRON_PUT_IN
+
+#ifdef TRON_CONV_STAMPS
+    if (tid == 0) { stamps[4] = __builtin_amdgcn_s_memtime(); stamps[5] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    // ---- epilogue (as tron_conv.hip): D row = 4 * (lane >> 4) + r (pixel), column = lane & 15 (channel) ------------
     int o[C::MT];
     bool live[C::MT];
 #pragma unroll
     for (int t = 0; t < C::MT; ++t) {
-        const int px = wm * C::PW + 16 * t + 4 * g;
+        const int px = 16 * (tile0 + t) + 4 * g;
         const int img = px / C::SS, p = px - img * C::SS;
-        live[t] = px < pxw_end && img <= last_img;
-        o[t] = (img * cout + wn * 32 + li) * C::SS + p;
+        live[t] = t < my_mt && img <= last_img;
+        o[t] = (img * cout + wn * 16 * NT + li) * C::SS + p;
     }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        const float bv = bias ? bias[co0 + wn * 32 + n * 16 + li] : 0.0f;
+        const float bv = bias ? bias[wn * 16 * NT + n * 16 + li] : 0.0f;
 #pragma unroll
         for (int t = 0; t < C::MT; ++t) acc0[t][n] = (acc0[t][n] + acc1[t][n] * LO_UNSCALE) * ACT_UNSCALE + bv;
     }
@@ -364,15 +407,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWN == 2 ? 2 : 1) void k_conv3x3_f1
     }
 }
 
-template <int S, int NWN, bool SMALL>
-int launch(const void *in, const float *wgt, const float *bias, const float *res, float *out, float *pre_out, int64_t B,
-           int cin, int cout, float plane4, int apply_mish, int in_codes, hipStream_t st)
+template <int S, int NT, bool SMALL>
+int launch(const void *in, const f16 *ws, const float *bias, const float *res, float *out, float *pre_out, int64_t B,
+           int cin, float plane4, int apply_mish, int in_codes, hipStream_t st)
 {
     using C = Cfg<S>;
-    constexpr int COUT_WG = 32 * NWN;
-    constexpr size_t LDS_BYTES = 2 * (size_t)C::IN_BYTES + 2 * (size_t)TAPS_PAD * COUT_WG * PITCH;
+    constexpr size_t LDS_BYTES = 4 * (size_t)C::IN_HALF + 4 * (size_t)TAPS_PAD * 32 * NT * PITCH;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    auto kern = k_conv3x3_f16<S, NWN, SMALL>;
+    auto kern = k_conv3x3_f16<S, NT, SMALL>;
     static uint64_t prepared = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
@@ -383,25 +425,32 @@ int launch(const void *in, const float *wgt, const float *bias, const float *res
         prepared |= 1ull << (dev & 63);
     }
     const int64_t groups = (B + C::P - 1) / C::P;
-    const int64_t blocks = groups * (cout / COUT_WG);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NWM * NWN), LDS_BYTES, st, in, wgt, bias, res, out, pre_out,
-                       (int)B, cin, cout, (int)groups, plane4, apply_mish, in_codes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(THREADS), LDS_BYTES, st, in, ws, bias, res, out, pre_out, (int)B,
+                       cin, plane4, apply_mish, in_codes);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
 }  // namespace
 
+int64_t tron_conv3x3_f16x3_workspace(int cin, int cout)
+{
+    const int64_t nchunks = (cin + CIC - 1) / CIC;
+    return nchunks * 2 * TAPS_PAD * cout * CIC * (int64_t)sizeof(f16);
+}
+
 // called by tron_conv3x3_fwd (tron_conv.hip) after it validated the arguments; TRON_ERR_UNSUPPORTED = not this shape
 int tron_conv3x3_f16x3(const void *in, int in_is_codes, const float *weight, const float *bias, const float *residual,
                        float *out, float *pre_out, int64_t batch, int cin, int cout, int side, float plane4,
-                       int apply_mish, hipStream_t st)
+                       int apply_mish, void *workspace, hipStream_t st)
 {
     const bool small = cin == 3 || cin == 4;
-    if (side != 12 || (!small && cin % CIC != 0)) return TRON_ERR_UNSUPPORTED;
+    if (side != 12 || (!small && cin % CIC != 0) || !workspace) return TRON_ERR_UNSUPPORTED;
+    f16 *ws = reinterpret_cast<f16 *>(workspace);
+    const int nchunks = (cin + CIC - 1) / CIC;
+    const int total = nchunks * TAPS_PAD * cout * CIC;
+    hipLaunchKernelGGL(k_split_weights, dim3((total + 255) / 256), dim3(256), 0, st, weight, cout, cin, nchunks, ws);
     if (small)
-        return launch<12, 1, true>(in, weight, bias, residual, out, pre_out, batch, cin, cout, plane4, apply_mish,
-                                   in_is_codes ? 1 : 0, st);
-    if (cout == 64)
-        return launch<12, 2, false>(in, weight, bias, residual, out, pre_out, batch, cin, cout, plane4, apply_mish, 0, st);
-    return launch<12, 1, false>(in, weight, bias, residual, out, pre_out, batch, cin, cout, plane4, apply_mish, 0, st);
+        return launch<12, 1, true>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_is_codes ? 1 : 0, st);
+    if (cout == 64) return launch<12, 2, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, 0, st);
+    return launch<12, 1, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, 0, st);
 }

@@ -61,7 +61,8 @@ SIGNATURES = {
     "tron_replay_size": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "tron_replay_indices": (C.c_int, [_vp, _i32, _vp, _vp]),
     "tron_synchronize": (C.c_int, [_vp]),
-    "tron_conv3x3_fwd": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "tron_conv3x3_fwd": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp]),
+    "tron_conv3x3_workspace": (C.c_int64, [_i32, _i32]),
 }
 
 MINIMAX = {"voronoi": 0, "distwall": 1}

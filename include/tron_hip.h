@@ -273,11 +273,15 @@ int tron_bias_mish_bwd(const float *y_pre, const float *grad_out, float *grad_pr
  * TRON_CONV_F16X3: every operand split into two f16 halves (v = hi + lo 2^-11) and three
  * v_mfma_f32_16x16x32_f16 per k-slab (hi*hi, hi*lo, lo*hi; f32 accumulation) — 5x less matrix-pipe time at an
  * error of 2^-22 per product instead of 2^-24 (still within 1e-5 on the Q-values, tests/test_gpu_conv.py).
- * Shapes the split kernel does not cover (side 26) silently use the f32 kernel.                              */
+ * Shapes the split kernel does not cover (side 26) silently use the f32 kernel.  workspace: caller-owned device
+ * scratch of at least tron_conv3x3_workspace(cin, cout) bytes for the split weights (written afresh by every call,
+ * so nothing cached can go stale); only TRON_CONV_F16X3 needs it (NULL there means: use the f32 kernel).     */
 enum { TRON_CONV_F32 = 0, TRON_CONV_F16X3 = 1 };
 int tron_conv3x3_fwd(const void *in, int32_t in_is_codes, const float *weight, const float *bias,
                      const float *residual, float *out, float *pre_out, int64_t batch, int32_t cin,
-                     int32_t cout, int32_t side, float plane4, int32_t apply_mish, int32_t math, void *stream);
+                     int32_t cout, int32_t side, float plane4, int32_t apply_mish, int32_t math, void *workspace,
+                     void *stream);
+int64_t tron_conv3x3_workspace(int32_t cin, int32_t cout);
 
 /* Wait for `stream` and report what the kernels queued on it did: launch_status-style calls above only
  * see a REJECTED launch; a fault inside a kernel surfaces at the next synchronisation.  Returns TRON_OK

@@ -7,18 +7,28 @@ import config, torch  # noqa
 import numpy as np
 from tron import _native as nat
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-cin, cout, S = 32, 32, 12
+cin, cout, S = int(os.environ.get("CIN", 32)), int(os.environ.get("COUT", 32)), 12
+MATH = int(os.environ.get("MATH", 0))
+PER = 2 if MATH else 4
 conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
 x = torch.randn(B, cin, S, S, device="cuda"); r = torch.randn(B, cout, S, S, device="cuda")
 out = torch.empty(B, cout, S, S, device="cuda")
-blocks = B // 4
+blocks = B // PER * (2 if (cout == 64 and not MATH) else 1)
 st = torch.zeros(blocks, 6, dtype=torch.int64, device="cuda")
 L = nat.lib()
+ws = torch.empty(int(L.tron_conv3x3_workspace(cin, cout)), dtype=torch.uint8, device="cuda")
 for rep in range(30):          # warm the clocks up: the stamps of the last launch are read
     nat.check(L.tron_conv3x3_fwd(nat.ptr(x), 0, nat.ptr(conv.weight.detach()), nat.ptr(conv.bias.detach()), nat.ptr(r), nat.ptr(out),
-                                 nat.ptr(st), B, cin, cout, S, 0.0, 1, nat.stream_ptr()))
+                                 nat.ptr(st), B, cin, cout, S, 0.0, 1, MATH, nat.ptr(ws), nat.stream_ptr()))
 torch.cuda.synchronize()
 s = st.cpu().numpy().astype(np.float64)
+if MATH:      # f16 kernel stamps: start, end of prologue, end of main loop
+    pro_rt = (s[:, 3] - s[:, 1]) * 10.0
+    main_cyc, main_rt = s[:, 4] - s[:, 2], (s[:, 5] - s[:, 3]) * 10.0
+    print(f"prologue median {np.median(pro_rt) / 1e3:.2f} us; main loop median {np.median(main_rt) / 1e3:.2f} us = {np.median(main_cyc):.0f} cycles; "
+          f"ideal MFMA cycles per SIMD {cin // 16 * 5 * 9 * (cout // 32) * 3 * 16}; clock {np.median(main_cyc / main_rt):.3f} GHz; "
+          f"kernel span {(s[:, 5].max() - s[:, 1].min()) * 10 / 1e3:.1f} us for {blocks} blocks")
+    sys.exit(0)
 main_cyc, main_rt = s[:, 2] - s[:, 0], (s[:, 3] - s[:, 1]) * 10.0          # realtime ticks are 10 ns
 epi_cyc, epi_rt = s[:, 4] - s[:, 2], (s[:, 5] - s[:, 3]) * 10.0
 clk = main_cyc / main_rt           # cycles per ns = GHz

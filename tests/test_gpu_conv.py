@@ -34,9 +34,13 @@ def _ref(x, conv, res, act):
     return y, (F.mish(y) if act else y)
 
 
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
 @pytest.mark.parametrize("S,B", [(12, 1), (12, 7), (12, 260), (26, 1), (26, 3), (26, 130)])
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64), (64, 32)])
-def test_conv3x3_matches_float64_reference(fused, S, B, cin, cout):
+def test_conv3x3_matches_float64_reference(fused, S, B, cin, cout, math, monkeypatch):
+    """Both arithmetic modes of tron_conv3x3_fwd: the exact-f32 MFMA kernel and the split-f16 one (12x12 boards; at
+    26x26 the request falls back to the f32 kernel inside the library)."""
+    monkeypatch.setattr(fused, "default_math", math)
     torch.manual_seed(S * 1000 + B + cin + cout)
     conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
     x = torch.randn(B, cin, S, S, device="cuda")
@@ -57,12 +61,14 @@ def test_conv3x3_matches_float64_reference(fused, S, B, cin, cout):
     assert torch.equal(got, F.conv2d(x, conv.weight, None, padding=1))       # small integers: exact
 
 
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
 @pytest.mark.parametrize("S,B", [(12, 5), (12, 1030), (26, 2), (26, 300)])
 @pytest.mark.parametrize("cin", [3, 4])
-def test_conv1_from_codes_and_from_planes(fused, S, B, cin):
+def test_conv1_from_codes_and_from_planes(fused, S, B, cin, math, monkeypatch):
     """conv1 reads the env's int8 observation codes (map.py:67-84) and builds util.pop_up's planes
     (util.py:11-37) (+ the constant prob_map plane, game.py:124-132) on the fly."""
     from tron.vec import pop_up_planes
+    monkeypatch.setattr(fused, "default_math", math)
     torch.manual_seed(S + B + cin)
     conv = torch.nn.Conv2d(cin, 32, 3, padding=1).cuda()
     vals = torch.tensor([1, -1, -2, -3, 10, -10], dtype=torch.int8, device="cuda")
@@ -84,10 +90,17 @@ def test_unsupported_shapes_are_reported(fused):
     assert not fused.supported(torch.nn.Conv2d(32, 48, 3, padding=1).cuda(), 12)
     with pytest.raises(nat.TronNativeError):
         fused.conv3x3(torch.randn(2, 32, 14, 14, device="cuda"), conv)
+    # activations far outside f16's range go through the split kernel unharmed (2^-6 pre-scale, exact)
+    x = torch.randn(6, 32, 12, 12, device="cuda") * 3.0e5
+    got = fused.conv3x3(x, conv, act=False, math="f16x3")
+    ref = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+    assert torch.isfinite(got).all() and ((got.double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
 
 
-def test_infer_matches_reference_q_values(fused):
-    """Net.infer (HIP trunk) on the recorded inputs: Q within 1e-5 of the reference network's."""
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
+def test_infer_matches_reference_q_values(fused, math, monkeypatch):
+    """Net.infer (HIP trunk, either arithmetic) on the recorded inputs: Q within 1e-5 of the reference network's."""
+    monkeypatch.setattr(fused, "default_math", math)
     sys.path.insert(0, GOLDEN)
     from netgen import det_state_dict
     from Net.DQNNet import Net
