@@ -38,6 +38,7 @@ WIDTH = 24
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0   # the same guide's measured float4 copy rate: what a pure stream achieves
 F32_MATRIX_PEAK_TFLOPS = 157.3   # fp32-in MFMA = fp32 vector peak (guide, chip-level parameters)
+F16_MATRIX_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak (guide); the split-f16 convolutions spend 3 f16 MFMAs per f32 one
 # the reference's own Python `Game.step` loop, one thread, survey container (the reference
 # cannot travel to the GPU box, so these are recorded figures, not re-timed here)
 REFERENCE_PYTHON_RECORDED = {"10x10": 3.5e3, "24x24": 0.9e3, "32x32": 0.5e3,
@@ -206,8 +207,13 @@ def dqn_record(envs, width, steps, warmup, batch, repeats, world, rank):
             "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MATRIX_PEAK_TFLOPS,
                          "achieved": flops / sec / 1e12, "frac": flops / sec / 1e12 / F32_MATRIX_PEAK_TFLOPS,
                          "flops_forward_per_sample": f_fwd,
-                         "note": "fp32 like the reference (Q within 1e-5); peak = fp32-input MFMA = fp32 vector "
-                                 "rate; whole-loop time incl. env step, replay push/sample, optimizer"}}
+                         "peak_f16x3": F16_MATRIX_PEAK_TFLOPS / 3,
+                         "frac_of_f16x3_peak": flops / sec / 1e12 / (F16_MATRIX_PEAK_TFLOPS / 3),
+                         "note": "f32 results like the reference (Q within 1e-5).  peak = the f32-input MFMA rate (= f32 "
+                                 "vector rate), what exact-f32 arithmetic can reach; the 3x3 convolutions run as three f16 "
+                                 "MFMAs per f32 product (csrc/tron_conv_f16.hip: v = hi + lo 2^-11), whose ceiling is the dense "
+                                 "f16 peak / 3 (peak_f16x3).  Whole-loop time incl. env step, replay push/sample, optimizer; "
+                                 "weight gradients, conv7 and the linear layers are still f32 library kernels"}}
 
 
 def main():

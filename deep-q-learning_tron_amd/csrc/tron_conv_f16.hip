@@ -51,23 +51,28 @@ constexpr int NWM = 4, NWN = 2;   // waves along M and N
 constexpr int THREADS = 64 * NWM * NWN;
 constexpr float ACT_SCALE = 1.0f / 64.0f, ACT_UNSCALE = 64.0f, LO_SCALE = 2048.0f, LO_UNSCALE = 1.0f / 2048.0f;
 
+// A workgroup's region: P whole images (small boards) or one row band of one image (NB bands; larger boards).  A band
+// starts on an even row, so its first pixel's offset (row * S, S even) is a multiple of 4: epilogue float4s stay aligned.
 template <int S_>
 struct Cfg {
     static constexpr int S = S_;
     static constexpr int SP = S + 2;
-    static constexpr int PLANE = SP * SP;
     static constexpr int SS = S * S;
     static constexpr int P = (S * S <= 144) ? (288 / (S * S)) : 1;     // images per workgroup
-    static constexpr int PX = P * SS;
-    static constexpr int TILES = (PX + 15) / 16;                        // 16-pixel M tiles per workgroup
-    static constexpr int MT = (TILES + NWM - 1) / NWM;                  // most tiles a wave gets
-    static constexpr int MT_MIN = TILES / NWM;                          // ... and fewest: staging rides on these steps
+    static constexpr int NB = (S * S <= 400) ? 1 : 2;                   // row bands per image
+    static constexpr int SPLIT = NB == 1 ? S : ((S / 2) & ~1);          // band 0 = rows [0, SPLIT), band 1 = [SPLIT, S)
+    static constexpr int ROWS_MAX = NB == 1 ? S : (S - SPLIT > SPLIT ? S - SPLIT : SPLIT);
+    static constexpr int PLANE = (ROWS_MAX + 2) * SP;                   // padded plane of one image's band in LDS, pixels
+    static constexpr int TILES_MAX = (P * ROWS_MAX * S + 15) / 16;      // 16-pixel M tiles of the larger band
+    static constexpr int TILES_MIN = (P * (NB == 1 ? S : (SPLIT < S - SPLIT ? SPLIT : S - SPLIT)) * S + 15) / 16;
+    static constexpr int MT = (TILES_MAX + NWM - 1) / NWM;              // most tiles a wave gets
+    static constexpr int MT_MIN = TILES_MIN / NWM;                      // fewest: staging rides on these tile-steps
     static constexpr int IN_HALF = P * PLANE * PITCH;                   // hi (or lo) image of one input chunk
-    static constexpr int IN_ITEMS = PX * (CIC / 4);                     // (pixel, channel quad) items of an input chunk
+    static constexpr int IN_ITEMS = P * (ROWS_MAX + 2) * S * (CIC / 4); // (pixel incl. halo rows, channel quad) items, at most
     static constexpr int IN_LD = (IN_ITEMS + THREADS - 1) / THREADS;
-    static_assert(SS % 4 == 0, "a float4 of pixels must not cross an image (epilogue)");
-    static_assert(PX % 16 == 0, "whole M tiles only");
-    static_assert(MT <= 5, "accumulators: MT x NT x 2 x 4 registers");
+    static_assert(S % 2 == 0, "even sides only");
+    static_assert(P == 1 || NB == 1, "several images or several bands, not both");
+    static_assert(MT <= 6, "accumulators: MT x NT x 2 x 4 registers");
 };
 
 __device__ __forceinline__ float mish1(float x)                         // as in tron_conv.hip
@@ -133,10 +138,16 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // waves w and w + 4 share a SIMD: the second N half walks the M slots backwards, so a SIMD gets 5 + 4 tiles
     const int wn = wave / NWM, wm = wn ? NWM - 1 - (wave & (NWM - 1)) : (wave & (NWM - 1));
-    const int tile0 = wm * C::MT_MIN + (wm < C::TILES % NWM ? wm : C::TILES % NWM);   // first M tile of this wave
-    const int my_mt = C::MT_MIN + (wm < C::TILES % NWM ? 1 : 0);
     const int li = lane & 15, g = lane >> 4, tsel = g >> 1, oct = g & 1;
-    const int img0 = blockIdx.x * C::P;
+    const int img0 = (blockIdx.x / C::NB) * C::P;
+    const int band = blockIdx.x % C::NB;                                // neighbours in the grid share an image: halo rows hit L2
+    const int r0 = band ? C::SPLIT : 0, rows = C::NB == 1 ? S : (band ? S - C::SPLIT : C::SPLIT);
+    const int rpx = rows * S;                                           // pixels of one image in this region
+    const int npx = C::P * rpx;
+    const int tiles = (npx + 15) >> 4;
+    const int t_base = tiles / NWM, t_rem = tiles % NWM;
+    const int tile0 = wm * t_base + (wm < t_rem ? wm : t_rem);           // first M tile of this wave
+    const int my_mt = t_base + (wm < t_rem ? 1 : 0);
     const int nchunks = SMALL ? 1 : cin / CIC;
     const int last_img = B - 1 - img0;
     const int cout = COUT;
@@ -154,9 +165,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
 #pragma unroll
     for (int t = 0; t < C::MT; ++t) {
         int px = 16 * (tile0 + t) + li;
-        px = px < C::PX ? px : C::PX - 1;                               // a wave's surplus tile slot: valid address, unused
-        const int img = px / C::SS, p = px - img * C::SS;
-        const int y = p / S, x = p - y * S;
+        px = px < npx ? px : npx - 1;                                   // surplus tile slots / pixels: valid address, unused
+        const int img = px / rpx, p = px - img * rpx;
+        const int y = p / S, x = p - y * S;                             // y: row within the band
         a_base[t] = (img * C::PLANE + y * C::SP + x) * PITCH + oct * 16;
     }
     // byte offset of slab s's tap for this lane: taps 2s (tsel 0) / 2s+1 (tsel 1); the tenth tap (weights zero) reads
@@ -182,6 +193,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
 
     f32x4 rin[C::IN_LD];
     uint4 rw[W_LD];
+    const int epx = (rows + 2) * S;                                     // a band's pixels plus its two halo rows
+    const int n_items = C::P * epx * (CIC / 4);
 
     // ---- staging pieces -------------------------------------------------------------------------------------
     // one activation -> its (hi, lo) halves at pixel `pix_` (padded index), channel `ci_`, input buffer at `ib_`
@@ -203,11 +216,14 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         asm volatile("" : "+v"(tidl_));                      /* keep the address math out of registers across chunks */ \
         _Pragma("unroll") for (int j = 0; j < C::IN_LD; ++j) {                                                        \
             int q_ = tidl_ + j * THREADS;                                                                             \
-            q_ = q_ < C::IN_ITEMS ? q_ : C::IN_ITEMS - 1;                                                             \
+            q_ = q_ < n_items ? q_ : n_items - 1;                                                                     \
             const int px_ = q_ >> 2, quad_ = q_ & 3;                                                                  \
-            const int im_ = px_ / C::SS, p_ = px_ - im_ * C::SS;                                                      \
+            const int im_ = px_ / epx, p_ = px_ - im_ * epx;             /* p_: pixel within the band + halo rows */  \
+            const int re_ = p_ / S, xx_ = p_ - re_ * S;                                                               \
+            int gr_ = r0 - 1 + re_;                                       /* image row; clamped: dropped at the write */ \
+            gr_ = gr_ < 0 ? 0 : (gr_ >= S ? S - 1 : gr_);                                                             \
             const int ims_ = im_ < last_img ? im_ : last_img;                                                         \
-            const float *src_ = in_wg + ((ims_ * cin + (c_) * CIC + quad_ * 4) * C::SS + p_);                         \
+            const float *src_ = in_wg + ((ims_ * cin + (c_) * CIC + quad_ * 4) * C::SS + gr_ * S + xx_);              \
             rin[j] = (f32x4){src_[0], src_[C::SS], src_[2 * C::SS], src_[3 * C::SS]};                                 \
         }                                                                                                             \
     } while (0)
@@ -217,11 +233,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         int tidv_ = tid;                                                                                              \
         asm volatile("" : "+v"(tidv_));                                                                               \
         const int q_ = tidv_ + (j_) * THREADS;                                                                        \
-        if (((j_) + 1) * THREADS <= C::IN_ITEMS || q_ < C::IN_ITEMS) {                                                \
-            const int px_ = q_ >> 2, quad_ = q_ & 3;                                                                  \
-            const int im_ = px_ / C::SS, p_ = px_ - im_ * C::SS;                                                      \
-            const int y_ = p_ / S, xx_ = p_ - y_ * S;                                                                 \
-            const int off_ = (im_ * C::PLANE + (y_ + 1) * C::SP + (xx_ + 1)) * PITCH + quad_ * 8;                     \
+        const int px_ = q_ >> 2, quad_ = q_ & 3;                                                                      \
+        const int im_ = px_ / epx, p_ = px_ - im_ * epx;                                                              \
+        const int re_ = p_ / S, xx_ = p_ - re_ * S;                                                                   \
+        const int gr_ = r0 - 1 + re_;                                                                                 \
+        if (q_ < n_items && gr_ >= 0 && gr_ < S) {                        /* rows outside the image stay zero */        \
+            const int off_ = (im_ * C::PLANE + re_ * C::SP + (xx_ + 1)) * PITCH + quad_ * 8;                          \
             f16x4 h_, l_;                                                                                             \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                           \
                 f16 hh_, ll_;                                                                                         \
@@ -300,37 +317,24 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     // ---- prologue: chunk 0 -------------------------------------------------------------------------------------
     __syncthreads();                                                     // zero fill done
     if (SMALL) {
-        // conv1: split the input here (27 / 36 k-values per output: nothing to amortise)
-        if (in_codes) {
-            if (tid < C::PX / 4) {
-                const int im0 = (tid * 4) / C::SS;
-                const int ims = im0 < last_img ? im0 : last_img;
-                const uint32_t rc = reinterpret_cast<const uint32_t *>(in)[(size_t)(img0 + ims) * (C::SS / 4) + (tid - im0 * (C::SS / 4))];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int px = tid * 4 + e;
-                    const int im = px / C::SS, p = px - im * C::SS;
-                    const int y = p / S, x = p - y * S;
-                    const int v = im <= last_img ? (int)(int8_t)(rc >> (8 * e)) : 1;
-                    const int pix = im * C::PLANE + (y + 1) * C::SP + (x + 1);
-                    TRON_PUT_IN(lds, pix, 0, (v == -1) ? 1.0f : 0.0f);                          // util.py:18-19
-                    TRON_PUT_IN(lds, pix, 1, (v == -2) ? 1.0f : (v == 10) ? 10.0f : 0.0f);     // util.py:20-21,26-27
-                    TRON_PUT_IN(lds, pix, 2, (v == -3) ? 1.0f : (v == -10) ? 10.0f : 0.0f);
-                    if (cin == 4) TRON_PUT_IN(lds, pix, 3, plane4);
-                }
-            }
-        } else {
-            for (int q = tid; q < C::P * cin * (C::SS / 4); q += THREADS) {
-                const int im = q / (cin * (C::SS / 4)), r = q - im * (cin * (C::SS / 4));
-                const int ci = r / (C::SS / 4), p0 = (r - ci * (C::SS / 4)) * 4;
-                const int ims = im < last_img ? im : last_img;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(in_wg + (ims * cin * C::SS + (r - ci * (C::SS / 4)) * 4 + ci * C::SS));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int p = p0 + e;
-                    const int y = p / S, x = p - y * S;
-                    TRON_PUT_IN(lds, im * C::PLANE + (y + 1) * C::SP + (x + 1), ci, im <= last_img ? v[e] : 0.0f);
-                }
+        // conv1: split the input here (27 / 36 k-values per output: nothing to amortise); one pass over the band's
+        // pixels and halo rows
+        for (int e = tid; e < C::P * epx; e += THREADS) {
+            const int im = e / epx, p = e - im * epx;
+            const int re = p / S, x = p - re * S;
+            const int gr = r0 - 1 + re;
+            if (gr < 0 || gr >= S) continue;
+            const int pix = im * C::PLANE + re * C::SP + (x + 1);
+            const bool have = im <= last_img;
+            if (in_codes) {
+                const int v = have ? (int)reinterpret_cast<const int8_t *>(in)[(size_t)(img0 + im) * C::SS + gr * S + x] : 1;
+                TRON_PUT_IN(lds, pix, 0, (v == -1) ? 1.0f : 0.0f);                              // util.py:18-19
+                TRON_PUT_IN(lds, pix, 1, (v == -2) ? 1.0f : (v == 10) ? 10.0f : 0.0f);         // util.py:20-21,26-27
+                TRON_PUT_IN(lds, pix, 2, (v == -3) ? 1.0f : (v == -10) ? 10.0f : 0.0f);
+                if (cin == 4) TRON_PUT_IN(lds, pix, 3, have ? plane4 : 0.0f);
+            } else {
+                for (int ci = 0; ci < cin; ++ci)
+                    TRON_PUT_IN(lds, pix, ci, have ? in_wg[(im * cin + ci) * C::SS + gr * S + x] : 0.0f);
             }
         }
     } else {
@@ -368,10 +372,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     bool live[C::MT];
 #pragma unroll
     for (int t = 0; t < C::MT; ++t) {
-        const int px = 16 * (tile0 + t) + 4 * g;
-        const int img = px / C::SS, p = px - img * C::SS;
-        live[t] = t < my_mt && img <= last_img;
-        o[t] = (img * cout + wn * 16 * NT + li) * C::SS + p;
+        const int px = 16 * (tile0 + t) + 4 * g;                         // npx is a multiple of 4: all four pixels or none
+        const int img = px / rpx, p = px - img * rpx;
+        live[t] = t < my_mt && px < npx && img <= last_img;
+        o[t] = (img * cout + wn * 16 * NT + li) * C::SS + r0 * S + p;
     }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -424,7 +428,7 @@ int launch(const void *in, const f16 *ws, const float *bias, const float *res, f
             (void)hipGetLastError();
         prepared |= 1ull << (dev & 63);
     }
-    const int64_t groups = (B + C::P - 1) / C::P;
+    const int64_t groups = (B + C::P - 1) / C::P * C::NB;
     hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(THREADS), LDS_BYTES, st, in, ws, bias, res, out, pre_out, (int)B,
                        cin, plane4, apply_mish, in_codes);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
@@ -444,13 +448,22 @@ int tron_conv3x3_f16x3(const void *in, int in_is_codes, const float *weight, con
                        int apply_mish, void *workspace, hipStream_t st)
 {
     const bool small = cin == 3 || cin == 4;
-    if (side != 12 || (!small && cin % CIC != 0) || !workspace) return TRON_ERR_UNSUPPORTED;
+    if ((side != 12 && side != 26) || (!small && cin % CIC != 0) || !workspace) return TRON_ERR_UNSUPPORTED;
     f16 *ws = reinterpret_cast<f16 *>(workspace);
     const int nchunks = (cin + CIC - 1) / CIC;
     const int total = nchunks * TAPS_PAD * cout * CIC;
     hipLaunchKernelGGL(k_split_weights, dim3((total + 255) / 256), dim3(256), 0, st, weight, cout, cin, nchunks, ws);
-    if (small)
-        return launch<12, 1, true>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_is_codes ? 1 : 0, st);
-    if (cout == 64) return launch<12, 2, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, 0, st);
-    return launch<12, 1, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, 0, st);
+#define TRON_F16_CASE(S_)                                                                                                 \
+    if (side == S_) {                                                                                                     \
+        if (small)                                                                                                        \
+            return launch<S_, 1, true>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish,             \
+                                       in_is_codes ? 1 : 0, st);                                                          \
+        if (cout == 64)                                                                                                   \
+            return launch<S_, 2, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, 0, st);    \
+        return launch<S_, 1, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, 0, st);        \
+    }
+    TRON_F16_CASE(12)
+    TRON_F16_CASE(26)
+#undef TRON_F16_CASE
+    return TRON_ERR_UNSUPPORTED;
 }
