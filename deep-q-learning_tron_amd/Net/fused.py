@@ -26,20 +26,41 @@ def supported(conv, side):
             and conv.weight.dtype == torch.float32)
 
 
-def conv3x3_raw(x, weight, bias=None, residual=None, act=True, codes=False, plane4=0.0, want_pre=False, math=None):
+class Split16:
+    """A layer's output as the split-f16 operand image the next layer of the split kernel stages directly
+    (include/tron_hip.h, TRON_CONV_IN_SPLIT16): per image [16-channel chunk][hi | lo][pixel][16 ci] f16."""
+
+    def __init__(self, batch, channels, side, device):
+        self.shape = (batch, channels, side, side)
+        self.buf = torch.empty(batch * channels * side * side * 4, dtype=torch.uint8, device=device)
+
+
+def conv3x3_raw(x, weight, bias=None, residual=None, act=True, codes=False, plane4=0.0, want_pre=False, math=None,
+                want_f32=True, want_split=False):
     """act(conv3x3(x, weight, padding=1) + bias + residual) on tensors: weight f32 [Cout, Cin, 3, 3] as nn.Conv2d keeps
-    it, x f32 [B, Cin, S, S] — or, with codes=True, int8 observation codes [B, S, S] standing for Cin pop_up planes.
-    Returns out (and the pre-activation when want_pre)."""
-    B, S = x.shape[0], x.shape[-1]
+    it; x f32 [B, Cin, S, S], or (codes=True) int8 observation codes [B, S, S] standing for Cin pop_up planes, or a
+    Split16 from the previous layer.  Returns the f32 output (None if want_f32=False), then — when asked — the
+    pre-activation and / or the Split16 image of the output (want_split; split-f16 arithmetic only)."""
     cout, cin = weight.shape[0], weight.shape[1]
-    x = x.contiguous()
-    if codes:
-        if x.dtype != torch.int8:
-            raise TypeError("codes=True takes the env's int8 observation codes")
-    elif x.dtype != torch.float32 or x.shape[1] != cin:
-        raise TypeError(f"expected f32 [B, {cin}, S, S], got {tuple(x.shape)} {x.dtype}")
-    out = torch.empty(B, cout, S, S, dtype=torch.float32, device=x.device)
-    pre = torch.empty_like(out) if want_pre else None
+    if isinstance(x, Split16):
+        B, S = x.shape[0], x.shape[-1]
+        if x.shape[1] != cin:
+            raise TypeError(f"expected {cin} channels, got {x.shape[1]}")
+        in_fmt, xin, dev = nat.CONV_IN_SPLIT16, x.buf, x.buf.device
+    else:
+        B, S = x.shape[0], x.shape[-1]
+        xin, dev = x.contiguous(), x.device
+        if codes:
+            if xin.dtype != torch.int8:
+                raise TypeError("codes=True takes the env's int8 observation codes")
+            in_fmt = nat.CONV_IN_CODES
+        else:
+            if xin.dtype != torch.float32 or xin.shape[1] != cin:
+                raise TypeError(f"expected f32 [B, {cin}, S, S], got {tuple(xin.shape)} {xin.dtype}")
+            in_fmt = nat.CONV_IN_F32
+    out = torch.empty(B, cout, S, S, dtype=torch.float32, device=dev) if want_f32 else None
+    pre = torch.empty(B, cout, S, S, dtype=torch.float32, device=dev) if want_pre else None
+    split = Split16(B, cout, S, dev) if want_split else None
     res = None if residual is None else residual.contiguous()
     b = None if bias is None else bias.detach()
     w = weight.detach()
@@ -48,26 +69,42 @@ def conv3x3_raw(x, weight, bias=None, residual=None, act=True, codes=False, plan
     m = MATH[math or default_math]
     ws = None
     if m == nat.CONV_F16X3:        # scratch for the split weights, rewritten by every call
-        ws = torch.empty(int(nat.lib().tron_conv3x3_workspace(cin, cout)), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
-        nat.check(nat.lib().tron_conv3x3_fwd(nat.ptr(x), int(codes), nat.ptr(w), nat.ptr(b), nat.ptr(res),
+        ws = torch.empty(int(nat.lib().tron_conv3x3_workspace(cin, cout)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().tron_conv3x3_fwd(nat.ptr(xin), in_fmt, nat.ptr(w), nat.ptr(b), nat.ptr(res),
                                              nat.ptr(out), nat.ptr(pre), B, cin, cout, S, float(plane4), int(act),
-                                             m, nat.ptr(ws), nat.stream_ptr()), "tron_conv3x3_fwd")
-    return (out, pre) if want_pre else out
+                                             m, nat.ptr(ws), nat.ptr(None if split is None else split.buf),
+                                             nat.stream_ptr()), "tron_conv3x3_fwd")
+    ret = [out]
+    if want_pre:
+        ret.append(pre)
+    if want_split:
+        ret.append(split)
+    return ret[0] if len(ret) == 1 else tuple(ret)
 
 
-def conv3x3(x, conv, residual=None, act=True, codes=False, plane4=0.0, want_pre=False, math=None):
+def conv3x3(x, conv, residual=None, act=True, codes=False, plane4=0.0, want_pre=False, math=None, want_f32=True,
+            want_split=False):
     """conv3x3_raw on an nn.Conv2d module."""
-    return conv3x3_raw(x, conv.weight, conv.bias, residual, act, codes, plane4, want_pre, math)
+    return conv3x3_raw(x, conv.weight, conv.bias, residual, act, codes, plane4, want_pre, math, want_f32, want_split)
 
 
-def trunk(net, x, codes=False, plane4=0.0):
-    """conv1..conv6 with their two residual links (DQNNet.py:34-50): [B, 64, S, S]."""
-    x = conv3x3(x, net.conv1, codes=codes, plane4=plane4)
-    idx = x
-    x = conv3x3(x, net.conv2)
-    x = conv3x3(x, net.conv3, residual=idx)
-    x = conv3x3(x, net.conv4)
-    idx = x
-    x = conv3x3(x, net.conv5)
-    return conv3x3(x, net.conv6, residual=idx)
+def trunk(net, x, codes=False, plane4=0.0, math=None):
+    """conv1..conv6 with their two residual links (DQNNet.py:34-50): [B, 64, S, S].  With the split-f16 arithmetic the
+    layers hand their outputs on as Split16 images (no re-splitting in the consumer); f32 tensors are written only where
+    somebody reads them: conv1's and conv4's outputs (the residuals of conv3 and conv6) and conv6's."""
+    if MATH[math or default_math] != nat.CONV_F16X3:
+        x = conv3x3(x, net.conv1, codes=codes, plane4=plane4, math=math)
+        idx = x
+        x = conv3x3(x, net.conv2, math=math)
+        x = conv3x3(x, net.conv3, residual=idx, math=math)
+        x = conv3x3(x, net.conv4, math=math)
+        idx = x
+        x = conv3x3(x, net.conv5, math=math)
+        return conv3x3(x, net.conv6, residual=idx, math=math)
+    idx, s = conv3x3(x, net.conv1, codes=codes, plane4=plane4, math=math, want_split=True)
+    _, s = conv3x3(s, net.conv2, math=math, want_f32=False, want_split=True)
+    _, s = conv3x3(s, net.conv3, residual=idx, math=math, want_f32=False, want_split=True)
+    idx, s = conv3x3(s, net.conv4, math=math, want_split=True)
+    _, s = conv3x3(s, net.conv5, math=math, want_f32=False, want_split=True)
+    return conv3x3(s, net.conv6, residual=idx, math=math)

@@ -429,12 +429,20 @@ int launch_conv(const void *in, const float *wgt, const float *bias, const float
 
 }  // namespace
 
-extern "C" int tron_conv3x3_fwd(const void *in, int32_t in_is_codes, const float *weight, const float *bias,
+extern "C" int tron_conv3x3_fwd(const void *in, int32_t in_fmt, const float *weight, const float *bias,
                                 const float *residual, float *out, float *pre_out, int64_t batch, int32_t cin,
                                 int32_t cout, int32_t side, float plane4, int32_t apply_mish, int32_t math, void *workspace,
-                                void *stream)
+                                void *out_split, void *stream)
 {
-    if (!in || !weight || !out || batch < 0 || cin < 1) return TRON_ERR_BAD_ARG;
+    if (!in || !weight || (!out && !out_split) || batch < 0 || cin < 1) return TRON_ERR_BAD_ARG;
+    if (in_fmt < TRON_CONV_IN_F32 || in_fmt > TRON_CONV_IN_SPLIT16) return TRON_ERR_BAD_ARG;
+    const int in_is_codes = in_fmt == TRON_CONV_IN_CODES;
+    // the split-f16 activation image exists only between layers of the split kernel
+    const bool needs_f16 = in_fmt == TRON_CONV_IN_SPLIT16 || out_split != nullptr;
+    if (needs_f16 && (math != TRON_CONV_F16X3 || !workspace || (side != 12 && side != 26) || cout % 16 != 0 ||
+                      (in_fmt == TRON_CONV_IN_SPLIT16 && cin % 16 != 0)))
+        return TRON_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(out_split) & 15u) return TRON_ERR_BAD_ARG;
     if (batch == 0) return TRON_OK;
     if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(out) |
          reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(pre_out)) & 15u)
@@ -448,9 +456,9 @@ extern "C" int tron_conv3x3_fwd(const void *in, int32_t in_is_codes, const float
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (math == TRON_CONV_F16X3) {      // shapes the split kernel has no instantiation for take the f32 kernel
         if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15u)) return TRON_ERR_BAD_ARG;
-        const int rc = tron_conv3x3_f16x3(in, in_is_codes, weight, bias, residual, out, pre_out, batch, cin, cout, side,
-                                          plane4, apply_mish, workspace, st);
-        if (rc != TRON_ERR_UNSUPPORTED) return rc;
+        const int rc = tron_conv3x3_f16x3(in, in_fmt, weight, bias, residual, out, pre_out, batch, cin, cout, side,
+                                          plane4, apply_mish, workspace, out_split, st);
+        if (rc != TRON_ERR_UNSUPPORTED || needs_f16) return rc;
     }
 #define TRON_CONV_CASE(S_)                                                                                                \
     if (side == S_)                                                                                                        \

@@ -5,7 +5,8 @@
 
 // tron_conv_f16.hip: split-f16 matrix-core path; TRON_ERR_UNSUPPORTED when it has no instantiation for the shape.
 // `workspace` (>= tron_conv3x3_f16x3_workspace(cin, cout) bytes, 16-byte aligned) receives the split weights.
-int tron_conv3x3_f16x3(const void *in, int in_is_codes, const float *weight, const float *bias, const float *residual,
+// in_fmt: TRON_CONV_IN_*; out_split (may be NULL): also emit the output as the split-f16 image the next layer stages.
+int tron_conv3x3_f16x3(const void *in, int in_fmt, const float *weight, const float *bias, const float *residual,
                        float *out, float *pre_out, int64_t batch, int cin, int cout, int side, float plane4,
-                       int apply_mish, void *workspace, hipStream_t st);
+                       int apply_mish, void *workspace, void *out_split, hipStream_t st);
 int64_t tron_conv3x3_f16x3_workspace(int cin, int cout);

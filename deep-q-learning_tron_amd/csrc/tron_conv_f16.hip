@@ -118,8 +118,10 @@ template <int S, int NT, bool SMALL>
 __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     const void *__restrict__ in, const f16 *__restrict__ ws, const float *__restrict__ bias,
     const float *__restrict__ res, float *__restrict__ out, float *__restrict__ pre_out, int B, int cin, float plane4,
-    int apply_mish, int in_codes)
+    int apply_mish, int in_fmt, unsigned char *__restrict__ out_s16)
 {
+    const int in_codes = in_fmt == 1;
+    const bool in_s16 = !SMALL && in_fmt == 2;
     using C = Cfg<S>;
     constexpr int COUT = 32 * NT;
     constexpr int W_HALF = TAPS_PAD * COUT * PITCH;                     // hi (or lo) image of one weight chunk
@@ -129,11 +131,13 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     constexpr int W_BUF = 2 * W_HALF;
     constexpr int STEPS = SLABS * C::MT_MIN;                            // tile-steps every wave runs per chunk
     // steps that store weight pieces / input float4s: late enough for the loads issued at the chunk's start to have landed
-    constexpr int STAGE_W0 = STEPS - C::IN_LD - W_LD - 2, STAGE_IN0 = STAGE_W0 + W_LD;
+    constexpr int STAGE_W0 = STEPS - C::IN_LD - W_LD, STAGE_IN0 = STAGE_W0 + W_LD;
     static_assert(STAGE_W0 >= 6, "give the global loads time");
     static_assert(STAGE_IN0 + C::IN_LD <= STEPS, "one staged piece per tile-step");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    // LDS: in[0] (hi|lo) | in[1] (hi|lo) | w[0] (hi|lo) | w[1] (hi|lo)
+    // LDS: in[0] (hi|lo) | in[1] (hi|lo) | w[0] (hi|lo) | w[1] (hi|lo) | dump (1 KB: where surplus threads' staging
+    // writes go, so that the staging pieces are branch-free and can be scheduled between MFMAs)
+    unsigned char *dump = lds + 2 * IN_BUF + 2 * W_BUF;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // waves w and w + 4 share a SIMD: the second N half walks the M slots backwards, so a SIMD gets 5 + 4 tiles
@@ -181,6 +185,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
 
     const size_t wg_base = (size_t)img0 * cout * C::SS;
     const float *in_wg = (SMALL && in_codes) ? nullptr : reinterpret_cast<const float *>(in) + (size_t)img0 * cin * C::SS;
+    // the split-f16 activation image ("S16"): per image [16-channel chunk][hi | lo][pixel][16 ci] f16 — as many bytes as
+    // the f32 tensor, laid out so that a chunk's rows are copied into the padded LDS planes 16 bytes at a time
+    const unsigned char *in16_wg = reinterpret_cast<const unsigned char *>(in) + (size_t)img0 * cin * C::SS * 4;
 
     f32x4 acc0[C::MT][NT], acc1[C::MT][NT];
 #pragma unroll
@@ -192,9 +199,15 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         }
 
     f32x4 rin[C::IN_LD];
-    uint4 rw[W_LD];
+    f32x4 rw[W_LD];                                                     // raw 16-byte pieces (native vector: no scratch)
     const int epx = (rows + 2) * S;                                     // a band's pixels plus its two halo rows
-    const int n_items = C::P * epx * (CIC / 4);
+    const int n_items = C::P * epx * (CIC / 4);                         // f32 input: (pixel, quad) items; S16 input: as many 16-byte pieces
+    const int erows = rows + 2, npr = 2 * S, nph = C::P * erows * npr;  // S16: pieces per row, per half
+    // the staging index math divides by band-dependent (wave-uniform) values: multiply-high by a reciprocal computed
+    // once (exact while x * d < 2^32; x, d < 2^12 here) instead of a ~25-instruction integer division per use
+    const uint32_t m_epx = 0xFFFFFFFFu / (uint32_t)epx + 1u, m_nph = 0xFFFFFFFFu / (uint32_t)nph + 1u,
+                   m_ernpr = 0xFFFFFFFFu / (uint32_t)(erows * npr) + 1u;
+#define TRON_DIV(x_, m_) ((int)__umulhi((uint32_t)(x_), (m_)))
 
     // ---- staging pieces -------------------------------------------------------------------------------------
     // one activation -> its (hi, lo) halves at pixel `pix_` (padded index), channel `ci_`, input buffer at `ib_`
@@ -214,17 +227,32 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     do {                                                                                                              \
         int tidl_ = tid;                                                                                              \
         asm volatile("" : "+v"(tidl_));                      /* keep the address math out of registers across chunks */ \
+        if (in_s16) {                                         /* already split by the producing layer: 16-byte pieces */ \
+            _Pragma("unroll") for (int j = 0; j < C::IN_LD; ++j) {                                                    \
+                int q_ = tidl_ + j * THREADS;                                                                         \
+                q_ = q_ < n_items ? q_ : n_items - 1;                                                                 \
+                const int h_ = TRON_DIV(q_, m_nph), r_ = q_ - h_ * nph;                                                          \
+                const int im_ = TRON_DIV(r_, m_ernpr), r2_ = r_ - im_ * (erows * npr);                                   \
+                const int re_ = r2_ / npr, pc_ = r2_ - re_ * npr;                                                     \
+                int gr_ = r0 - 1 + re_;                                                                               \
+                gr_ = gr_ < 0 ? 0 : (gr_ >= S ? S - 1 : gr_);                                                         \
+                const int ims_ = im_ < last_img ? im_ : last_img;                                                     \
+                rin[j] = *reinterpret_cast<const f32x4 *>(in16_wg + ((size_t)ims_ * cin * C::SS * 4 +                 \
+                                                                      ((c_) * 2 + h_) * C::SS * 32 + gr_ * S * 32 + pc_ * 16)); \
+            }                                                                                                         \
+        } else {                                                                                                      \
         _Pragma("unroll") for (int j = 0; j < C::IN_LD; ++j) {                                                        \
             int q_ = tidl_ + j * THREADS;                                                                             \
             q_ = q_ < n_items ? q_ : n_items - 1;                                                                     \
             const int px_ = q_ >> 2, quad_ = q_ & 3;                                                                  \
-            const int im_ = px_ / epx, p_ = px_ - im_ * epx;             /* p_: pixel within the band + halo rows */  \
+            const int im_ = TRON_DIV(px_, m_epx), p_ = px_ - im_ * epx;             /* p_: pixel within the band + halo rows */  \
             const int re_ = p_ / S, xx_ = p_ - re_ * S;                                                               \
             int gr_ = r0 - 1 + re_;                                       /* image row; clamped: dropped at the write */ \
             gr_ = gr_ < 0 ? 0 : (gr_ >= S ? S - 1 : gr_);                                                             \
             const int ims_ = im_ < last_img ? im_ : last_img;                                                         \
             const float *src_ = in_wg + ((ims_ * cin + (c_) * CIC + quad_ * 4) * C::SS + gr_ * S + xx_);              \
             rin[j] = (f32x4){src_[0], src_[C::SS], src_[2 * C::SS], src_[3 * C::SS]};                                 \
+        }                                                                                                             \
         }                                                                                                             \
     } while (0)
     // staged item j_ -> input buffer ib_ (4 hi halves in one 8-byte write, 4 lo halves in another)
@@ -233,21 +261,30 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         int tidv_ = tid;                                                                                              \
         asm volatile("" : "+v"(tidv_));                                                                               \
         const int q_ = tidv_ + (j_) * THREADS;                                                                        \
+        if (in_s16) {                                                                                                 \
+            const int h_ = TRON_DIV(q_, m_nph), r_ = q_ - h_ * nph;                                                              \
+            const int im_ = TRON_DIV(r_, m_ernpr), r2_ = r_ - im_ * (erows * npr);                                       \
+            const int re_ = r2_ / npr, pc_ = r2_ - re_ * npr;                                                         \
+            const int gr_ = r0 - 1 + re_;                                                                             \
+            const bool ok_ = q_ < n_items && gr_ >= 0 && gr_ < S && im_ <= last_img;                                  \
+            const int off_ = h_ * C::IN_HALF + (im_ * C::PLANE + re_ * C::SP + 1) * PITCH + pc_ * 16;                 \
+            *reinterpret_cast<f32x4 *>(ok_ ? (ib_) + off_ : dump + lane * 16) = rin[j_];   /* branch-free: see dump */  \
+        } else {                                                                                                      \
         const int px_ = q_ >> 2, quad_ = q_ & 3;                                                                      \
-        const int im_ = px_ / epx, p_ = px_ - im_ * epx;                                                              \
+        const int im_ = TRON_DIV(px_, m_epx), p_ = px_ - im_ * epx;                                                              \
         const int re_ = p_ / S, xx_ = p_ - re_ * S;                                                                   \
         const int gr_ = r0 - 1 + re_;                                                                                 \
-        if (q_ < n_items && gr_ >= 0 && gr_ < S) {                        /* rows outside the image stay zero */        \
-            const int off_ = (im_ * C::PLANE + re_ * C::SP + (xx_ + 1)) * PITCH + quad_ * 8;                          \
-            f16x4 h_, l_;                                                                                             \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                           \
-                f16 hh_, ll_;                                                                                         \
-                split((im_ <= last_img ? rin[j_][e] : 0.0f) * ACT_SCALE, hh_, ll_);                                   \
-                h_[e] = hh_;                                                                                          \
-                l_[e] = ll_;                                                                                          \
-            }                                                                                                         \
-            *reinterpret_cast<f16x4 *>((ib_) + off_) = h_;                                                            \
-            *reinterpret_cast<f16x4 *>((ib_) + C::IN_HALF + off_) = l_;                                               \
+        const bool ok_ = q_ < n_items && gr_ >= 0 && gr_ < S;             /* rows outside the image stay zero */        \
+        const int off_ = (im_ * C::PLANE + re_ * C::SP + (xx_ + 1)) * PITCH + quad_ * 8;                              \
+        f16x4 h_, l_;                                                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                               \
+            f16 hh_, ll_;                                                                                             \
+            split((im_ <= last_img ? rin[j_][e] : 0.0f) * ACT_SCALE, hh_, ll_);                                       \
+            h_[e] = hh_;                                                                                              \
+            l_[e] = ll_;                                                                                              \
+        }                                                                                                             \
+        *reinterpret_cast<f16x4 *>(ok_ ? (ib_) + off_ : dump + lane * 16) = h_;                                       \
+        *reinterpret_cast<f16x4 *>(ok_ ? (ib_) + C::IN_HALF + off_ : dump + lane * 16 + 8) = l_;                      \
         }                                                                                                             \
     } while (0)
     // weight chunk c_: a linear copy of its pre-split image, piece j_
@@ -256,13 +293,14 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         _Pragma("unroll") for (int j = 0; j < W_LD; ++j) {                                                            \
             int q_ = tid + j * THREADS;                                                                               \
             q_ = q_ < W_Q ? q_ : W_Q - 1;                                                                             \
-            rw[j] = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(ws) + (size_t)(c_) * W_BUF)[q_]; \
+            rw[j] = reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(ws) + (size_t)(c_) * W_BUF)[q_]; \
         }                                                                                                             \
     } while (0)
 #define TRON_STORE_W(wb_, j_)                                                                                        \
     do {                                                                                                              \
         const int q_ = tid + (j_) * THREADS;                                                                          \
-        if (((j_) + 1) * THREADS <= W_Q || q_ < W_Q) reinterpret_cast<uint4 *>(wb_)[q_] = rw[j_];                     \
+        const bool ok_ = ((j_) + 1) * THREADS <= W_Q || q_ < W_Q;                                                     \
+        *reinterpret_cast<f32x4 *>(ok_ ? (wb_) + q_ * 16 : dump + lane * 16) = rw[j_];                                \
     } while (0)
 
     // ---- one chunk: 5 slabs x up to MT tile-steps; STAGE_: also bring chunk c+1 into the other buffers ---------------
@@ -272,7 +310,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         const unsigned char *w_h = lds + 2 * IN_BUF + ((c_) & 1) * W_BUF, *w_l = w_h + W_HALF;                        \
         unsigned char *nxt_in_ = lds + (((c_) + 1) & 1) * IN_BUF;                                                     \
         unsigned char *nxt_w_ = lds + 2 * IN_BUF + (((c_) + 1) & 1) * W_BUF;                                          \
-        if (STAGE_ && TRON_F16_ABLATE != 1) {                                                                         \
+        if (STAGE_ && TRON_F16_ABLATE != 1 && TRON_F16_ABLATE != 4) {                                                 \
             TRON_LOAD_W((c_) + 1);                                                                                    \
             TRON_LOAD_IN((c_) + 1);                                                                                   \
         }                                                                                                             \
@@ -283,30 +321,39 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
                 bh[n] = *reinterpret_cast<const f16x8 *>(w_h + bo);                                                   \
                 bl[n] = *reinterpret_cast<const f16x8 *>(w_l + bo);                                                   \
             }                                                                                                         \
-            /* two-deep register pipeline over the M tiles: tile t+1's fragments are read while tile t's MFMAs issue */ \
-            f16x8 ah[2], al[2];                                                                                       \
+            /* three-deep register pipeline over the M tiles: tile t+2's fragments are requested while tile t's MFMAs */ \
+            /* issue — one tile-step (96 cycles) does not cover the LDS latency under load                           */ \
+            f16x8 ah[3], al[3];                                                                                       \
             const int toff = tap_offset(s);                                                                           \
             ah[0] = *reinterpret_cast<const f16x8 *>(in_h + a_base[0] + toff);                                        \
             al[0] = *reinterpret_cast<const f16x8 *>(in_l + a_base[0] + toff);                                        \
+            ah[1] = *reinterpret_cast<const f16x8 *>(in_h + a_base[1] + toff);                                        \
+            al[1] = *reinterpret_cast<const f16x8 *>(in_l + a_base[1] + toff);                                        \
             _Pragma("unroll") for (int t = 0; t < C::MT; ++t) {                                                       \
-                if (t + 1 < C::MT && TRON_F16_ABLATE != 2) {                                                          \
-                    ah[(t + 1) & 1] = *reinterpret_cast<const f16x8 *>(in_h + a_base[t + 1] + toff);                  \
-                    al[(t + 1) & 1] = *reinterpret_cast<const f16x8 *>(in_l + a_base[t + 1] + toff);                  \
-                } else if (t + 1 < C::MT) {                                                                           \
-                    ah[(t + 1) & 1] = ah[t & 1];                                                                      \
-                    al[(t + 1) & 1] = al[t & 1];                                                                      \
+                if (t + 2 < C::MT && TRON_F16_ABLATE != 2) {                                                          \
+                    ah[(t + 2) % 3] = *reinterpret_cast<const f16x8 *>(in_h + a_base[t + 2] + toff);                  \
+                    al[(t + 2) % 3] = *reinterpret_cast<const f16x8 *>(in_l + a_base[t + 2] + toff);                  \
                 }                                                                                                     \
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
-                if (STAGE_ && t < C::MT_MIN && TRON_F16_ABLATE != 1) { /* staging rides in the shadow of this tile's MFMAs */ \
+                if (STAGE_ && t < C::MT_MIN && TRON_F16_ABLATE != 1 && TRON_F16_ABLATE != 3) { /* staging rides in the shadow of this tile's MFMAs */ \
                     const int step = s * C::MT_MIN + t;                                                               \
                     if (step >= STAGE_W0 && step < STAGE_W0 + W_LD) TRON_STORE_W(nxt_w_, step - STAGE_W0);            \
                     if (step >= STAGE_IN0 && step < STAGE_IN0 + C::IN_LD) TRON_STORE_IN(nxt_in_, step - STAGE_IN0);   \
                 }                                                                                                     \
+                if (STAGE_ && t < C::MT_MIN && TRON_F16_ABLATE != 1 && TRON_F16_ABLATE != 3 &&                        \
+                    s * C::MT_MIN + t >= STAGE_W0 && s * C::MT_MIN + t < STAGE_IN0 + C::IN_LD) {                      \
+                    /* spread the piece's VALU / LDS-write instructions between this tile's MFMAs */                  \
+                    _Pragma("unroll") for (int i = 0; i < 3 * NT; ++i) {                                              \
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
+                        __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);                                            \
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                            \
+                    }                                                                                                 \
+                }                                                                                                     \
                 if (t < C::MT_MIN || my_mt > t) {                                                                     \
                     _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                  \
-                        acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t & 1], bh[n], acc0[t][n], 0, 0, 0);   \
-                        acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t & 1], bl[n], acc1[t][n], 0, 0, 0);   \
-                        acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t & 1], bh[n], acc1[t][n], 0, 0, 0);   \
+                        acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t % 3], bh[n], acc0[t][n], 0, 0, 0);   \
+                        acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t % 3], bl[n], acc1[t][n], 0, 0, 0);   \
+                        acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t % 3], bh[n], acc1[t][n], 0, 0, 0);   \
                     }                                                                                                 \
                 }                                                                                                     \
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -361,6 +408,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
 #undef TRON_STORE_W
 #undef TRON_LOAD_W
 #undef TRON_STORE_IN
+#undef TRON_DIV
 #undef TRON_LOAD_IN
 #undef TRON_PUT_IN
 
@@ -396,27 +444,40 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc0[t][n] += r[t][n];
     }
-    float *out_wg = out + wg_base;
+    float *out_wg = out ? out + wg_base : nullptr;
     float *pre_wg = pre_out ? pre_out + wg_base : nullptr;
+    unsigned char *o16_wg = out_s16 ? out_s16 + wg_base * 4 : nullptr;
 #pragma unroll
     for (int t = 0; t < C::MT; ++t) {
         if (!live[t]) continue;
+        const int px = 16 * (tile0 + t) + 4 * g;
+        const int img = px / rpx, pg = r0 * S + (px - img * rpx);        // image, pixel within the image
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             f32x4 v = acc0[t][n];
             if (pre_wg) *reinterpret_cast<f32x4 *>(pre_wg + o[t] + n * 16 * C::SS) = v;
             if (apply_mish) v = (f32x4){mish1(v[0]), mish1(v[1]), mish1(v[2]), mish1(v[3])};
-            *reinterpret_cast<f32x4 *>(out_wg + o[t] + n * 16 * C::SS) = v;
+            if (out_wg) *reinterpret_cast<f32x4 *>(out_wg + o[t] + n * 16 * C::SS) = v;
+            if (o16_wg) {                 // the same values as the next layer's operand halves: [chunk][hi | lo][pixel][16 ci]
+                unsigned char *d = o16_wg + (size_t)img * cout * C::SS * 4 + (size_t)((wn * NT + n) * 2) * C::SS * 32 + pg * 32 + li * 2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f16 hh, ll;
+                    split(v[r] * ACT_SCALE, hh, ll);
+                    *reinterpret_cast<f16 *>(d + r * 32) = hh;
+                    *reinterpret_cast<f16 *>(d + C::SS * 32 + r * 32) = ll;
+                }
+            }
         }
     }
 }
 
 template <int S, int NT, bool SMALL>
 int launch(const void *in, const f16 *ws, const float *bias, const float *res, float *out, float *pre_out, int64_t B,
-           int cin, float plane4, int apply_mish, int in_codes, hipStream_t st)
+           int cin, float plane4, int apply_mish, int in_fmt, void *out_s16, hipStream_t st)
 {
     using C = Cfg<S>;
-    constexpr size_t LDS_BYTES = 4 * (size_t)C::IN_HALF + 4 * (size_t)TAPS_PAD * 32 * NT * PITCH;
+    constexpr size_t LDS_BYTES = 4 * (size_t)C::IN_HALF + 4 * (size_t)TAPS_PAD * 32 * NT * PITCH + 1024;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     auto kern = k_conv3x3_f16<S, NT, SMALL>;
     static uint64_t prepared = 0;
@@ -430,7 +491,7 @@ int launch(const void *in, const f16 *ws, const float *bias, const float *res, f
     }
     const int64_t groups = (B + C::P - 1) / C::P * C::NB;
     hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(THREADS), LDS_BYTES, st, in, ws, bias, res, out, pre_out, (int)B,
-                       cin, plane4, apply_mish, in_codes);
+                       cin, plane4, apply_mish, in_fmt, reinterpret_cast<unsigned char *>(out_s16));
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
@@ -443,9 +504,9 @@ int64_t tron_conv3x3_f16x3_workspace(int cin, int cout)
 }
 
 // called by tron_conv3x3_fwd (tron_conv.hip) after it validated the arguments; TRON_ERR_UNSUPPORTED = not this shape
-int tron_conv3x3_f16x3(const void *in, int in_is_codes, const float *weight, const float *bias, const float *residual,
+int tron_conv3x3_f16x3(const void *in, int in_fmt, const float *weight, const float *bias, const float *residual,
                        float *out, float *pre_out, int64_t batch, int cin, int cout, int side, float plane4,
-                       int apply_mish, void *workspace, hipStream_t st)
+                       int apply_mish, void *workspace, void *out_split, hipStream_t st)
 {
     const bool small = cin == 3 || cin == 4;
     if ((side != 12 && side != 26) || (!small && cin % CIC != 0) || !workspace) return TRON_ERR_UNSUPPORTED;
@@ -456,11 +517,13 @@ int tron_conv3x3_f16x3(const void *in, int in_is_codes, const float *weight, con
 #define TRON_F16_CASE(S_)                                                                                                 \
     if (side == S_) {                                                                                                     \
         if (small)                                                                                                        \
-            return launch<S_, 1, true>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish,             \
-                                       in_is_codes ? 1 : 0, st);                                                          \
+            return launch<S_, 1, true>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_fmt,     \
+                                       out_split, st);                                                                    \
         if (cout == 64)                                                                                                   \
-            return launch<S_, 2, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, 0, st);    \
-        return launch<S_, 1, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, 0, st);        \
+            return launch<S_, 2, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_fmt,    \
+                                        out_split, st);                                                                   \
+        return launch<S_, 1, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_fmt,        \
+                                    out_split, st);                                                                       \
     }
     TRON_F16_CASE(12)
     TRON_F16_CASE(26)

@@ -261,7 +261,7 @@ int tron_bias_mish_bwd(const float *y_pre, const float *grad_out, float *grad_pr
 /* out[b][co][y][x] = act(bias[co] + residual[b][co][y][x] + sum_{ci,ky,kx} W[co][ci][ky][kx] *
  * in[b][ci][y+ky-1][x+kx-1]) for a batch of side x side images, NCHW f32, exact fp32 arithmetic
  * (v_mfma_f32_16x16x4_f32): F.conv2d(padding=1) + bias + optional residual + optional mish in one launch.
- * in_is_codes != 0: `in` is int8 observation codes [batch][side*side] (Map.state_for_player, map.py:67-84)
+ * in_fmt TRON_CONV_IN_CODES: `in` is int8 observation codes [batch][side*side] (Map.state_for_player, map.py:67-84)
  * and the input channels are util.pop_up's planes (wall, my, enemy; util.py:11-37) built on the fly, plus the
  * constant `plane4` (Game.prob_map, game.py:124-132) when cin == 4 — conv1 straight from the env's output.
  * Otherwise `in` is f32[batch][cin][side][side], cin 3 or 4 (conv1 on its planes) or a multiple of 8.  weight is the nn.Conv2d parameter as it
@@ -277,10 +277,16 @@ int tron_bias_mish_bwd(const float *y_pre, const float *grad_out, float *grad_pr
  * scratch of at least tron_conv3x3_workspace(cin, cout) bytes for the split weights (written afresh by every call,
  * so nothing cached can go stale); only TRON_CONV_F16X3 needs it (NULL there means: use the f32 kernel).     */
 enum { TRON_CONV_F32 = 0, TRON_CONV_F16X3 = 1 };
-int tron_conv3x3_fwd(const void *in, int32_t in_is_codes, const float *weight, const float *bias,
+/* in_fmt: what `in` holds.  TRON_CONV_IN_SPLIT16 / out_split (may be NULL) chain layers of the split kernel without
+ * re-splitting: out_split receives the layer's output as the operand halves the next layer stages — per image
+ * [16-channel chunk][hi | lo][pixel][16 ci] f16, batch * cout * side * side * 4 bytes like the f32 tensor — and a
+ * layer given that image as `in` copies it into LDS 16 bytes at a time.  `out` may then be NULL (an inner layer whose
+ * f32 value nobody reads).  Only with TRON_CONV_F16X3.                                                          */
+enum { TRON_CONV_IN_F32 = 0, TRON_CONV_IN_CODES = 1, TRON_CONV_IN_SPLIT16 = 2 };
+int tron_conv3x3_fwd(const void *in, int32_t in_fmt, const float *weight, const float *bias,
                      const float *residual, float *out, float *pre_out, int64_t batch, int32_t cin,
                      int32_t cout, int32_t side, float plane4, int32_t apply_mish, int32_t math, void *workspace,
-                     void *stream);
+                     void *out_split, void *stream);
 int64_t tron_conv3x3_workspace(int32_t cin, int32_t cout);
 
 /* Wait for `stream` and report what the kernels queued on it did: launch_status-style calls above only

@@ -9,17 +9,21 @@ from tron import _native as nat
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 cin, cout, S = int(os.environ.get("CIN", 32)), int(os.environ.get("COUT", 32)), 12
 MATH = int(os.environ.get("MATH", 0))
+IN_FMT = int(os.environ.get("IN_FMT", 0))      # 2: the input is a split-f16 image (timing only: random halves)
+OUT_S16 = int(os.environ.get("OUT_S16", 0))
 PER = 2 if MATH else 4
 conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
 x = torch.randn(B, cin, S, S, device="cuda"); r = torch.randn(B, cout, S, S, device="cuda")
 out = torch.empty(B, cout, S, S, device="cuda")
+x16 = (torch.randn(B * cin * S * S * 2, device="cuda") * 0.1).to(torch.float16)
+o16 = torch.empty(B * cout * S * S * 4, dtype=torch.uint8, device="cuda")
 blocks = B // PER * (2 if (cout == 64 and not MATH) else 1)
 st = torch.zeros(blocks, 6, dtype=torch.int64, device="cuda")
 L = nat.lib()
 ws = torch.empty(int(L.tron_conv3x3_workspace(cin, cout)), dtype=torch.uint8, device="cuda")
 for rep in range(30):          # warm the clocks up: the stamps of the last launch are read
-    nat.check(L.tron_conv3x3_fwd(nat.ptr(x), 0, nat.ptr(conv.weight.detach()), nat.ptr(conv.bias.detach()), nat.ptr(r), nat.ptr(out),
-                                 nat.ptr(st), B, cin, cout, S, 0.0, 1, MATH, nat.ptr(ws), nat.stream_ptr()))
+    nat.check(L.tron_conv3x3_fwd(nat.ptr(x16 if IN_FMT == 2 else x), IN_FMT, nat.ptr(conv.weight.detach()), nat.ptr(conv.bias.detach()), nat.ptr(r), nat.ptr(out),
+                                 nat.ptr(st), B, cin, cout, S, 0.0, 1, MATH, nat.ptr(ws), nat.ptr(o16) if OUT_S16 else None, nat.stream_ptr()))
 torch.cuda.synchronize()
 s = st.cpu().numpy().astype(np.float64)
 if MATH:      # f16 kernel stamps: start, end of prologue, end of main loop

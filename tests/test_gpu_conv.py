@@ -169,3 +169,28 @@ def test_training_conv_gradients_match_float64(fused, S, B, cin, cout, with_res)
         close(x.grad, xd.grad, "input")
     if with_res:
         close(res.grad, rd.grad, "residual")
+
+
+@pytest.mark.parametrize("S,B", [(12, 1), (12, 131), (26, 2), (26, 65)])
+def test_split16_chain_equals_unchained_layers(fused, S, B):
+    """Layers chained through the split-f16 image (TRON_CONV_IN_SPLIT16 / out_split) give bit-for-bit what the same
+    split kernel gives when every layer re-splits the previous layer's f32 output: the image IS that split."""
+    from Net.DQNNet import Net
+    torch.manual_seed(S + B)
+    net = Net(3, S - 2).cuda()
+    vals = torch.tensor([1, -1, -2, -3, 10, -10], dtype=torch.int8, device="cuda")
+    codes = vals[torch.randint(0, 6, (B, S, S), device="cuda")]
+    chained = fused.trunk(net, codes, codes=True, math="f16x3")
+    x = fused.conv3x3(codes, net.conv1, codes=True, math="f16x3")
+    idx = x
+    x = fused.conv3x3(x, net.conv2, math="f16x3")
+    x = fused.conv3x3(x, net.conv3, residual=idx, math="f16x3")
+    x = fused.conv3x3(x, net.conv4, math="f16x3")
+    idx = x
+    x = fused.conv3x3(x, net.conv5, math="f16x3")
+    x = fused.conv3x3(x, net.conv6, residual=idx, math="f16x3")
+    assert torch.equal(chained, x)
+    # and a layer asked for both forms returns the same f32 tensor either way
+    a = fused.conv3x3(idx, net.conv5, math="f16x3")
+    b, s16 = fused.conv3x3(idx, net.conv5, math="f16x3", want_split=True)
+    assert torch.equal(a, b) and s16.buf.numel() == a.numel() * 4
