@@ -89,8 +89,9 @@ class Net(nn.Module):
         """Q-values without autograd and without dropout (what `eval()` + `no_grad()` give, DDQN.py:90-110,129-142)
         on the hand-written HIP path: the six 3x3 convolutions are csrc/tron_conv.hip launches (fp32 matrix cores,
         bias + residual + mish fused, conv1 straight from the env's int8 observation codes when codes=True);
-        pooling, conv7 and the four small linear layers stay on the libraries.  Falls back to the module's own
-        forward for shapes the kernel does not cover (odd sides, CPU tensors)."""
+        at 12x12 pooling, conv7 and the four linear layers are one csrc/tron_head.hip call (24x24 boards keep them on
+        the libraries).  Falls back to the module's own forward for shapes the kernels do not cover (odd sides, CPU
+        tensors)."""
         from Net import fused
         side = x.shape[-1]
         with torch.no_grad():
@@ -108,6 +109,8 @@ class Net(nn.Module):
                 finally:
                     self.train(was_training)
             x = fused.trunk(self, x.reshape(-1, side, side) if codes else x, codes=codes, plane4=plane4)
+            if fused.default_math == "f16x3" and fused.head_supported(self, side):
+                return fused.head(self, x)
             x = self.pool(x)
             x = _conv_bias_mish(self.conv7, x)
             x = x.reshape(-1, self.flat)

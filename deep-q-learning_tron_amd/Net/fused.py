@@ -108,3 +108,32 @@ def trunk(net, x, codes=False, plane4=0.0, math=None):
     idx, s = conv3x3(s, net.conv4, math=math, want_split=True)
     _, s = conv3x3(s, net.conv5, math=math, want_f32=False, want_split=True)
     return conv3x3(s, net.conv6, residual=idx, math=math)
+
+
+def head_supported(net, side):
+    """tron_dqn_head_fwd covers the reference's own geometry: 12x12 observations, 64*3*3 into fc1 (DQNNet.py:24,55)."""
+    return (side == 12 and getattr(net, "flat", 0) == 576 and net.conv7.weight.shape == (64, 64, 7, 7)
+            and net.fc1.weight.shape == (256, 576) and net.fc2.weight.shape == (128, 256)
+            and net.actor1.weight.shape == (64, 128) and net.actor2.weight.shape == (4, 64)
+            and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in net.parameters()))
+
+
+def head(net, x, want_q=True, want_greedy=False):
+    """pool -> conv7 -> flatten -> fc1 -> fc2 -> actor1 -> actor2 (DQNNet.py:52-63, eval mode) on the trunk's f32 output
+    [B, 64, 12, 12] in one library call (csrc/tron_head.hip).  Returns Q [B, 4] and / or the greedy action int8 [B]."""
+    L = nat.lib()
+    B, side = x.shape[0], x.shape[-1]
+    assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape[1:]) == (64, side, side), x.shape
+    q = torch.empty(B, 4, dtype=torch.float32, device=x.device) if want_q else None
+    g = torch.empty(B, dtype=torch.int8, device=x.device) if want_greedy else None
+    if B == 0:
+        return (q, g) if want_greedy else q
+    ws = torch.empty(int(L.tron_dqn_head_workspace(B, side)), dtype=torch.uint8, device=x.device)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(x.device):
+        nat.check(L.tron_dqn_head_fwd(x.data_ptr(), B, side, net.conv7.weight.data_ptr(), net.conv7.bias.data_ptr(),
+                                      net.fc1.weight.data_ptr(), net.fc1.bias.data_ptr(), net.fc2.weight.data_ptr(),
+                                      net.fc2.bias.data_ptr(), net.actor1.weight.data_ptr(), net.actor1.bias.data_ptr(),
+                                      net.actor2.weight.data_ptr(), net.actor2.bias.data_ptr(), ws.data_ptr(), ptr(q),
+                                      ptr(g), torch.cuda.current_stream(x.device).cuda_stream), "tron_dqn_head_fwd")
+    return (q, g) if want_greedy else q

@@ -1,0 +1,330 @@
+// tron_head.hip — what follows the 3x3 trunk in the reference's DQN net (Net/DQNNet.py:52-63):
+//     x = pool(x); x = mish(conv7(x)); x = x.view(-1, 64*3*3); x = mish(fc1(x)); x = mish(fc2(x));
+//     q = actor2(mish(actor1(x)))                      (dropout is the identity in eval mode)
+// as one C-ABI call, tron_dqn_head_fwd, for gradient-free forwards (policy, targets).
+//
+// All of it is GEMM-shaped once conv7 is written densely: on the 6x6 pooled planes a 7x7 / stride 2 / pad 3 convolution
+// has 3x3 outputs and most taps fall on padding, so the dense map [64*6*6 = 2304] -> [64*3*3 = 576] (2.65 MFLOP per
+// sample) is cheaper than the nominal convolution (3.6 MFLOP).  Every product runs on the f16 matrix cores with both
+// operands split in two halves (v = hi + lo 2^-11, three MFMAs per k-slab, f32 accumulation — csrc/tron_conv_f16.hip
+// has the derivation and the error bound), and the layers hand their outputs on already split:
+//     k_pool_split      avg-pool 3/2/1 (count_include_pad) of the trunk's f32 output -> split f16 rows [B][2304]
+//     k_dense7_split    conv7's weight -> the dense matrix [576][2304], split            (per call: nothing cached)
+//     k_split_rows      an nn.Linear weight [N][K] -> split
+//     k_gemm_f16x3      C = act(A W^T + bias), A and W split f16 row-major; C as f32 and / or split f16
+//     k_q_head          actor2 (64 -> 4) in f32 + argmax
+// GEMM tile: 128 x 64 per 8-wave workgroup (wave = 32 x 32 = 2 x 2 MFMA tiles), K in chunks of 64 staged by 16-byte
+// copies into single-buffered LDS (55 KB: two to three workgroups share a CU and cover each other's barriers).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tron_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float ACT_SCALE = 1.0f / 64.0f, ACT_UNSCALE = 64.0f, LO_SCALE = 2048.0f, LO_UNSCALE = 1.0f / 2048.0f;
+
+__device__ __forceinline__ float mish1(float x)                         // as in tron_conv.hip
+{
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+    const float n = __fmaf_rn(e, e, e + e);
+    const float d = n + 2.0f;
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __fmaf_rn(r, __fmaf_rn(-d, r, 1.0f), r);
+    const float y = x * (n * r);
+    return x > 20.0f ? x : y;
+}
+__device__ __forceinline__ void split(float v, f16 &hi, f16 &lo)
+{
+    hi = (f16)v;
+    lo = (f16)((v - (float)hi) * LO_SCALE);
+}
+
+// x f32 [B][C][S][S] -> AvgPool2d(3, stride 2, padding 1) (divisor 9 everywhere: count_include_pad) -> rows
+// [B][C * PS * PS] in NCHW-flatten order, pre-scaled by 2^-6 and split
+__global__ void k_pool_split(const float *__restrict__ x, int64_t total, int C, int S, int PS, f16 *__restrict__ oh,
+                             f16 *__restrict__ ol)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int px = (int)(i % PS), py = (int)((i / PS) % PS);
+        const int64_t plane = i / (PS * PS);                            // b * C + c
+        const float *p = x + plane * S * S;
+        float s = 0.0f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = 2 * py + dy, xx = 2 * px + dx;
+                if (yy >= 0 && yy < S && xx >= 0 && xx < S) s += p[yy * S + xx];
+            }
+        f16 h, l;
+        split(s * (1.0f / 9.0f) * ACT_SCALE, h, l);
+        oh[i] = h;
+        ol[i] = l;
+    }
+}
+
+// conv7 (Co x Ci x 7 x 7, stride 2, pad 3) on PS x PS planes as a dense [Co*OS*OS][Ci*PS*PS] matrix, split
+__global__ void k_dense7_split(const float *__restrict__ w, int Co, int Ci, int PS, int OS, f16 *__restrict__ oh,
+                               f16 *__restrict__ ol)
+{
+    const int K = Ci * PS * PS, N = Co * OS * OS;
+    const int total = N * K;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int n = i / K, k = i - n * K;
+        const int co = n / (OS * OS), op = n - co * (OS * OS), oy = op / OS, ox = op - oy * OS;
+        const int ci = k / (PS * PS), ip = k - ci * (PS * PS), iy = ip / PS, ix = ip - iy * PS;
+        const int ky = iy - 2 * oy + 3, kx = ix - 2 * ox + 3;
+        const float v = (ky >= 0 && ky < 7 && kx >= 0 && kx < 7) ? w[((size_t)(co * Ci + ci) * 7 + ky) * 7 + kx] : 0.0f;
+        f16 h, l;
+        split(v, h, l);
+        oh[i] = h;
+        ol[i] = l;
+    }
+}
+
+__global__ void k_split_rows(const float *__restrict__ w, int total, f16 *__restrict__ oh, f16 *__restrict__ ol)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        f16 h, l;
+        split(w[i], h, l);
+        oh[i] = h;
+        ol[i] = l;
+    }
+}
+
+constexpr int GM = 128, GN = 64, GK = 64;          // workgroup tile, K chunk
+constexpr int GPITCH = GK * 2 + 16;                // bytes per LDS row (16 bytes of padding spread the banks)
+constexpr int G_THREADS = 512;
+constexpr int A_HALF = GM * GPITCH, W_HALF = GN * GPITCH;
+constexpr int G_LDS = 2 * A_HALF + 2 * W_HALF;     // 55 296 bytes
+
+// C[M][N] = act((A W^T) * 64 + bias[n / bias_div]); A = Ah + Al 2^-11 (pre-scaled by 2^-6), W = Wh + Wl 2^-11, all f16
+// row-major with K contiguous.  N % 64 == 0, K % 64 == 0.  out_f32 and / or (out_h, out_l) (pre-scaled by 2^-6 again).
+__global__ __launch_bounds__(G_THREADS, 4) void k_gemm_f16x3(const f16 *__restrict__ Ah, const f16 *__restrict__ Al,
+                                                             const f16 *__restrict__ Wh, const f16 *__restrict__ Wl,
+                                                             const float *__restrict__ bias, int bias_div, int M, int N,
+                                                             int K, int act, float *__restrict__ out_f32,
+                                                             f16 *__restrict__ out_h, f16 *__restrict__ out_l)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *a_h = lds, *a_l = lds + A_HALF, *w_h = lds + 2 * A_HALF, *w_l = w_h + W_HALF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 3, wn = wave >> 2, li = lane & 15, g = lane >> 4;
+    const int nblocks = N / GN;
+    const int m0 = (blockIdx.x / nblocks) * GM, n0 = (blockIdx.x % nblocks) * GN;   // neighbours share the A rows in L2
+
+    // staging: 16-byte pieces; A: [2 halves][128 rows][8 pieces], W: [2 halves][64 rows][8 pieces]
+    f32x4 ra[4], rw[2];
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = tid + j * G_THREADS, half = q >> 10, r = q & 1023, row = r >> 3, pc = r & 7;
+            int m = m0 + row;
+            m = m < M ? m : M - 1;
+            ra[j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(half ? Al : Ah) +
+                                                     ((size_t)m * K + (size_t)kc * GK) * 2 + pc * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = tid + j * G_THREADS, half = q >> 9, r = q & 511, row = r >> 3, pc = r & 7;
+            rw[j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(half ? Wl : Wh) +
+                                                     ((size_t)(n0 + row) * K + (size_t)kc * GK) * 2 + pc * 16);
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = tid + j * G_THREADS, half = q >> 10, r = q & 1023, row = r >> 3, pc = r & 7;
+            *reinterpret_cast<f32x4 *>(lds + half * A_HALF + row * GPITCH + pc * 16) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = tid + j * G_THREADS, half = q >> 9, r = q & 511, row = r >> 3, pc = r & 7;
+            *reinterpret_cast<f32x4 *>(lds + 2 * A_HALF + half * W_HALF + row * GPITCH + pc * 16) = rw[j];
+        }
+    };
+
+    f32x4 acc0[2][2], acc1[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            acc0[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc1[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    const int a_off = (wm * 32 + li) * GPITCH + g * 16, b_off = (wn * 32 + li) * GPITCH + g * 16;
+    const int nk = K / GK;
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        if (kc + 1 < nk) load_chunk(kc + 1);                            // in flight under the MFMAs
+#pragma unroll
+        for (int s = 0; s < GK / 32; ++s) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const f16x8 *>(a_h + a_off + t * 16 * GPITCH + s * 64);
+                al[t] = *reinterpret_cast<const f16x8 *>(a_l + a_off + t * 16 * GPITCH + s * 64);
+                bh[t] = *reinterpret_cast<const f16x8 *>(w_h + b_off + t * 16 * GPITCH + s * 64);
+                bl[t] = *reinterpret_cast<const f16x8 *>(w_l + b_off + t * 16 * GPITCH + s * 64);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc0[t][n], 0, 0, 0);
+                    acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc1[t][n], 0, 0, 0);
+                    acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc1[t][n], 0, 0, 0);
+                }
+        }
+        __syncthreads();                                                 // everyone is done reading this chunk
+        if (kc + 1 < nk) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: D row = 4 * (lane >> 4) + r, column = lane & 15
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = n0 + wn * 32 + n * 16 + li;
+        const float bv = bias ? bias[col / bias_div] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 v = (acc0[t][n] + acc1[t][n] * LO_UNSCALE) * ACT_UNSCALE + bv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + t * 16 + 4 * g + r;
+                if (m >= M) continue;
+                const float y = act ? mish1(v[r]) : v[r];
+                if (out_f32) out_f32[(size_t)m * N + col] = y;
+                if (out_h) {
+                    f16 hh, ll;
+                    split(y * ACT_SCALE, hh, ll);
+                    out_h[(size_t)m * N + col] = hh;
+                    out_l[(size_t)m * N + col] = ll;
+                }
+            }
+        }
+    }
+}
+
+// actor2: q[b][a] = x[b] . w[a] + bias[a] in f32 (64 x 4 MACs per sample), and the greedy action
+__global__ void k_q_head(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, int B,
+                         int K, float *__restrict__ q, int8_t *__restrict__ greedy)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float acc[4] = {bias[0], bias[1], bias[2], bias[3]};
+    for (int k = 0; k < K; k += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)b * K + k);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4 ww = *reinterpret_cast<const float4 *>(w + a * K + k);
+            acc[a] = __fmaf_rn(v.x, ww.x, acc[a]);
+            acc[a] = __fmaf_rn(v.y, ww.y, acc[a]);
+            acc[a] = __fmaf_rn(v.z, ww.z, acc[a]);
+            acc[a] = __fmaf_rn(v.w, ww.w, acc[a]);
+        }
+    }
+    if (q) *reinterpret_cast<float4 *>(q + (size_t)b * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (greedy) {                                                        // first maximum, like torch.argmax / np.argmax
+        int best = 0;
+#pragma unroll
+        for (int a = 1; a < 4; ++a)
+            if (acc[a] > acc[best]) best = a;
+        greedy[b] = (int8_t)best;
+    }
+}
+
+inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+struct HeadPlan {                      // byte offsets into the workspace
+    int64_t a7h, a7l, d7h, d7l, c7h, c7l, w1h, w1l, c1h, c1l, w2h, w2l, c2h, c2l, w3h, w3l, c3, total;
+};
+HeadPlan plan(int64_t B, int K7, int N7)
+{
+    HeadPlan p{};
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { const int64_t at = o; o = align256(o + bytes); return at; };
+    p.a7h = take(B * K7 * 2); p.a7l = take(B * K7 * 2);
+    p.d7h = take((int64_t)N7 * K7 * 2); p.d7l = take((int64_t)N7 * K7 * 2);
+    p.c7h = take(B * N7 * 2); p.c7l = take(B * N7 * 2);
+    p.w1h = take(256ll * N7 * 2); p.w1l = take(256ll * N7 * 2);
+    p.c1h = take(B * 256 * 2); p.c1l = take(B * 256 * 2);
+    p.w2h = take(128 * 256 * 2); p.w2l = take(128 * 256 * 2);
+    p.c2h = take(B * 128 * 2); p.c2l = take(B * 128 * 2);
+    p.w3h = take(64 * 128 * 2); p.w3l = take(64 * 128 * 2);
+    p.c3 = take(B * 64 * 4);
+    p.total = o;
+    return p;
+}
+
+int gemm(const f16 *Ah, const f16 *Al, const f16 *Wh, const f16 *Wl, const float *bias, int bias_div, int64_t M, int N, int K,
+         int act, float *out_f32, f16 *out_h, f16 *out_l, hipStream_t st)
+{
+    static uint64_t prepared = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
+    if (!(prepared & (1ull << (dev & 63)))) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G_LDS) != hipSuccess)
+            (void)hipGetLastError();
+        prepared |= 1ull << (dev & 63);
+    }
+    const int64_t blocks = ((M + GM - 1) / GM) * (N / GN);
+    hipLaunchKernelGGL(k_gemm_f16x3, dim3((unsigned)blocks), dim3(G_THREADS), G_LDS, st, Ah, Al, Wh, Wl, bias, bias_div, (int)M,
+                       N, K, act, out_f32, out_h, out_l);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int64_t tron_dqn_head_workspace(int64_t batch, int32_t side)
+{
+    if (batch < 1 || side != 12) return 0;
+    return plan(batch, 64 * 6 * 6, 64 * 3 * 3).total;
+}
+
+extern "C" int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t side, const float *conv7_w,
+                                 const float *conv7_b, const float *fc1_w, const float *fc1_b, const float *fc2_w,
+                                 const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,
+                                 const float *actor2_b, void *workspace, float *q_out, int8_t *greedy_out, void *stream)
+{
+    if (!trunk_out || !conv7_w || !conv7_b || !fc1_w || !fc1_b || !fc2_w || !fc2_b || !actor1_w || !actor1_b ||
+        !actor2_w || !actor2_b || !workspace || (!q_out && !greedy_out) || batch < 0)
+        return TRON_ERR_BAD_ARG;
+    if (batch == 0) return TRON_OK;
+    if (side != 12 || batch > (1ll << 24)) return TRON_ERR_UNSUPPORTED;       // 6x6 pooled planes, 3x3 after conv7
+    if ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(trunk_out) | reinterpret_cast<uintptr_t>(q_out)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    constexpr int C = 64, PS = 6, OS = 3, K7 = C * PS * PS, N7 = C * OS * OS;
+    const HeadPlan p = plan(batch, K7, N7);
+    unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    auto H = [&](int64_t off) { return reinterpret_cast<f16 *>(ws + off); };
+    const int64_t npool = batch * K7;
+    hipLaunchKernelGGL(k_pool_split, dim3((unsigned)((npool + 255) / 256 < 65535 * 8 ? (npool + 255) / 256 : 65535 * 8)), dim3(256), 0,
+                       st, trunk_out, npool, C, side, PS, H(p.a7h), H(p.a7l));
+    hipLaunchKernelGGL(k_dense7_split, dim3((N7 * K7 + 255) / 256), dim3(256), 0, st, conv7_w, C, C, PS, OS, H(p.d7h), H(p.d7l));
+    hipLaunchKernelGGL(k_split_rows, dim3((256 * N7 + 255) / 256), dim3(256), 0, st, fc1_w, 256 * N7, H(p.w1h), H(p.w1l));
+    hipLaunchKernelGGL(k_split_rows, dim3((128 * 256 + 255) / 256), dim3(256), 0, st, fc2_w, 128 * 256, H(p.w2h), H(p.w2l));
+    hipLaunchKernelGGL(k_split_rows, dim3((64 * 128 + 255) / 256), dim3(256), 0, st, actor1_w, 64 * 128, H(p.w3h), H(p.w3l));
+    if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
+    int rc = gemm(H(p.a7h), H(p.a7l), H(p.d7h), H(p.d7l), conv7_b, OS * OS, batch, N7, K7, 1, nullptr, H(p.c7h), H(p.c7l), st);
+    if (rc == TRON_OK) rc = gemm(H(p.c7h), H(p.c7l), H(p.w1h), H(p.w1l), fc1_b, 1, batch, 256, N7, 1, nullptr, H(p.c1h), H(p.c1l), st);
+    if (rc == TRON_OK) rc = gemm(H(p.c1h), H(p.c1l), H(p.w2h), H(p.w2l), fc2_b, 1, batch, 128, 256, 1, nullptr, H(p.c2h), H(p.c2l), st);
+    float *c3 = reinterpret_cast<float *>(ws + p.c3);
+    if (rc == TRON_OK) rc = gemm(H(p.c2h), H(p.c2l), H(p.w3h), H(p.w3l), actor1_b, 1, batch, 64, 128, 1, c3, nullptr, nullptr, st);
+    if (rc != TRON_OK) return rc;
+    hipLaunchKernelGGL(k_q_head, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, c3, actor2_w, actor2_b, (int)batch, 64,
+                       q_out, greedy_out);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}

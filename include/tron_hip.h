@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TRON_ABI_VERSION 3
+#define TRON_ABI_VERSION 4
 
 typedef enum {
     TRON_OK = 0,
@@ -288,6 +288,22 @@ int tron_conv3x3_fwd(const void *in, int32_t in_fmt, const float *weight, const 
                      int32_t cout, int32_t side, float plane4, int32_t apply_mish, int32_t math, void *workspace,
                      void *out_split, void *stream);
 int64_t tron_conv3x3_workspace(int32_t cin, int32_t cout);
+
+/* ---- the rest of the DQN net after the 3x3 trunk (Net/DQNNet.py:52-63) ------------------------------------------
+ * q = actor2(mish(actor1(mish(fc2(mish(fc1(flatten(mish(conv7(pool(x)))))))))))  for gradient-free forwards
+ * (dropout is the identity in eval mode): avg-pool 3/2/1, conv7 (7x7, stride 2, pad 3) as the dense
+ * [64*6*6] -> [64*3*3] map it is on 6x6 planes, and the three linear layers, all on the f16 matrix cores with
+ * every operand split in two halves (TRON_CONV_F16X3's arithmetic), actor2 in f32.  trunk_out: f32[batch][64][side]
+ * [side] (conv6's output).  Weights are the nn.Module parameters as they are (conv7_w f32[64][64][7][7], fc1_w
+ * f32[256][576], fc2_w f32[128][256], actor1_w f32[64][128], actor2_w f32[4][64]); they are split into `workspace`
+ * afresh by every call.  q_out f32[batch][4] and / or greedy_out int8[batch] (first maximum, as torch.argmax).
+ * side must be 12 (10x10 boards: the only size whose flatten is 64*3*3, what fc1 expects) else
+ * TRON_ERR_UNSUPPORTED.  workspace: at least tron_dqn_head_workspace(batch, side) bytes, 16-byte aligned.        */
+int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t side, const float *conv7_w,
+                      const float *conv7_b, const float *fc1_w, const float *fc1_b, const float *fc2_w,
+                      const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,
+                      const float *actor2_b, void *workspace, float *q_out, int8_t *greedy_out, void *stream);
+int64_t tron_dqn_head_workspace(int64_t batch, int32_t side);
 
 /* Wait for `stream` and report what the kernels queued on it did: launch_status-style calls above only
  * see a REJECTED launch; a fault inside a kernel surfaces at the next synchronisation.  Returns TRON_OK

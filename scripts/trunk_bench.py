@@ -35,3 +35,23 @@ for _ in range(10):
     q = net.infer(codes, codes=True)
 torch.cuda.synchronize()
 print(f"Net.infer: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms")
+if S == 12 and fused.head_supported(net, S):
+    x = fused.trunk(net, codes, codes=True)
+
+    def lib_tail(x):
+        with torch.no_grad():
+            y = torch.nn.functional.mish(net.conv7(net.pool(x))).reshape(-1, net.flat)
+            y = torch.nn.functional.mish(net.fc1(y))
+            y = torch.nn.functional.mish(net.fc2(y))
+            return net.actor2(torch.nn.functional.mish(net.actor1(y)))
+    for name, fn in (("tron_dqn_head_fwd", lambda: fused.head(net, x)), ("library tail", lambda: lib_tail(x))):
+        for _ in range(3):
+            fn()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(10):
+            fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        print(f"{name}: {ev[0].elapsed_time(ev[1]) / 10:.3f} ms", flush=True)
+    print("head vs library tail max |dQ|:", (fused.head(net, x) - lib_tail(x)).abs().max().item())
