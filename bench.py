@@ -179,7 +179,7 @@ def dqn_record(envs, width, steps, warmup, batch, repeats, world, rank):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            a = brain.qnetwork_local.infer(codes, codes=True).argmax(1).to(torch.int8).reshape(envs, 2)
+            a = brain.qnetwork_local.infer(codes, codes=True, greedy=True).reshape(envs, 2)
             codes = env.step(a)[0].reshape(2 * envs, S, S)
         torch.cuda.synchronize()
         if rep:

@@ -144,10 +144,10 @@ class Agent():
     def act_batch(self, obs, epsilon, codes=False):
         """Batched epsilon-greedy on the device: obs f32 planes [B,C,S,S] — or, codes=True, the env's int8
         observation codes [B,S,S] — -> int8 actions [B].  The greedy forward runs on Net.infer (HIP conv kernels)."""
-        greedy = self.qnetwork_local.infer(obs, codes=codes).argmax(1)
-        rnd = torch.randint(0, self.action_size, greedy.shape, device=greedy.device)
+        greedy = self.qnetwork_local.infer(obs, codes=codes, greedy=True)
+        rnd = torch.randint(0, self.action_size, greedy.shape, device=greedy.device, dtype=torch.int8)
         explore = torch.rand(greedy.shape, device=greedy.device) <= epsilon
-        return torch.where(explore, rnd, greedy).to(torch.int8)
+        return torch.where(explore, rnd, greedy)
 
     def targets(self, rewards, next_state, dones, gamma):
         """Double-DQN labels (DDQN.py:129-142): a* = argmax Q_local(s'), y = r + g Q_target(s', a*)(1-done).

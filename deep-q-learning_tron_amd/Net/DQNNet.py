@@ -85,13 +85,14 @@ class Net(nn.Module):
     def act(self, x, env_prob=None):              # DQNNet.py:64-66 (env_prob accepted for Game.main_loop)
         return torch.argmax(self(x), dim=1)
 
-    def infer(self, x, codes=False, plane4=0.0):
+    def infer(self, x, codes=False, plane4=0.0, greedy=False):
         """Q-values without autograd and without dropout (what `eval()` + `no_grad()` give, DDQN.py:90-110,129-142)
         on the hand-written HIP path: the six 3x3 convolutions are csrc/tron_conv.hip launches (fp32 matrix cores,
         bias + residual + mish fused, conv1 straight from the env's int8 observation codes when codes=True);
         at 12x12 pooling, conv7 and the four linear layers are one csrc/tron_head.hip call (24x24 boards keep them on
         the libraries).  Falls back to the module's own forward for shapes the kernels do not cover (odd sides, CPU
-        tensors)."""
+        tensors).  greedy=True returns the arg-max action per row as int8 instead (`Net.act`, DQNNet.py:64-66), taken
+        inside the head kernel where that runs."""
         from Net import fused
         side = x.shape[-1]
         with torch.no_grad():
@@ -105,15 +106,16 @@ class Net(nn.Module):
                 was_training = self.training
                 self.eval()
                 try:
-                    return self(x)
+                    return self(x).argmax(1).to(torch.int8) if greedy else self(x)
                 finally:
                     self.train(was_training)
             x = fused.trunk(self, x.reshape(-1, side, side) if codes else x, codes=codes, plane4=plane4)
             if fused.default_math == "f16x3" and fused.head_supported(self, side):
-                return fused.head(self, x)
+                return fused.head(self, x, want_q=False, want_greedy=True)[1] if greedy else fused.head(self, x)
             x = self.pool(x)
             x = _conv_bias_mish(self.conv7, x)
             x = x.reshape(-1, self.flat)
             x = _mish(self.fc1(x))
             x = _mish(self.fc2(x))
-            return self.actor2(_mish(self.actor1(x)))
+            q = self.actor2(_mish(self.actor1(x)))
+            return q.argmax(1).to(torch.int8) if greedy else q

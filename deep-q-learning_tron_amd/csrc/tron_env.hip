@@ -1185,6 +1185,7 @@ struct tron_env {
     hipStream_t side;         // TRON_ROLLOUT_TWO_STREAMS: second launch stream + fork/join events, created on first use
     hipEvent_t fork, join;
     int part0, nparts;        // slice of the tiles the next launch covers (0, 1 = all of them)
+    int roll_E;               // envs per tile of the persistent rollout (0: not chosen yet), see roll_tile_envs
 };
 
 namespace {
@@ -1580,6 +1581,35 @@ namespace {
 // late ones start as the early ones finish their steps — measured best at 65 536 x 24x24 (22.1 us per
 // step; 23.5-24.0 us with 1024-1536 workgroups walking several tiles each; 27.2 us with one launch per
 // step).  TRON_ROLL_E / TRON_ROLL_GRID / TRON_ROLL_CHUNK override tile size, grid and steps per launch.
+// Tile size of the persistent rollout.  One tile per workgroup, and the chip holds `slots` workgroups at once
+// (occupancy x CUs: 5 x 256 at 24x24), so the launch runs in ceil(ntiles / slots) rounds and the last one should be
+// full: at 65 536 envs 32-env tiles are 2 048 workgroups = 1.6 rounds (the tail runs 3 per CU, latency-bound), 26-env
+// tiles are 2 521 = 1.97 rounds — 21.4 instead of 21.9 us per step (gpurun sweep, round 2).  Picks the E in
+// [3/4 E0, E0] with the fullest last round (E0 = the per-step kernels' tile); small batches that fit in one round
+// keep E0.
+int roll_tile_envs(const tron_env *h)
+{
+    const int E0 = h->E;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) { (void)hipGetLastError(); return E0; }
+    int best = E0;
+    double best_fill = -1.0;
+    for (int E = E0; E >= (3 * E0 + 3) / 4 && E >= 1; --E) {
+        const size_t smem = ((size_t)E + 1u) * h->cpe * 16u + 4u * (size_t)E * 16u;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_obs_roll, BLOCK, smem) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            continue;
+        }
+        const double slots = (double)per_cu * prop.multiProcessorCount;
+        const double rounds = ((h->P.N + E - 1) / E) / slots;
+        if (rounds <= 1.0) return E == E0 ? E0 : best;                  // everything resident at once: nothing to balance
+        const double fill = rounds / (double)(long long)(rounds + 0.999999);
+        if (fill > best_fill + 0.02) { best_fill = fill; best = E; }    // prefer the larger tile unless clearly fuller
+    }
+    return best;
+}
+
 int rollout_persistent(tron_env *h, int32_t k_steps, uint32_t flags, StepOut out, hipStream_t st)
 {
     static int env_e = 0, env_grid = 0, chunk = TRON_ROLLOUT_CHUNK;
@@ -1592,7 +1622,9 @@ int rollout_persistent(tron_env *h, int32_t k_steps, uint32_t flags, StepOut out
     }
     static uint64_t prepared = 0;
     allow_big_lds(reinterpret_cast<const void *>(k_obs_roll), h->device, prepared);
-    const int E = env_e > 0 ? env_e : h->E;
+    if (!h->roll_E) h->roll_E = roll_tile_envs(h);
+    // the resident variant is store-bound and measured best on the per-step tile (3.51 vs 3.21 G env-steps/s at 26)
+    const int E = env_e > 0 ? env_e : (flags & TRON_ROLLOUT_RESIDENT) ? h->E : h->roll_E;
     const size_t smem = ((size_t)E + 1u) * h->cpe * 16u + 4u * (size_t)E * 16u;
     if (smem > 160u * 1024u) return TRON_ERR_BAD_ARG;
     const int ntiles = (h->P.N + E - 1) / E;

@@ -8,7 +8,7 @@
 // sample) is cheaper than the nominal convolution (3.6 MFLOP).  Every product runs on the f16 matrix cores with both
 // operands split in two halves (v = hi + lo 2^-11, three MFMAs per k-slab, f32 accumulation — csrc/tron_conv_f16.hip
 // has the derivation and the error bound), and the layers hand their outputs on already split:
-//     k_pool_split      avg-pool 3/2/1 (count_include_pad) of the trunk's f32 output -> split f16 rows [B][2304]
+//     k_pool_split12    avg-pool 3/2/1 (count_include_pad) of the trunk's f32 output -> split f16 rows [B][2304]
 //     k_dense7_split    conv7's weight -> the dense matrix [576][2304], split            (per call: nothing cached)
 //     k_split_rows      an nn.Linear weight [N][K] -> split
 //     k_gemm_f16x3      C = act(A W^T + bias), A and W split f16 row-major; C as f32 and / or split f16
@@ -44,28 +44,43 @@ __device__ __forceinline__ void split(float v, f16 &hi, f16 &lo)
     lo = (f16)((v - (float)hi) * LO_SCALE);
 }
 
-// x f32 [B][C][S][S] -> AvgPool2d(3, stride 2, padding 1) (divisor 9 everywhere: count_include_pad) -> rows
-// [B][C * PS * PS] in NCHW-flatten order, pre-scaled by 2^-6 and split
-__global__ void k_pool_split(const float *__restrict__ x, int64_t total, int C, int S, int PS, f16 *__restrict__ oh,
-                             f16 *__restrict__ ol)
+// x f32 [B][C][12][12] -> AvgPool2d(3, stride 2, padding 1) (divisor 9 everywhere: count_include_pad) -> rows
+// [B][C * 6 * 6] in NCHW-flatten order, pre-scaled by 2^-6 and split.  One thread = one pooled row of one plane: three
+// input rows as 16-byte loads (a 12-float row is 48 bytes, so every row is aligned), six outputs as 4-byte stores.
+__global__ __launch_bounds__(256) void k_pool_split12(const float *__restrict__ x, int64_t rows, f16 *__restrict__ oh,
+                                                      f16 *__restrict__ ol)
 {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int px = (int)(i % PS), py = (int)((i / PS) % PS);
-        const int64_t plane = i / (PS * PS);                            // b * C + c
-        const float *p = x + plane * S * S;
-        float s = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += stride) {
+        const int py = (int)(i % 6);
+        const int64_t plane = i / 6;
+        const float *p = x + plane * 144;
+        float col[13];                                                   // col[1 + xx] = sum over the 3 rows; col[0] = pad
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+        for (int k = 0; k < 13; ++k) col[k] = 0.0f;
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int yy = 2 * py + dy, xx = 2 * px + dx;
-                if (yy >= 0 && yy < S && xx >= 0 && xx < S) s += p[yy * S + xx];
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = 2 * py + dy;
+            if (yy < 0) continue;                                        // yy <= 11 always (py <= 5, dy <= 1)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(p + yy * 12 + q * 4);
+                col[1 + q * 4] += v[0];
+                col[2 + q * 4] += v[1];
+                col[3 + q * 4] += v[2];
+                col[4 + q * 4] += v[3];
             }
-        f16 h, l;
-        split(s * (1.0f / 9.0f) * ACT_SCALE, h, l);
-        oh[i] = h;
-        ol[i] = l;
+        }
+        f16 h[6], l[6];
+#pragma unroll
+        for (int px = 0; px < 6; ++px)                                   // window columns 2px-1 .. 2px+1 -> col[2px .. 2px+2]
+            split((col[2 * px] + col[2 * px + 1] + col[2 * px + 2]) * (1.0f / 9.0f) * ACT_SCALE, h[px], l[px]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            *reinterpret_cast<f16x2 *>(oh + i * 6 + 2 * k) = (f16x2){h[2 * k], h[2 * k + 1]};
+            *reinterpret_cast<f16x2 *>(ol + i * 6 + 2 * k) = (f16x2){l[2 * k], l[2 * k + 1]};
+        }
     }
 }
 
@@ -310,9 +325,8 @@ extern "C" int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t 
     const HeadPlan p = plan(batch, K7, N7);
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
     auto H = [&](int64_t off) { return reinterpret_cast<f16 *>(ws + off); };
-    const int64_t npool = batch * K7;
-    hipLaunchKernelGGL(k_pool_split, dim3((unsigned)((npool + 255) / 256 < 65535 * 8 ? (npool + 255) / 256 : 65535 * 8)), dim3(256), 0,
-                       st, trunk_out, npool, C, side, PS, H(p.a7h), H(p.a7l));
+    const int64_t nrows = batch * C * PS;
+    hipLaunchKernelGGL(k_pool_split12, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, trunk_out, nrows, H(p.a7h), H(p.a7l));
     hipLaunchKernelGGL(k_dense7_split, dim3((N7 * K7 + 255) / 256), dim3(256), 0, st, conv7_w, C, C, PS, OS, H(p.d7h), H(p.d7l));
     hipLaunchKernelGGL(k_split_rows, dim3((256 * N7 + 255) / 256), dim3(256), 0, st, fc1_w, 256 * N7, H(p.w1h), H(p.w1l));
     hipLaunchKernelGGL(k_split_rows, dim3((128 * 256 + 255) / 256), dim3(256), 0, st, fc2_w, 128 * 256, H(p.w2h), H(p.w2l));

@@ -246,3 +246,14 @@ def test_dqn_head_large_activations_and_bad_args(fused):
     assert L.tron_dqn_head_fwd(x.data_ptr(), 4, 12, *ptrs, ws.data_ptr(), None, None, None) == nat.ERR_BAD_ARG
     assert L.tron_dqn_head_fwd(x.data_ptr(), 4, 12, *ptrs, None, qo.data_ptr(), None, None) == nat.ERR_BAD_ARG
     assert L.tron_dqn_head_fwd(x.data_ptr(), 0, 12, *ptrs, ws.data_ptr(), qo.data_ptr(), None, None) == 0
+
+
+@pytest.mark.parametrize("W", [10, 24])
+def test_infer_greedy_is_argmax_of_infer(fused, W):
+    from Net.DQNNet import Net
+    torch.manual_seed(W)
+    net = Net(3, W).cuda()
+    vals = torch.tensor([1, -1, -2, -3, 10, -10], dtype=torch.int8, device="cuda")
+    codes = vals[torch.randint(0, 6, (257, W + 2, W + 2), device="cuda")]
+    g = net.infer(codes, codes=True, greedy=True)
+    assert g.dtype == torch.int8 and torch.equal(g.long(), net.infer(codes, codes=True).argmax(1))
