@@ -44,24 +44,24 @@ def mish(x):
     return F.mish(x)
 
 
-def bias_mish_bwd(pre, g):
-    """(grad_pre, grad_bias) for out = mish(pre), pre = y + bias[c] (+ residual): one pass of csrc/tron_nn.hip."""
+def bias_mish_bwd(pre, g, want_absmax=False):
+    """(grad_pre, grad_bias) for out = mish(pre), pre = y + bias[c] (+ residual): one pass of csrc/tron_nn.hip.
+    want_absmax: also the per-block maxima of |grad_pre| (f32 [C * 64]) that the conv gradient kernels scale by."""
     from tron import _native as nat
     N, C, H, W = pre.shape
     gp = torch.empty_like(pre)
     gb = torch.empty(C, dtype=torch.float32, device=pre.device)
-    scratch = torch.empty(C * 64, dtype=torch.float32, device=pre.device)
+    scratch = torch.empty(C * 128, dtype=torch.float32, device=pre.device)
     with torch.cuda.device(pre.device):
         nat.check(nat.lib().tron_bias_mish_bwd(nat.ptr(pre), nat.ptr(g), nat.ptr(gp), nat.ptr(gb), nat.ptr(scratch), N, C,
                                                H * W, nat.stream_ptr()), "tron_bias_mish_bwd")
-    return gp, gb
+    return (gp, gb, scratch[C * 64:]) if want_absmax else (gp, gb)
 
 
 class _ConvBiasMishHIP(torch.autograd.Function):
-    """mish(conv3x3(x) + bias (+ residual)) with the forward AND the input gradient on csrc/tron_conv.hip (the data
-    gradient of a stride-1, pad-1 3x3 convolution is the same convolution with the weight's channel axes swapped and
-    its taps flipped), activation + bias gradient in one pass of csrc/tron_nn.hip; only the weight gradient stays on
-    MIOpen (aten.convolution_backward)."""
+    """mish(conv3x3(x) + bias (+ residual)) with forward, input gradient and weight gradient on the hand-written kernels
+    (csrc/tron_conv_f16.hip, tron_conv_wgrad.hip) and activation + bias gradient in one pass of csrc/tron_nn.hip.  Shapes
+    the gradient kernels do not cover (24x24 boards' weight gradient) go through aten.convolution_backward."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual):
@@ -78,15 +78,17 @@ class _ConvBiasMishHIP(torch.autograd.Function):
         g = grad_out.contiguous()
         if not _aligned16(g):
             g = g.clone(memory_format=torch.contiguous_format)
-        gp, gb = bias_mish_bwd(pre, g)
+        gp, gb, absmax = bias_mish_bwd(pre, g, want_absmax=True)
         gx = None
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()       # [cin][cout][3][3], taps reversed
-            gx = fused.conv3x3_raw(gp, wt, None, None, act=False)
+            gx = fused.conv3x3_dgrad(gp, weight.detach(), absmax)
         gw = None
         if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gp, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            if fused.wgrad_supported(weight, x.shape[-1]):
+                gw = fused.conv3x3_wgrad(x, gp, absmax)
+            else:
+                gw = torch.ops.aten.convolution_backward(gp, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
         return gx, gw, (gb if ctx.needs_input_grad[2] else None), (gp if ctx.has_res else None)
 
 

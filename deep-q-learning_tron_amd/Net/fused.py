@@ -110,6 +110,45 @@ def trunk(net, x, codes=False, plane4=0.0, math=None):
     return conv3x3(s, net.conv6, residual=idx, math=math)
 
 
+def conv3x3_dgrad(gp, weight, absmax=None):
+    """Input gradient of conv3x3(x, weight, padding=1): gp f32 [B, Cout, S, S] (the gradient at the convolution's output),
+    weight the FORWARD layer's [Cout, Cin, 3, 3] -> f32 [B, Cin, S, S] (tron_conv3x3_dgrad).  absmax: per-block maxima of
+    |gp| from bias_mish_bwd — the gradient is scaled by the power of two they give on its way into f16."""
+    L = nat.lib()
+    B, cout, side, _ = gp.shape
+    cin = weight.shape[1]
+    assert gp.is_contiguous() and gp.dtype == torch.float32 and tuple(weight.shape) == (cout, cin, 3, 3)
+    w = weight if weight.is_contiguous() else weight.contiguous()
+    gx = torch.empty(B, cin, side, side, dtype=torch.float32, device=gp.device)
+    ws = torch.empty(max(16, int(L.tron_conv3x3_workspace(cout, cin))), dtype=torch.uint8, device=gp.device)
+    with torch.cuda.device(gp.device):
+        nat.check(L.tron_conv3x3_dgrad(gp.data_ptr(), w.data_ptr(), None if absmax is None else absmax.data_ptr(),
+                                       0 if absmax is None else absmax.numel(), gx.data_ptr(), B, cin, cout, side,
+                                       ws.data_ptr(), torch.cuda.current_stream(gp.device).cuda_stream), "tron_conv3x3_dgrad")
+    return gx
+
+
+def wgrad_supported(weight, side):
+    return (side == 12 and weight.shape[0] in (32, 64) and weight.shape[1] in (3, 4, 32, 64) and tuple(weight.shape[2:]) == (3, 3)
+            and weight.is_cuda and weight.dtype == torch.float32)
+
+
+def conv3x3_wgrad(x, gp, absmax=None):
+    """Weight gradient of conv3x3(x, W, padding=1): x f32 [B, Cin, 12, 12], gp f32 [B, Cout, 12, 12] -> f32 [Cout, Cin, 3, 3]
+    (tron_conv3x3_wgrad; absmax as in conv3x3_dgrad, None = the library finds the maximum itself)."""
+    L = nat.lib()
+    B, cin, side, _ = x.shape
+    cout = gp.shape[1]
+    assert x.is_contiguous() and gp.is_contiguous() and x.dtype == gp.dtype == torch.float32 and gp.shape[0] == B
+    gw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
+    ws = torch.empty(int(L.tron_conv3x3_wgrad_workspace(cin, cout)), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        nat.check(L.tron_conv3x3_wgrad(x.data_ptr(), gp.data_ptr(), None if absmax is None else absmax.data_ptr(),
+                                       0 if absmax is None else absmax.numel(), gw.data_ptr(), B, cin, cout, side,
+                                       ws.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream), "tron_conv3x3_wgrad")
+    return gw
+
+
 def head_supported(net, side):
     """tron_dqn_head_fwd covers the reference's own geometry: 12x12 observations, 64*3*3 into fc1 (DQNNet.py:24,55)."""
     return (side == 12 and getattr(net, "flat", 0) == 576 and net.conv7.weight.shape == (64, 64, 7, 7)

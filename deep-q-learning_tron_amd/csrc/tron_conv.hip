@@ -457,7 +457,7 @@ extern "C" int tron_conv3x3_fwd(const void *in, int32_t in_fmt, const float *wei
     if (math == TRON_CONV_F16X3) {      // shapes the split kernel has no instantiation for take the f32 kernel
         if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15u)) return TRON_ERR_BAD_ARG;
         const int rc = tron_conv3x3_f16x3(in, in_fmt, weight, bias, residual, out, pre_out, batch, cin, cout, side,
-                                          plane4, apply_mish, workspace, out_split, st);
+                                          plane4, apply_mish, workspace, out_split, 0, nullptr, 0, st);
         if (rc != TRON_ERR_UNSUPPORTED || needs_f16) return rc;
     }
 #define TRON_CONV_CASE(S_)                                                                                                \
@@ -470,6 +470,22 @@ extern "C" int tron_conv3x3_fwd(const void *in, int32_t in_fmt, const float *wei
     TRON_CONV_CASE(26)
 #undef TRON_CONV_CASE
     return TRON_ERR_UNSUPPORTED;
+}
+
+// the data gradient of the same layer: the same convolution on the gradient with the weight's channel axes swapped and
+// its taps reversed; only the split-f16 kernel builds that weight image (k_split_weights)
+extern "C" int tron_conv3x3_dgrad(const float *grad_pre, const float *weight, const float *grad_absmax, int32_t n_absmax,
+                                  float *grad_in, int64_t batch, int32_t cin, int32_t cout, int32_t side, void *workspace,
+                                  void *stream)
+{
+    if (!grad_pre || !weight || !grad_in || !workspace || batch < 0 || (grad_absmax && n_absmax < 1)) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(grad_pre) | reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(grad_in) |
+         reinterpret_cast<uintptr_t>(workspace)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    if (batch == 0) return TRON_OK;
+    if ((cin != 32 && cin != 64) || cout % CIC != 0 || cout < CIC || cout > 64 || batch > (1ll << 24)) return TRON_ERR_UNSUPPORTED;
+    return tron_conv3x3_f16x3(grad_pre, TRON_CONV_IN_F32, weight, nullptr, nullptr, grad_in, nullptr, batch, cout, cin, side, 0.0f,
+                              0, workspace, nullptr, 1, grad_absmax, n_absmax, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t tron_conv3x3_workspace(int32_t cin, int32_t cout) { return tron_conv3x3_f16x3_workspace(cin, cout); }

@@ -95,7 +95,9 @@ __device__ __forceinline__ void split(float v, f16 &hi, f16 &lo)
 
 // W[cout][cin][3][3] f32 -> workspace f16 [chunk][half][tap 10][cout][16 ci]: per chunk exactly the LDS weight image
 // (hi image, then lo image; tenth tap and channels >= cin zero)
-__global__ void k_split_weights(const float *__restrict__ w, int cout, int cin, int nchunks, f16 *__restrict__ ws)
+// dgrad: `w` is the FORWARD layer's weight [cin][cout][3][3] and the image built is that of the data-gradient
+// convolution: channel axes swapped, taps reversed (W'[co][ci][tap] = W[ci][co][8 - tap]).
+__global__ void k_split_weights(const float *__restrict__ w, int cout, int cin, int nchunks, int dgrad, f16 *__restrict__ ws)
 {
     const int per_half = TAPS_PAD * cout * CIC;
     const int total = nchunks * per_half;
@@ -104,7 +106,9 @@ __global__ void k_split_weights(const float *__restrict__ w, int cout, int cin, 
         const int tap = r / (cout * CIC), r2 = r - tap * (cout * CIC);
         const int co = r2 / CIC, cl = r2 - co * CIC;
         const int ci = c * CIC + cl;
-        const float v = (tap < 9 && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.0f;
+        const float v = !(tap < 9 && ci < cin) ? 0.0f
+                        : dgrad            ? w[((size_t)ci * cout + co) * 9 + (8 - tap)]
+                                           : w[((size_t)co * cin + ci) * 9 + tap];
         f16 h, l;
         split(v, h, l);
         ws[(size_t)c * 2 * per_half + r] = h;
@@ -118,7 +122,7 @@ template <int S, int NT, bool SMALL>
 __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     const void *__restrict__ in, const f16 *__restrict__ ws, const float *__restrict__ bias,
     const float *__restrict__ res, float *__restrict__ out, float *__restrict__ pre_out, int B, int cin, float plane4,
-    int apply_mish, int in_fmt, unsigned char *__restrict__ out_s16)
+    int apply_mish, int in_fmt, unsigned char *__restrict__ out_s16, const float *__restrict__ absmax, int n_absmax)
 {
     const int in_codes = in_fmt == 1;
     const bool in_s16 = !SMALL && in_fmt == 2;
@@ -161,6 +165,26 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     pre_out = nullptr;
     if (tid == 0) { stamps[0] = __builtin_amdgcn_s_memtime(); stamps[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
+    // Scale of the f32 activations on their way into f16: 2^-6 for the network's activations; a gradient tensor (the
+    // data-gradient call) is orders of magnitude smaller and brings its per-block maxima along: the power of two that
+    // puts its largest magnitude in [2^13, 2^14) keeps the halves in f16's normal range.
+    float act_scale = ACT_SCALE, act_unscale = ACT_UNSCALE;
+    if (absmax) {
+        __shared__ float red[THREADS / 64];
+        float m = 0.0f;
+        for (int i = tid; i < n_absmax; i += THREADS) m = fmaxf(m, absmax[i]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < THREADS / 64; ++k) m = fmaxf(m, red[k]);
+        const int e = (int)((__float_as_uint(m) >> 23) & 255u) - 126;   // m = f 2^e, f in [0.5, 1)
+        if (m > 0.0f && e >= -100 && e <= 100) {
+            act_scale = __uint_as_float((uint32_t)(127 + 14 - e) << 23);
+            act_unscale = __uint_as_float((uint32_t)(127 - 14 + e) << 23);
+        }
+    }
     // zero both input buffers once: halo pixels (and, for SMALL, the absent channels) stay zero for good
     for (int i = tid; i < 2 * IN_BUF / 16; i += THREADS) reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
 
@@ -279,7 +303,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         f16x4 h_, l_;                                                                                                 \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                               \
             f16 hh_, ll_;                                                                                             \
-            split((im_ <= last_img ? rin[j_][e] : 0.0f) * ACT_SCALE, hh_, ll_);                                       \
+            split((im_ <= last_img ? rin[j_][e] : 0.0f) * act_scale, hh_, ll_);                                       \
             h_[e] = hh_;                                                                                              \
             l_[e] = ll_;                                                                                              \
         }                                                                                                             \
@@ -429,7 +453,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     for (int n = 0; n < NT; ++n) {
         const float bv = bias ? bias[wn * 16 * NT + n * 16 + li] : 0.0f;
 #pragma unroll
-        for (int t = 0; t < C::MT; ++t) acc0[t][n] = (acc0[t][n] + acc1[t][n] * LO_UNSCALE) * ACT_UNSCALE + bv;
+        for (int t = 0; t < C::MT; ++t) acc0[t][n] = (acc0[t][n] + acc1[t][n] * LO_UNSCALE) * act_unscale + bv;
     }
     if (res) {
         const float *res_wg = res + wg_base;
@@ -474,7 +498,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
 
 template <int S, int NT, bool SMALL>
 int launch(const void *in, const f16 *ws, const float *bias, const float *res, float *out, float *pre_out, int64_t B,
-           int cin, float plane4, int apply_mish, int in_fmt, void *out_s16, hipStream_t st)
+           int cin, float plane4, int apply_mish, int in_fmt, void *out_s16, const float *absmax, int n_absmax, hipStream_t st)
 {
     using C = Cfg<S>;
     constexpr size_t LDS_BYTES = 4 * (size_t)C::IN_HALF + 4 * (size_t)TAPS_PAD * 32 * NT * PITCH + 1024;
@@ -491,7 +515,7 @@ int launch(const void *in, const f16 *ws, const float *bias, const float *res, f
     }
     const int64_t groups = (B + C::P - 1) / C::P * C::NB;
     hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(THREADS), LDS_BYTES, st, in, ws, bias, res, out, pre_out, (int)B,
-                       cin, plane4, apply_mish, in_fmt, reinterpret_cast<unsigned char *>(out_s16));
+                       cin, plane4, apply_mish, in_fmt, reinterpret_cast<unsigned char *>(out_s16), absmax, n_absmax);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
@@ -506,24 +530,25 @@ int64_t tron_conv3x3_f16x3_workspace(int cin, int cout)
 // called by tron_conv3x3_fwd (tron_conv.hip) after it validated the arguments; TRON_ERR_UNSUPPORTED = not this shape
 int tron_conv3x3_f16x3(const void *in, int in_fmt, const float *weight, const float *bias, const float *residual,
                        float *out, float *pre_out, int64_t batch, int cin, int cout, int side, float plane4,
-                       int apply_mish, void *workspace, void *out_split, hipStream_t st)
+                       int apply_mish, void *workspace, void *out_split, int dgrad, const float *grad_absmax,
+                       int n_absmax, hipStream_t st)
 {
     const bool small = cin == 3 || cin == 4;
     if ((side != 12 && side != 26) || (!small && cin % CIC != 0) || !workspace) return TRON_ERR_UNSUPPORTED;
     f16 *ws = reinterpret_cast<f16 *>(workspace);
     const int nchunks = (cin + CIC - 1) / CIC;
     const int total = nchunks * TAPS_PAD * cout * CIC;
-    hipLaunchKernelGGL(k_split_weights, dim3((total + 255) / 256), dim3(256), 0, st, weight, cout, cin, nchunks, ws);
+    hipLaunchKernelGGL(k_split_weights, dim3((total + 255) / 256), dim3(256), 0, st, weight, cout, cin, nchunks, dgrad, ws);
 #define TRON_F16_CASE(S_)                                                                                                 \
     if (side == S_) {                                                                                                     \
         if (small)                                                                                                        \
             return launch<S_, 1, true>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_fmt,     \
-                                       out_split, st);                                                                    \
+                                       out_split, grad_absmax, n_absmax, st);                                                                    \
         if (cout == 64)                                                                                                   \
             return launch<S_, 2, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_fmt,    \
-                                        out_split, st);                                                                   \
+                                        out_split, grad_absmax, n_absmax, st);                                                                   \
         return launch<S_, 1, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_fmt,        \
-                                    out_split, st);                                                                       \
+                                    out_split, grad_absmax, n_absmax, st);                                                                       \
     }
     TRON_F16_CASE(12)
     TRON_F16_CASE(26)

@@ -84,11 +84,11 @@ __global__ __launch_bounds__(256) void k_bias_mish_bwd(const float *__restrict__
                                                        float *__restrict__ gx, float *__restrict__ partial, int N, int C,
                                                        int hw4)
 {
-    __shared__ float red[4];
+    __shared__ float red[4], redm[4];
     const int c = blockIdx.x / BIAS_SEGS, seg = blockIdx.x - c * BIAS_SEGS;
     const int n0 = (int)((long long)N * seg / BIAS_SEGS), n1 = (int)((long long)N * (seg + 1) / BIAS_SEGS);
     const int total = (n1 - n0) * hw4;
-    float acc = 0.0f;
+    float acc = 0.0f, amax = 0.0f;
     for (int i = threadIdx.x; i < total; i += 256) {
         const int n = n0 + i / hw4, q = i - (i / hw4) * hw4;
         const size_t o = ((size_t)n * C + c) * hw4 + q;
@@ -96,12 +96,22 @@ __global__ __launch_bounds__(256) void k_bias_mish_bwd(const float *__restrict__
         const float4 r = make_float4(mish_grad1(v.x, g.x), mish_grad1(v.y, g.y), mish_grad1(v.z, g.z), mish_grad1(v.w, g.w));
         reinterpret_cast<float4 *>(gx)[o] = r;
         acc += (r.x + r.y) + (r.z + r.w);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    for (int d = 32; d >= 1; d >>= 1) {
+        acc += __shfl_xor(acc, d);
+        amax = fmaxf(amax, __shfl_xor(amax, d));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = acc;
+        redm[threadIdx.x >> 6] = amax;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        partial[gridDim.x + blockIdx.x] = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));   // for the weight-gradient kernel's scale
+    }
 }
 
 __global__ void k_bias_grad_finish(const float *__restrict__ partial, float *__restrict__ bias_grad, int C)

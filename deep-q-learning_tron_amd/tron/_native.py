@@ -64,6 +64,9 @@ SIGNATURES = {
     "tron_synchronize": (C.c_int, [_vp]),
     "tron_conv3x3_fwd": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp]),
     "tron_conv3x3_workspace": (C.c_int64, [_i32, _i32]),
+    "tron_conv3x3_wgrad": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "tron_conv3x3_wgrad_workspace": (C.c_int64, [_i32, _i32]),
+    "tron_conv3x3_dgrad": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "tron_dqn_head_fwd": (C.c_int, [_vp, _i64, _i32] + [_vp] * 10 + [_vp, _vp, _vp, _vp]),
     "tron_dqn_head_workspace": (C.c_int64, [_i64, _i32]),
 }

@@ -252,7 +252,9 @@ int tron_bias_mish_fwd(float *y_pre, const float *bias, const float *residual, f
                        int32_t channels, int32_t hw, void *stream);
 
 /* Backward of that pass: grad_pre = grad_out * mish'(y_pre) and bias_grad[c] = sum over batch and positions of
- * grad_pre — one launch plus a tiny fixed-order finish (deterministic).  scratch: f32[channels * 64], caller-owned. */
+ * grad_pre — one launch plus a tiny fixed-order finish (deterministic).  scratch: f32[channels * 128], caller-owned:
+ * [0, channels*64) per-block bias sums, [channels*64, channels*128) per-block maxima of |grad_pre| (what
+ * tron_conv3x3_wgrad takes as grad_absmax, n_absmax = channels * 64).                                              */
 int tron_bias_mish_bwd(const float *y_pre, const float *grad_out, float *grad_pre, float *bias_grad, float *scratch,
                        int64_t batch, int32_t channels, int32_t hw, void *stream);
 
@@ -288,6 +290,28 @@ int tron_conv3x3_fwd(const void *in, int32_t in_fmt, const float *weight, const 
                      int32_t cout, int32_t side, float plane4, int32_t apply_mish, int32_t math, void *workspace,
                      void *out_split, void *stream);
 int64_t tron_conv3x3_workspace(int32_t cin, int32_t cout);
+
+/* The weight gradient of the same convolutions (loss.backward() through conv1..conv6, DDQN.py:148):
+ * grad_weight[co][ci][ky][kx] = sum over b, y, x of grad_pre[b][co][y][x] * in[b][ci][y+ky-1][x+kx-1], overwritten (not
+ * accumulated), f32[cout][cin][3][3] like nn.Conv2d's weight.grad.  in: f32[batch][cin][side][side] (the layer's input),
+ * grad_pre: f32[batch][cout][side][side] (the gradient at the convolution's output, before bias / activation — what
+ * tron_bias_mish_bwd writes).  Split-f16 matrix-core arithmetic (TRON_CONV_F16X3's), f32 accumulation, sums in a fixed
+ * order (deterministic).  grad_absmax: n_absmax per-block maxima of |grad_pre| on the device (tron_bias_mish_bwd leaves
+ * them in its scratch) used to scale the gradient into f16's normal range, or NULL: a pre-pass finds the maximum.
+ * Supported: side 12; cin 3, 4, 32 or 64; cout 32 or 64; anything else TRON_ERR_UNSUPPORTED.  workspace: at least
+ * tron_conv3x3_wgrad_workspace(cin, cout) bytes; all buffers 16-byte aligned.                                    */
+int tron_conv3x3_wgrad(const float *in, const float *grad_pre, const float *grad_absmax, int32_t n_absmax,
+                       float *grad_weight, int64_t batch, int32_t cin, int32_t cout, int32_t side, void *workspace,
+                       void *stream);
+int64_t tron_conv3x3_wgrad_workspace(int32_t cin, int32_t cout);
+/* ... and the input gradient: grad_in[b][ci][y][x] = sum over co, ky, kx of grad_pre[b][co][y-ky+1][x-kx+1] *
+ * weight[co][ci][ky][kx] — the same convolution run on the gradient with the weight's channel axes swapped and its taps
+ * reversed (the kernel reads the forward layer's weight f32[cout][cin][3][3] that way; no transposed copy).  Same
+ * arithmetic and scaling as the weight gradient (grad_absmax NULL: the activations' fixed scale).  side 12 or 26, cin 32
+ * or 64, cout 16..64 in steps of 16; workspace: tron_conv3x3_workspace(cout, cin) bytes.                          */
+int tron_conv3x3_dgrad(const float *grad_pre, const float *weight, const float *grad_absmax, int32_t n_absmax,
+                       float *grad_in, int64_t batch, int32_t cin, int32_t cout, int32_t side, void *workspace,
+                       void *stream);
 
 /* ---- the rest of the DQN net after the 3x3 trunk (Net/DQNNet.py:52-63) ------------------------------------------
  * q = actor2(mish(actor1(mish(fc2(mish(fc1(flatten(mish(conv7(pool(x)))))))))))  for gradient-free forwards
