@@ -29,14 +29,20 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16;
+typedef __attribute__((address_space(1))) const f32x4 gvec4;      // global memory, explicitly
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int SIDE = 12, HW = SIDE * SIDE, ROWP = 14, IMG_K = 192, SLABS_IMG = IMG_K / 32, MARGIN = 16;
 constexpr int THREADS = 256, GRID_MAX = 256, STAGE2 = 8, ABSMAX_BLOCKS = 1024;
 constexpr float IN_SCALE = 1.0f / 64.0f, LO_SCALE = 2048.0f;
+#ifndef TRON_WG_ABLATE       // diagnostic builds: 1 no MFMA slabs, 2 no staging inside the loop, 3 no global loads
+#define TRON_WG_ABLATE 0
+#endif
 
-constexpr int odd16(int bytes) { return (((bytes + 15) / 16) | 1) * 16; }    // row pitch: an odd number of 16-byte units
+// row pitch for ds_read_b128 by (row = lane % 16, 16-byte column = lane / 16): 32 mod 64 bytes is conflict-free with the
+// instruction's lane groups (MI355X guide, LDS table); any other multiple of 16 is two-way
+constexpr int pitch_for(int bytes) { return (bytes + 31) / 64 * 64 + 32; }
 
 constexpr int COT = 2;                                         // 16-channel output tiles per wave: 32 channels per workgroup
 
@@ -44,9 +50,10 @@ template <int CIT, int IMGS>
 struct Cfg {
     static constexpr int KSPLIT = 4 / CIT;                     // waves sharing an input tile split the slabs
     static constexpr int SL = SLABS_IMG * IMGS / KSPLIT;       // slabs per wave per round
-    static constexpr int GP_PITCH = odd16(IMGS * IMG_K * 2), IN_PITCH = odd16((IMGS * IMG_K + 2 * MARGIN) * 2);
+    static constexpr int GP_PITCH = pitch_for(IMGS * IMG_K * 2), IN_PITCH = pitch_for((IMGS * IMG_K + 2 * MARGIN) * 2);
     static constexpr int GP_HALF = COT * 16 * GP_PITCH, IN_HALF = CIT * 16 * IN_PITCH;
-    static constexpr int LDS = 2 * GP_HALF + 2 * IN_HALF;
+    static constexpr int LDS = 2 * GP_HALF + 2 * IN_HALF;      // operands; a 64-byte dump slot per thread follows
+    static constexpr int LDS_ALL = LDS + THREADS * 64;
     static constexpr int GP_ITEMS = IMGS * COT * 16 * SIDE, IN_ITEMS = IMGS * CIT * 16 * SIDE;
     static constexpr int NIT = (GP_ITEMS + IN_ITEMS + THREADS - 1) / THREADS;
     static_assert(SLABS_IMG * IMGS % KSPLIT == 0, "slabs must split evenly");
@@ -89,6 +96,15 @@ __device__ __forceinline__ float grad_scale(const float *__restrict__ absmax, in
     return __uint_as_float((uint32_t)(127 + 14 - e) << 23);            // 2^(14 - e)
 }
 
+#ifdef TRON_WG_STAMPS        // diagnostic build only (scripts/wgrad_stamps.py): per-workgroup clocks, read back by tron_wgrad_stamps
+__device__ unsigned long long g_stamps[GRID_MAX * 8];
+#define TRON_WG_STAMP(i_) if (tid == 0) { g_stamps[blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime(); }
+#define TRON_WG_STAMP_RT(i_) if (tid == 0) { g_stamps[blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define TRON_WG_STAMP(i_)
+#define TRON_WG_STAMP_RT(i_)
+#endif
+
 template <int CIT, int IMGS>
 __global__ __launch_bounds__(THREADS, 1) void k_wgrad(const float *__restrict__ in, const float *__restrict__ gp,
                                                       const float *__restrict__ absmax, int n_absmax,
@@ -106,6 +122,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_wgrad(const float *__restrict__ 
     const int cit = wave % CIT, ks = wave / CIT;
 
     for (int i = tid * 16; i < C::LDS; i += THREADS * 16) *reinterpret_cast<f32x4 *>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    TRON_WG_STAMP(0)
     const float gscale = grad_scale(absmax, n_absmax, red);            // (contains the barrier after the clear)
     const int in_items = IMGS * cin * SIDE;
 
@@ -118,108 +135,211 @@ __global__ __launch_bounds__(THREADS, 1) void k_wgrad(const float *__restrict__ 
             acc1[t][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 
-    // staging items: one 12-float row of one channel of one image (gradient rows first, then input rows)
-    f32x4 pf[C::NIT][3];
+    // Staging items: one 12-float row of one channel of one image (gradient rows first, then input rows); thread i owns
+    // items i, i + THREADS, ...  An item's source (round 0) and LDS destination are the same in every round and are
+    // computed once; its half offset, image stride, scale and image index follow from "gradient or input?", a compare of
+    // tid with a constant per k, recomputed at each use instead of held in registers across the MFMA loop.  Surplus
+    // items read the tensor's first row and write a per-thread dump slot; images past the batch are multiplied by a
+    // zero scale.  No branches: the pieces can be scheduled between MFMAs.
+    const float *it_src[C::NIT];
+    int it_dst[C::NIT];
+#define TRON_WG_IS_GP(k_) (tid + (k_) * THREADS < C::GP_ITEMS)
+#define TRON_WG_REAL(k_) (tid + (k_) * THREADS < C::GP_ITEMS + in_items)
+#define TRON_WG_J(k_) (IMGS == 1 ? 0 : TRON_WG_IS_GP(k_) ? (tid + (k_) * THREADS) / (COUT * SIDE) : (tid + (k_) * THREADS - C::GP_ITEMS) / (cin * SIDE))
+#pragma unroll
+    for (int k = 0; k < C::NIT; ++k) {
+        const int it = tid + k * THREADS;
+        it_src[k] = gp;
+        it_dst[k] = C::LDS + tid * 64 - (TRON_WG_IS_GP(k) ? 0 : 2 * C::GP_HALF);   // dump: hi at +0, lo at +32 (TRON_WG_STORE)
+        if (it < C::GP_ITEMS) {
+            const int j = it / (COUT * SIDE), rem = it - j * (COUT * SIDE), c = rem / SIDE, y = rem - c * SIDE;
+            it_src[k] = gp + ((size_t)(j * cout + co0) * SIDE + rem) * SIDE;
+            it_dst[k] = c * C::GP_PITCH + (j * IMG_K + y * ROWP) * 2;              // relative to gp_h
+        } else if (it - C::GP_ITEMS < in_items) {
+            const int i2 = it - C::GP_ITEMS, j = i2 / (cin * SIDE), rem = i2 - j * (cin * SIDE);
+            const int c = rem / SIDE, y = rem - c * SIDE;
+            it_src[k] = in + ((size_t)j * cin * SIDE + rem) * SIDE;
+            it_dst[k] = c * C::IN_PITCH + (MARGIN + j * IMG_K + y * ROWP) * 2;     // relative to in_h
+        }
+    }
+    f32x4 pf[C::NIT][3];                                                 // raw rows in flight
+    uint32_t cvh[C::NIT][6], cvl[C::NIT][6];                             // the same rows as packed f16 halves
+    // (an explicit global-memory pointer: as a generic one these are flat_loads, whose lgkmcnt entangles the LDS waits of
+    // the MFMA loop with the HBM latency)
 #define TRON_WG_LOAD(round_)                                                                                             \
     _Pragma("unroll") for (int k_ = 0; k_ < C::NIT; ++k_) {                                                              \
-        const int it_ = tid + k_ * THREADS;                                                                              \
-        const float *src_ = nullptr;                                                                                     \
-        if (it_ < C::GP_ITEMS) {                                                                                         \
-            const int j_ = it_ / (COUT * SIDE), rem_ = it_ - j_ * (COUT * SIDE);                                         \
-            const int64_t img_ = (int64_t)(round_) * IMGS + j_;                                                          \
-            if (img_ < batch) src_ = gp + ((img_ * cout + co0) * SIDE + rem_) * SIDE;                                            \
-        } else if (it_ - C::GP_ITEMS < in_items) {                                                                       \
-            const int i2_ = it_ - C::GP_ITEMS, j_ = i2_ / (cin * SIDE), rem_ = i2_ - j_ * (cin * SIDE);                  \
-            const int64_t img_ = (int64_t)(round_) * IMGS + j_;                                                          \
-            if (img_ < batch) src_ = in + (img_ * cin * SIDE + rem_) * SIDE;                                             \
-        }                                                                                                                \
-        if (src_) {                                                                                                      \
-            pf[k_][0] = reinterpret_cast<const f32x4 *>(src_)[0];                                                        \
-            pf[k_][1] = reinterpret_cast<const f32x4 *>(src_)[1];                                                        \
-            pf[k_][2] = reinterpret_cast<const f32x4 *>(src_)[2];                                                        \
-        } else {                                                                                                         \
-            pf[k_][0] = pf[k_][1] = pf[k_][2] = (f32x4){0.f, 0.f, 0.f, 0.f};                                             \
-        }                                                                                                                \
+        const bool ok_ = TRON_WG_REAL(k_) && (int64_t)(round_) * IMGS + TRON_WG_J(k_) < batch;                           \
+        const int stride_ = IMGS * HW * (TRON_WG_IS_GP(k_) ? cout : cin);                                                \
+        const gvec4 *src_ = (const gvec4 *)(uintptr_t)(ok_ ? it_src[k_] + (int64_t)(round_) * stride_ : gp);             \
+        pf[k_][0] = src_[0];                                                                                             \
+        pf[k_][1] = src_[1];                                                                                             \
+        pf[k_][2] = src_[2];                                                                                             \
+    }
+    // one third of an item: 4 floats -> 2 + 2 packed dwords; piece p_ = 3 * item + third
+#define TRON_WG_CONVERT_PIECE(round_, p_)                                                                                \
+    {                                                                                                                    \
+        constexpr int k_ = (p_) / 3, q_ = (p_) % 3;                                                                      \
+        const float sc_ = ((int64_t)(round_) * IMGS + TRON_WG_J(k_) < batch) ? (TRON_WG_IS_GP(k_) ? gscale : IN_SCALE) : 0.0f; \
+        const f32x4 v_ = pf[k_][q_] * sc_;                                                                               \
+        const f16 h0_ = (f16)v_[0], h1_ = (f16)v_[1], h2_ = (f16)v_[2], h3_ = (f16)v_[3];                                \
+        const f16 l0_ = (f16)((v_[0] - (float)h0_) * LO_SCALE), l1_ = (f16)((v_[1] - (float)h1_) * LO_SCALE);            \
+        const f16 l2_ = (f16)((v_[2] - (float)h2_) * LO_SCALE), l3_ = (f16)((v_[3] - (float)h3_) * LO_SCALE);            \
+        cvh[k_][2 * q_] = pack2(h0_, h1_);                                                                               \
+        cvh[k_][2 * q_ + 1] = pack2(h2_, h3_);                                                                           \
+        cvl[k_][2 * q_] = pack2(l0_, l1_);                                                                               \
+        cvl[k_][2 * q_ + 1] = pack2(l2_, l3_);                                                                           \
     }
 #define TRON_WG_STORE()                                                                                                  \
     _Pragma("unroll") for (int k_ = 0; k_ < C::NIT; ++k_) {                                                              \
-        const int it_ = tid + k_ * THREADS;                                                                              \
-        unsigned char *dh_ = nullptr;                                                                                    \
-        int half_ = 0;                                                                                                   \
-        float sc_ = gscale;                                                                                              \
-        if (it_ < C::GP_ITEMS) {                                                                                         \
-            const int j_ = it_ / (COUT * SIDE), rem_ = it_ - j_ * (COUT * SIDE), c_ = rem_ / SIDE, y_ = rem_ - c_ * SIDE; \
-            dh_ = gp_h + c_ * C::GP_PITCH + (j_ * IMG_K + y_ * ROWP) * 2;                                                \
-            half_ = C::GP_HALF;                                                                                          \
-        } else if (it_ - C::GP_ITEMS < in_items) {                                                                       \
-            const int i2_ = it_ - C::GP_ITEMS, j_ = i2_ / (cin * SIDE), rem_ = i2_ - j_ * (cin * SIDE);                  \
-            const int c_ = rem_ / SIDE, y_ = rem_ - c_ * SIDE;                                                           \
-            dh_ = in_h + c_ * C::IN_PITCH + (MARGIN + j_ * IMG_K + y_ * ROWP) * 2;                                       \
-            half_ = C::IN_HALF;                                                                                          \
-            sc_ = IN_SCALE;                                                                                              \
-        }                                                                                                                \
-        if (dh_) {                                                                                                       \
-            _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                                                           \
-                const f32x4 v_ = pf[k_][q_] * sc_;                                                                       \
-                const f16 h0_ = (f16)v_[0], h1_ = (f16)v_[1], h2_ = (f16)v_[2], h3_ = (f16)v_[3];                        \
-                const f16 l0_ = (f16)((v_[0] - (float)h0_) * LO_SCALE), l1_ = (f16)((v_[1] - (float)h1_) * LO_SCALE);    \
-                const f16 l2_ = (f16)((v_[2] - (float)h2_) * LO_SCALE), l3_ = (f16)((v_[3] - (float)h3_) * LO_SCALE);    \
-                reinterpret_cast<uint32_t *>(dh_)[2 * q_] = pack2(h0_, h1_);                                             \
-                reinterpret_cast<uint32_t *>(dh_)[2 * q_ + 1] = pack2(h2_, h3_);                                         \
-                reinterpret_cast<uint32_t *>(dh_ + half_)[2 * q_] = pack2(l0_, l1_);                                     \
-                reinterpret_cast<uint32_t *>(dh_ + half_)[2 * q_ + 1] = pack2(l2_, l3_);                                 \
-            }                                                                                                            \
+        const bool gp_ = TRON_WG_IS_GP(k_);                                                                              \
+        uint32_t *dh_ = reinterpret_cast<uint32_t *>((gp_ ? gp_h : in_h) + it_dst[k_]);                                  \
+        uint32_t *dl_ = reinterpret_cast<uint32_t *>((gp_ ? gp_h : in_h) + it_dst[k_] +                                  \
+                                                     (!TRON_WG_REAL(k_) ? 32 : gp_ ? C::GP_HALF : C::IN_HALF));          \
+        _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                                                               \
+            dh_[q_] = cvh[k_][q_];                                                                                       \
+            dl_[q_] = cvl[k_][q_];                                                                                       \
         }                                                                                                                \
     }
-#define TRON_WG_TAP(tap_, idx_)                                                                                          \
+
+    // ---- the MFMA loop.  One wave per SIMD: nobody else covers an LDS wait, so every operand is read one tap GROUP
+    // (three taps = 18 MFMAs) before its first use, into registers whose previous contents are dead by then, and
+    // sched_barriers keep the compiler from sinking the reads down to their uses.  A wave's input window slides along
+    // one contiguous strip: slab s covers elements [32 s - 16, 32 s + 24) (+ 8 g) as blocks 0..4 of 8 elements, block 0
+    // of slab s + 1 is block 4 of slab s.  Group 0 (ky = 0: window indices 1, 2, 3) uses blocks 0-1, group 1 (15, 16, 17)
+    // blocks 1-3, group 2 (29, 30, 31) blocks 3-4.
+#define TRON_WG_BLOCK(k_, s_)                                                                                            \
     {                                                                                                                    \
-        const f16x8 bh_ = window_frag<idx_>(Dh), bl_ = window_frag<idx_>(Dl);                                            \
-        _Pragma("unroll") for (int t = 0; t < COT; ++t)                                                                  \
-            acc0[t][tap_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh_, acc0[t][tap_], 0, 0, 0);                  \
-        _Pragma("unroll") for (int t = 0; t < COT; ++t)                                                                  \
-            acc1[t][tap_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl_, acc1[t][tap_], 0, 0, 0);                  \
-        _Pragma("unroll") for (int t = 0; t < COT; ++t)                                                                  \
-            acc1[t][tap_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh_, acc1[t][tap_], 0, 0, 0);                  \
+        const u32x4 vh_ = *reinterpret_cast<const u32x4 *>(b_h + (s_) * 64 + (k_) * 16);                                 \
+        const u32x4 vl_ = *reinterpret_cast<const u32x4 *>(b_l + (s_) * 64 + (k_) * 16);                                 \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                  \
+            Dh[4 * (k_) + c] = vh_[c];                                                                                   \
+            Dl[4 * (k_) + c] = vl_[c];                                                                                   \
+        }                                                                                                                \
     }
+#define TRON_WG_A(b_, s_)                                                                                                \
+    _Pragma("unroll") for (int t = 0; t < COT; ++t) {                                                                    \
+        ah[b_][t] = *reinterpret_cast<const f16x8 *>(a_h + t * 16 * C::GP_PITCH + (s_) * 64);                            \
+        al[b_][t] = *reinterpret_cast<const f16x8 *>(a_l + t * 16 * C::GP_PITCH + (s_) * 64);                            \
+    }
+    // A tap group: taps tap0_ .. tap0_ + 2 (tap (ky, kx) is shift 14 (ky - 1) + (kx - 1) = window index 16 + shift), operands
+    // fh / fl cut from the window beforehand.  The three products of a tap are issued group-wide in three phases with
+    // scheduling barriers between them, hi*lo first and lo*hi last: both add to the same accumulator, a dependent MFMA
+    // issues 48 cycles after its producer (an independent one 16), and left alone the compiler puts them back to back.
+    // Phase 3 also cuts the NEXT group's operands (nidx0_: its first window index) out of the blocks read during phase 1.
+    // tp_: the group's first tap-step of the round; the staging pieces that ride in the taps' shadow are counted from it.
+#define TRON_WG_PIECE_AT(tp_)                                                                                            \
+    {                                                                                                                    \
+        constexpr int piece_ = (tp_) - (C::SL * 9 - C::NIT * 3);                                                         \
+        if constexpr (piece_ >= 0 && TRON_WG_ABLATE != 2) TRON_WG_CONVERT_PIECE(round + wgs, piece_ >= 0 ? piece_ : 0)   \
+    }
+#define TRON_WG_PHASE_SCHED(reads_)                                                                                      \
+    __builtin_amdgcn_sched_group_barrier(0x100, reads_, 0);                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3 * COT; ++i_) {                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                               \
+    }                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+#define TRON_WG_CUT(idx0_)                                                                                               \
+    fh[0] = window_frag<idx0_>(Dh); fh[1] = window_frag<(idx0_) + 1>(Dh); fh[2] = window_frag<(idx0_) + 2>(Dh);          \
+    fl[0] = window_frag<idx0_>(Dl); fl[1] = window_frag<(idx0_) + 1>(Dl); fl[2] = window_frag<(idx0_) + 2>(Dl);
+#define TRON_WG_GROUP(b_, tap0_, tp_, reads_, nidx0_, slide_)                                                            \
+    {                                                                                                                    \
+        TRON_WG_PIECE_AT(tp_)                                                                                            \
+        _Pragma("unroll") for (int t = 0; t < COT; ++t)                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                                \
+                acc1[t][(tap0_) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b_][t], fl[j], acc1[t][(tap0_) + j], 0, 0, 0); \
+        TRON_WG_PHASE_SCHED(reads_)                                                                                      \
+        TRON_WG_PIECE_AT((tp_) + 1)                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < COT; ++t)                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                                \
+                acc0[t][(tap0_) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b_][t], fh[j], acc0[t][(tap0_) + j], 0, 0, 0); \
+        TRON_WG_PHASE_SCHED(0)                                                                                           \
+        TRON_WG_PIECE_AT((tp_) + 2)                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < COT; ++t)                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                                \
+                acc1[t][(tap0_) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b_][t], fh[j], acc1[t][(tap0_) + j], 0, 0, 0); \
+        if constexpr ((nidx0_) > 0) {                                                                                    \
+            if constexpr (slide_) {                           /* the window slides: block 4 is the next slab's block 0 */ \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
+                    Dh[c] = Dh[16 + c];                                                                                  \
+                    Dl[c] = Dl[16 + c];                                                                                  \
+                }                                                                                                        \
+            }                                                                                                            \
+            TRON_WG_CUT(nidx0_)                                                                                          \
+        }                                                                                                                \
+        TRON_WG_PHASE_SCHED(0)                                                                                           \
+    }
+#define TRON_WG_SLAB(sl_)                                                                                                \
+    if constexpr ((sl_) < C::SL && TRON_WG_ABLATE != 1) {                                                                \
+        constexpr int b_ = (sl_) & 1;                                                                                    \
+        constexpr bool more_ = (sl_) + 1 < C::SL;                                                                        \
+        TRON_WG_BLOCK(2, s0 + (sl_)) TRON_WG_BLOCK(3, s0 + (sl_))                                                        \
+        TRON_WG_GROUP(b_, 0, (sl_) * 9, 4, 15, false)                                                                    \
+        TRON_WG_BLOCK(4, s0 + (sl_))                                                                                     \
+        TRON_WG_GROUP(b_, 3, (sl_) * 9 + 3, 2, 29, false)                                                                \
+        if constexpr (more_) {                                                                                           \
+            TRON_WG_A(b_ ^ 1, s0 + (sl_) + 1)                                                                            \
+            TRON_WG_BLOCK(1, s0 + (sl_) + 1)                  /* block 1 is dead after group 1 */                        \
+        }                                                                                                                \
+        TRON_WG_GROUP(b_, 6, (sl_) * 9 + 6, more_ ? 2 * COT + 2 : 0, more_ ? 1 : 0, true)                                \
+    }
+    static_assert(C::SL * 9 >= C::NIT * 3 && C::SL <= 6 && C::NIT <= 5, "one staging piece per tap");
+
+    const unsigned char *a_h = gp_h + li * C::GP_PITCH + g * 16, *a_l = a_h + C::GP_HALF;
+    const unsigned char *b_h = in_h + (cit * 16 + li) * C::IN_PITCH + g * 16, *b_l = b_h + C::IN_HALF;
+    const int s0 = ks * C::SL;
+    f16x8 ah[2][COT], al[2][COT];
+    uint32_t Dh[20], Dl[20];                                             // the window: blocks 0..4, four dwords each
+    f16x8 fh[3], fl[3];                                                  // the current tap group's operands
 
     int round = wg;
     TRON_WG_LOAD(round)
-    for (; round < nrounds; round += wgs) {
-        __syncthreads();                                                 // the previous round's operands are consumed
-        TRON_WG_STORE()
-        __syncthreads();
-        TRON_WG_LOAD(round + wgs)                             // in flight under the MFMAs (zeros past the end)
-        const unsigned char *a_h = gp_h + li * C::GP_PITCH + g * 16, *a_l = a_h + C::GP_HALF;
-        const unsigned char *b_h = in_h + (cit * 16 + li) * C::IN_PITCH + g * 16, *b_l = b_h + C::IN_HALF;
-#pragma unroll
-        for (int sl = 0; sl < C::SL; ++sl) {
-            const int s = ks * C::SL + sl;
-            f16x8 ah[COT], al[COT];
-#pragma unroll
-            for (int t = 0; t < COT; ++t) {
-                ah[t] = *reinterpret_cast<const f16x8 *>(a_h + t * 16 * C::GP_PITCH + s * 64);
-                al[t] = *reinterpret_cast<const f16x8 *>(a_l + t * 16 * C::GP_PITCH + s * 64);
-            }
-            uint32_t Dh[20], Dl[20];                                     // elements [32 s + 8 g - 16, + 40) of the input rows
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const u32x4 vh = *reinterpret_cast<const u32x4 *>(b_h + s * 64 + k * 16);
-                const u32x4 vl = *reinterpret_cast<const u32x4 *>(b_l + s * 64 + k * 16);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    Dh[4 * k + c] = vh[c];
-                    Dl[4 * k + c] = vl[c];
-                }
-            }
-            // tap (ky, kx): shift 14 (ky - 1) + (kx - 1), window index 16 + shift
-            TRON_WG_TAP(0, 1) TRON_WG_TAP(1, 2) TRON_WG_TAP(2, 3)
-            TRON_WG_TAP(3, 15) TRON_WG_TAP(4, 16) TRON_WG_TAP(5, 17)
-            TRON_WG_TAP(6, 29) TRON_WG_TAP(7, 30) TRON_WG_TAP(8, 31)
-        }
+    {
+        TRON_WG_CONVERT_PIECE(round, 0) TRON_WG_CONVERT_PIECE(round, 1) TRON_WG_CONVERT_PIECE(round, 2)
+        if constexpr (C::NIT > 1) { TRON_WG_CONVERT_PIECE(round, 3) TRON_WG_CONVERT_PIECE(round, 4) TRON_WG_CONVERT_PIECE(round, 5) }
+        if constexpr (C::NIT > 2) { TRON_WG_CONVERT_PIECE(round, 6) TRON_WG_CONVERT_PIECE(round, 7) TRON_WG_CONVERT_PIECE(round, 8) }
+        if constexpr (C::NIT > 3) { TRON_WG_CONVERT_PIECE(round, 9) TRON_WG_CONVERT_PIECE(round, 10) TRON_WG_CONVERT_PIECE(round, 11) }
+        if constexpr (C::NIT > 4) { TRON_WG_CONVERT_PIECE(round, 12) TRON_WG_CONVERT_PIECE(round, 13) TRON_WG_CONVERT_PIECE(round, 14) }
     }
+    TRON_WG_STAMP(1) TRON_WG_STAMP_RT(2)
+#ifdef TRON_WG_STAMPS
+    unsigned long long t_stage = 0, t_mark = 0;
+#endif
+    for (; round < nrounds; round += wgs) {
+#ifdef TRON_WG_STAMPS
+        t_mark = __builtin_amdgcn_s_memtime();
+#endif
+        __syncthreads();                                                 // the previous round's operands are consumed
+        if (TRON_WG_ABLATE != 2) { TRON_WG_STORE() }
+        __syncthreads();
+#ifdef TRON_WG_STAMPS
+        t_stage += __builtin_amdgcn_s_memtime() - t_mark;
+#endif
+        if (TRON_WG_ABLATE != 2 && TRON_WG_ABLATE != 3) { TRON_WG_LOAD(round + wgs) }   // lands under the first taps' MFMAs
+        if (TRON_WG_ABLATE != 1) {
+            TRON_WG_A(0, s0) TRON_WG_BLOCK(0, s0) TRON_WG_BLOCK(1, s0)
+            TRON_WG_CUT(1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        TRON_WG_SLAB(0) TRON_WG_SLAB(1) TRON_WG_SLAB(2) TRON_WG_SLAB(3) TRON_WG_SLAB(4) TRON_WG_SLAB(5)
+    }
+    TRON_WG_STAMP(3) TRON_WG_STAMP_RT(4)
+#ifdef TRON_WG_STAMPS
+    if (tid == 0) g_stamps[blockIdx.x * 8 + 5] = t_stage;
+#endif
+#undef TRON_WG_IS_GP
+#undef TRON_WG_REAL
+#undef TRON_WG_J
 #undef TRON_WG_LOAD
+#undef TRON_WG_CONVERT_PIECE
 #undef TRON_WG_STORE
-#undef TRON_WG_TAP
+#undef TRON_WG_BLOCK
+#undef TRON_WG_A
+#undef TRON_WG_PIECE_AT
+#undef TRON_WG_GROUP
+#undef TRON_WG_PHASE_SCHED
+#undef TRON_WG_CUT
+#undef TRON_WG_SLAB
 
     // D row = 4 g + r = co within the tile, column = li = ci within the tile
     const float unscale = 64.0f / gscale;
@@ -285,7 +405,7 @@ int launch(const float *in, const float *gp, const float *absmax, int n_absmax, 
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
     auto kern = k_wgrad<CIT, IMGS>;
     if (!(prepared & (1ull << (dev & 63)))) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_ALL) != hipSuccess)
             (void)hipGetLastError();
         prepared |= 1ull << (dev & 63);
     }
@@ -294,7 +414,7 @@ int launch(const float *in, const float *gp, const float *absmax, int n_absmax, 
     const int nrounds = (int)((batch + IMGS - 1) / IMGS);
     const int wgs = nrounds < GRID_MAX / nhalves ? nrounds : GRID_MAX / nhalves;   // workgroups per output half
     float *partial = reinterpret_cast<float *>(ws + p.partial), *stage2 = reinterpret_cast<float *>(ws + p.stage2);
-    hipLaunchKernelGGL(kern, dim3(wgs * nhalves), dim3(THREADS), C::LDS, st, in, gp, absmax, n_absmax, partial, (int)batch, cin,
+    hipLaunchKernelGGL(kern, dim3(wgs * nhalves), dim3(THREADS), C::LDS_ALL, st, in, gp, absmax, n_absmax, partial, (int)batch, cin,
                        cout, nrounds);
     const int nparts = wgs * C::KSPLIT;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 255) / 256, STAGE2), dim3(256), 0, st, partial, nparts, STAGE2, W, stage2);
@@ -303,6 +423,13 @@ int launch(const float *in, const float *gp, const float *absmax, int n_absmax, 
 }
 
 }  // namespace
+
+#ifdef TRON_WG_STAMPS
+extern "C" int tron_wgrad_stamps(unsigned long long *host_dst)
+{
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * GRID_MAX * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int64_t tron_conv3x3_wgrad_workspace(int32_t cin, int32_t cout)
 {
