@@ -347,7 +347,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
             }                                                                                                         \
             /* three-deep register pipeline over the M tiles: tile t+2's fragments are requested while tile t's MFMAs */ \
             /* issue — one tile-step (96 cycles) does not cover the LDS latency under load                           */ \
-            f16x8 ah[3], al[3];                                                                                       \
+            /* The lo*hi product adds to the accumulator the hi*lo product wrote, and a dependent MFMA issues 48 cycles   */ \
+            /* after its producer (an independent one 16): tile t's lo*hi MFMAs are issued two tile-steps later, so that  */ \
+            /* a whole step lies between the pair wherever the compiler puts them inside a step (ring of 5 fragments).    */ \
+            f16x8 ah[5], al[5];                                                                                       \
             const int toff = tap_offset(s);                                                                           \
             ah[0] = *reinterpret_cast<const f16x8 *>(in_h + a_base[0] + toff);                                        \
             al[0] = *reinterpret_cast<const f16x8 *>(in_l + a_base[0] + toff);                                        \
@@ -355,8 +358,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
             al[1] = *reinterpret_cast<const f16x8 *>(in_l + a_base[1] + toff);                                        \
             _Pragma("unroll") for (int t = 0; t < C::MT; ++t) {                                                       \
                 if (t + 2 < C::MT && TRON_F16_ABLATE != 2) {                                                          \
-                    ah[(t + 2) % 3] = *reinterpret_cast<const f16x8 *>(in_h + a_base[t + 2] + toff);                  \
-                    al[(t + 2) % 3] = *reinterpret_cast<const f16x8 *>(in_l + a_base[t + 2] + toff);                  \
+                    ah[(t + 2) % 5] = *reinterpret_cast<const f16x8 *>(in_h + a_base[t + 2] + toff);                  \
+                    al[(t + 2) % 5] = *reinterpret_cast<const f16x8 *>(in_l + a_base[t + 2] + toff);                  \
                 }                                                                                                     \
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
                 if (STAGE_ && t < C::MT_MIN && TRON_F16_ABLATE != 1 && TRON_F16_ABLATE != 3) { /* staging rides in the shadow of this tile's MFMAs */ \
@@ -373,15 +376,25 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
                         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                            \
                     }                                                                                                 \
                 }                                                                                                     \
+                if (t >= 2 && (t - 2 < C::MT_MIN || my_mt > t - 2)) {                                                 \
+                    _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                    \
+                        acc1[t >= 2 ? t - 2 : 0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[(t + 3) % 5], bh[n], acc1[t >= 2 ? t - 2 : 0][n], 0, 0, 0); \
+                }                                                                                                     \
                 if (t < C::MT_MIN || my_mt > t) {                                                                     \
                     _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                  \
-                        acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t % 3], bh[n], acc0[t][n], 0, 0, 0);   \
-                        acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t % 3], bl[n], acc1[t][n], 0, 0, 0);   \
-                        acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t % 3], bh[n], acc1[t][n], 0, 0, 0);   \
+                        acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t % 5], bl[n], acc1[t][n], 0, 0, 0);   \
+                        acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t % 5], bh[n], acc0[t][n], 0, 0, 0);   \
                     }                                                                                                 \
                 }                                                                                                     \
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
             }                                                                                                         \
+            _Pragma("unroll") for (int t = (C::MT >= 2 ? C::MT - 2 : 0); t < C::MT; ++t) {   /* the last two tiles' lo*hi */ \
+                if (t < C::MT_MIN || my_mt > t) {                                                                     \
+                    _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                    \
+                        acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t % 5], bh[n], acc1[t][n], 0, 0, 0);   \
+                }                                                                                                     \
+            }                                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
         }                                                                                                             \
     } while (0)
 
