@@ -173,9 +173,16 @@ class Agent():
         return loss.detach()
 
     def soft_update(self, local_model, target_model, tau):                       # DDQN.py:153-165
+        # theta_t <- tau theta + (1 - tau) theta_t over all 22 tensors in two multi-tensor launches (the per-tensor loop
+        # of the reference is 88 small launches per learn step)
         with torch.no_grad():
-            for target_param, local_param in zip(target_model.parameters(), local_model.parameters()):
-                target_param.data.copy_(tau * local_param.data + (1 - tau) * target_param.data)
+            tp, lp = list(target_model.parameters()), list(local_model.parameters())
+            if tp and tp[0].is_cuda:
+                torch._foreach_mul_(tp, 1 - tau)
+                torch._foreach_add_(tp, lp, alpha=tau)
+            else:
+                for target_param, local_param in zip(tp, lp):
+                    target_param.data.copy_(tau * local_param.data + (1 - tau) * target_param.data)
 
 
 def save_checkpoint(path, brain, epsilon=0.0, counters=None):

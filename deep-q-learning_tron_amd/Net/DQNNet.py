@@ -11,7 +11,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from config import MAP_WIDTH
-from Net.activations import mish as _mish, conv_bias_mish as _conv_bias_mish
+from Net.activations import (mish as _mish, conv_bias_mish as _conv_bias_mish, pool_conv7_mish as _pool_conv7_mish,
+                             pool_conv7_supported as _pool_conv7_supported)
 
 
 def conv7_side(side):
@@ -59,9 +60,12 @@ class Net(nn.Module):
         idx = x
         x = _conv_bias_mish(self.conv5, x)
         x = _conv_bias_mish(self.conv6, x, idx)
-        x = self.pool(x)
-        x = _conv_bias_mish(self.conv7, x)
-        x = x.reshape(-1, self.flat)
+        if _pool_conv7_supported(self.pool, self.conv7, x):
+            x = _pool_conv7_mish(self.pool, self.conv7, x)              # the two layers as GEMMs on conv7's dense form
+        else:
+            x = self.pool(x)
+            x = _conv_bias_mish(self.conv7, x)
+            x = x.reshape(-1, self.flat)
         x = self.dropout(self.activation(self.fc1(x)))
         x = self.dropout(self.activation(self.fc2(x)))
         return self.actor2(self.activation(self.actor1(x)))

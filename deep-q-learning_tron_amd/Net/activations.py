@@ -120,6 +120,74 @@ class _BiasMish(torch.autograd.Function):
         return gp, gb, (gp if ctx.has_res else None)
 
 
+class _PoolConv7(torch.autograd.Function):
+    """mish(conv7(avg_pool(x))) flattened, for 12x12 planes (Net/DQNNet.py:52-55): on the 6x6 pooled planes the 7x7 /
+    stride 2 / pad 3 convolution is the dense map [Ci*36] -> [Co*9] (most taps fall on padding), so forward, input
+    gradient and weight gradient are three plain f32 GEMMs on the matrix csrc/tron_head.hip builds from the weight
+    (tron_conv7_dense) and folds its gradient back into; pooling forward / backward are tron_pool12.  Replaces MIOpen's
+    conv7 kernels + their NCHW<->NHWC transposes + torch's avg_pool2d backward (1.1 ms -> 0.45 ms at 4 096 samples)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from tron import _native as nat
+        L = nat.lib()
+        B, C = x.shape[0], x.shape[1]
+        Co = weight.shape[0]
+        st = nat.stream_ptr()
+        with torch.cuda.device(x.device):
+            pooled = torch.empty(B, C * 36, dtype=torch.float32, device=x.device)
+            nat.check(L.tron_pool12(nat.ptr(x), nat.ptr(pooled), B * C, 0, st), "tron_pool12")
+            dense = torch.empty(Co * 9, C * 36, dtype=torch.float32, device=x.device)
+            nat.check(L.tron_conv7_dense(nat.ptr(weight), nat.ptr(dense), Co, C, 0, st), "tron_conv7_dense")
+            pre = torch.addmm(bias.repeat_interleave(9), pooled, dense.t())
+            out = torch.empty_like(pre)
+            nat.check(L.tron_mish_fwd(nat.ptr(pre), nat.ptr(out), pre.numel(), st), "tron_mish_fwd")
+        ctx.save_for_backward(pooled, dense, pre)
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from tron import _native as nat
+        L = nat.lib()
+        pooled, dense, pre = ctx.saved_tensors
+        B, C = ctx.shape[0], ctx.shape[1]
+        Co = dense.shape[0] // 9
+        g = grad_out.contiguous()
+        if not _aligned16(g):
+            g = g.clone(memory_format=torch.contiguous_format)
+        st = nat.stream_ptr()
+        gx = gw = gb = None
+        with torch.cuda.device(pre.device):
+            gp = torch.empty_like(pre)
+            nat.check(L.tron_mish_bwd(nat.ptr(pre), nat.ptr(g), nat.ptr(gp), pre.numel(), st), "tron_mish_bwd")
+            if ctx.needs_input_grad[0]:
+                gpool = gp @ dense
+                gx = torch.empty(ctx.shape, dtype=torch.float32, device=pre.device)
+                nat.check(L.tron_pool12(nat.ptr(gpool), nat.ptr(gx), B * C, 1, st), "tron_pool12")
+            if ctx.needs_input_grad[1]:
+                gdense = gp.t() @ pooled
+                gw = torch.empty(Co, C, 7, 7, dtype=torch.float32, device=pre.device)
+                nat.check(L.tron_conv7_dense(nat.ptr(gdense), nat.ptr(gw), Co, C, 1, st), "tron_conv7_dense")
+            if ctx.needs_input_grad[2]:
+                gb = gp.view(B, Co, 9).sum((0, 2))
+        return gx, gw, gb
+
+
+def pool_conv7_supported(pool, conv, x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] == 12 and x.shape[-2] == 12 and x.shape[0] > 0
+            and _aligned16(x) and isinstance(pool, torch.nn.AvgPool2d) and pool.kernel_size == 3 and pool.stride == 2
+            and pool.padding == 1 and pool.count_include_pad and not pool.ceil_mode and pool.divisor_override is None
+            and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (7, 7) and conv.stride == (2, 2)
+            and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None
+            and conv.in_channels == x.shape[1] and conv.weight.is_contiguous() and conv.weight.dtype == torch.float32)
+
+
+def pool_conv7_mish(pool, conv, x):
+    """mish(conv7(pool(x))) as [B, Co*3*3] (already flattened in NCHW order) — DQNNet.py:52-55."""
+    return _PoolConv7.apply(x, conv.weight, conv.bias)
+
+
 def conv_bias_mish(conv, x, residual=None):
     """mish(conv(x) + residual) with the bias add, the residual add and the activation fused behind the
     (bias-free) MIOpen convolution when the tensors allow it; otherwise the plain composition."""

@@ -113,6 +113,91 @@ __global__ void k_split_rows(const float *__restrict__ w, int total, f16 *__rest
     }
 }
 
+// ---- the same two layers for the TRAINING path (f32; the products run as library GEMMs on the dense matrix) -----------
+// AvgPool2d(3, stride 2, padding 1) of 12x12 planes, f32 -> f32 [B][C][6][6]; one thread = one pooled row
+__global__ __launch_bounds__(256) void k_pool12(const float *__restrict__ x, int64_t rows, float *__restrict__ y)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += stride) {
+        const int py = (int)(i % 6);
+        const float *p = x + (i / 6) * 144;
+        float col[13];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) col[k] = 0.0f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = 2 * py + dy;
+            if (yy < 0) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(p + yy * 12 + q * 4);
+                col[1 + q * 4] += v[0];
+                col[2 + q * 4] += v[1];
+                col[3 + q * 4] += v[2];
+                col[4 + q * 4] += v[3];
+            }
+        }
+        float o[6];
+#pragma unroll
+        for (int px = 0; px < 6; ++px) o[px] = (col[2 * px] + col[2 * px + 1] + col[2 * px + 2]) * (1.0f / 9.0f);
+        float *d = y + i * 6;                                            // 24-byte rows: 8-byte aligned
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<float2 *>(d + 2 * k) = make_float2(o[2 * k], o[2 * k + 1]);
+    }
+}
+
+// its backward: gx[y][x] = (1/9) * sum of gy over the windows that contain (y, x) — rows (y+1)/2 and, for odd y, also
+// (y+2)/2... written per INPUT row: one thread = one input row of 12, 16-byte stores
+__global__ __launch_bounds__(256) void k_pool12_bwd(const float *__restrict__ gy, int64_t rows, float *__restrict__ gx)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += stride) {
+        const int y = (int)(i % 12);
+        const float *g = gy + (i / 12) * 36;
+        // window row py covers input rows 2py-1 .. 2py+1: even y belongs to py = y/2 only, odd y to (y-1)/2 and (y+1)/2
+        const int p0 = y >> 1, p1 = (y & 1) ? p0 + 1 : -1;
+        float r[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r[k] = g[p0 * 6 + k] + ((p1 >= 0 && p1 < 6) ? g[p1 * 6 + k] : 0.0f);
+        float o[12];
+#pragma unroll
+        for (int x = 0; x < 12; ++x) o[x] = ((x & 1) ? r[x >> 1] + ((x >> 1) + 1 < 6 ? r[(x >> 1) + 1] : 0.0f) : r[x >> 1]) * (1.0f / 9.0f);
+        float *d = gx + i * 12;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<f32x4 *>(d + 4 * q) = (f32x4){o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+    }
+}
+
+// conv7 weight [Co][Ci][7][7] -> dense [Co*9][Ci*36] f32 (fold = 0), or the dense matrix's gradient -> the weight's:
+// dW[co][ci][ky][kx] = sum over the <= 9 outputs (oy, ox) whose tap (ky, kx) lands inside the 6x6 plane (fold = 1)
+__global__ void k_dense7(const float *__restrict__ src, float *__restrict__ dst, int Co, int Ci, int fold)
+{
+    if (!fold) {
+        const int K = Ci * 36, total = Co * 9 * K;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+            const int n = i / K, k = i - n * K;
+            const int co = n / 9, op = n - co * 9, oy = op / 3, ox = op - oy * 3;
+            const int ci = k / 36, ip = k - ci * 36, iy = ip / 6, ix = ip - iy * 6;
+            const int ky = iy - 2 * oy + 3, kx = ix - 2 * ox + 3;
+            dst[i] = (ky >= 0 && ky < 7 && kx >= 0 && kx < 7) ? src[((size_t)(co * Ci + ci) * 7 + ky) * 7 + kx] : 0.0f;
+        }
+    } else {
+        const int K = Ci * 36, total = Co * Ci * 49;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+            const int kx = i % 7, ky = (i / 7) % 7, ci = (i / 49) % Ci, co = i / (49 * Ci);
+            float s = 0.0f;
+#pragma unroll
+            for (int oy = 0; oy < 3; ++oy)
+#pragma unroll
+                for (int ox = 0; ox < 3; ++ox) {
+                    const int iy = 2 * oy + ky - 3, ix = 2 * ox + kx - 3;
+                    if (iy >= 0 && iy < 6 && ix >= 0 && ix < 6) s += src[(size_t)(co * 9 + oy * 3 + ox) * K + ci * 36 + iy * 6 + ix];
+                }
+            dst[i] = s;
+        }
+    }
+}
+
 constexpr int GM = 128, GN = 64, GK = 64;          // workgroup tile, K chunk
 constexpr int GPITCH = GK * 2 + 16;                // bytes per LDS row (16 bytes of padding spread the banks)
 constexpr int G_THREADS = 512;
@@ -340,5 +425,29 @@ extern "C" int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t 
     if (rc != TRON_OK) return rc;
     hipLaunchKernelGGL(k_q_head, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, c3, actor2_w, actor2_b, (int)batch, 64,
                        q_out, greedy_out);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+// ---- training-path pieces of the same layers (Net/activations.py::_PoolConv7): pooling forward / backward on 12x12
+// planes and conv7's dense form and its gradient's fold-back; the GEMMs between them are library calls ------------------
+extern "C" int tron_pool12(const float *x, float *y, int64_t planes, int32_t backward, void *stream)
+{
+    if (!x || !y || planes < 0) return TRON_ERR_BAD_ARG;
+    if (planes == 0) return TRON_OK;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) return TRON_ERR_BAD_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t rows = planes * (backward ? 12 : 6);
+    const unsigned blocks = (unsigned)((rows + 255) / 256 < (1 << 20) ? (rows + 255) / 256 : (1 << 20));
+    if (backward) hipLaunchKernelGGL(k_pool12_bwd, dim3(blocks), dim3(256), 0, st, x, rows, y);
+    else hipLaunchKernelGGL(k_pool12, dim3(blocks), dim3(256), 0, st, x, rows, y);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int tron_conv7_dense(const float *src, float *dst, int32_t cout, int32_t cin, int32_t fold, void *stream)
+{
+    if (!src || !dst || cout < 1 || cin < 1 || (int64_t)cout * cin * 324 > (1ll << 30)) return TRON_ERR_BAD_ARG;
+    const int total = fold ? cout * cin * 49 : cout * 9 * cin * 36;
+    hipLaunchKernelGGL(k_dense7, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, cout, cin,
+                       fold);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }

@@ -328,6 +328,13 @@ int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t side, const
                       const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,
                       const float *actor2_b, void *workspace, float *q_out, int8_t *greedy_out, void *stream);
 int64_t tron_dqn_head_workspace(int64_t batch, int32_t side);
+/* The same two layers on the training path (their products are library GEMMs on conv7's dense form):
+ * tron_pool12: AvgPool2d(3, stride 2, padding 1) (Net/DQNNet.py:20,52) of `planes` 12x12 f32 planes -> 6x6 (backward 0),
+ * or its gradient 6x6 -> 12x12 (backward 1).  tron_conv7_dense: fold 0: conv7's weight f32[cout][cin][7][7] -> the
+ * matrix f32[cout*9][cin*36] that maps a flattened 6x6 input to the flattened 3x3 output of the 7x7 / stride 2 / pad 3
+ * convolution (DQNNet.py:22,53); fold 1: that matrix's gradient -> the weight's gradient.                          */
+int tron_pool12(const float *x, float *y, int64_t planes, int32_t backward, void *stream);
+int tron_conv7_dense(const float *src, float *dst, int32_t cout, int32_t cin, int32_t fold, void *stream);
 
 /* Wait for `stream` and report what the kernels queued on it did: launch_status-style calls above only
  * see a REJECTED launch; a fault inside a kernel surfaces at the next synchronisation.  Returns TRON_OK

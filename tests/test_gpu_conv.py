@@ -314,3 +314,43 @@ def test_conv3x3_dgrad_matches_float64_at_gradient_magnitudes(fused, S, B, cin, 
     got = fused.conv3x3_dgrad(gp, w, absmax)
     err = (got.double() - xd.grad).abs().max().item() / xd.grad.abs().max().item()
     assert err < 2e-6, err
+
+
+@pytest.mark.parametrize("B", [1, 7, 300])
+def test_pool_conv7_dense_path_matches_float64(fused, B):
+    """Net/activations.py::_PoolConv7 (tron_pool12 + conv7 as GEMMs on its dense form, DQNNet.py:52-55) against autograd
+    through float64 mish(conv2d(avg_pool2d(x))): output, input gradient, weight and bias gradients."""
+    from Net.activations import pool_conv7_mish, pool_conv7_supported
+    torch.manual_seed(B)
+    pool = torch.nn.AvgPool2d(kernel_size=3, padding=1, stride=2)
+    conv = torch.nn.Conv2d(64, 64, 7, padding=3, stride=2).cuda()
+    x = torch.randn(B, 64, 12, 12, device="cuda", requires_grad=True)
+    assert pool_conv7_supported(pool, conv, x)
+    out = pool_conv7_mish(pool, conv, x)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    xd = x.detach().double().requires_grad_(True)
+    wd, bd = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    ref = F.mish(F.conv2d(F.avg_pool2d(xd, 3, stride=2, padding=1), wd, bd, stride=2, padding=3)).reshape(B, -1)
+    ref.backward(gout.double())
+    assert (out.double() - ref).abs().max().item() < TOL
+    for got, want, what in ((x.grad, xd.grad, "input"), (conv.weight.grad, wd.grad, "weight"), (conv.bias.grad, bd.grad, "bias")):
+        scale = max(1.0, want.abs().max().item())
+        assert (got.double() - want).abs().max().item() < 2e-5 * scale, (what, (got.double() - want).abs().max().item(), scale)
+
+
+def test_net_forward_uses_dense_tail_and_matches_plain_module(fused):
+    from Net.DQNNet import Net
+    torch.manual_seed(5)
+    net = Net(4, 10).cuda().eval()
+    x = torch.randn(33, 4, 12, 12, device="cuda")
+    q = net(x)
+    loss = q.square().mean()
+    loss.backward()
+    g1 = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    ref = net.double()._forward_plain(x.double())
+    ref.square().mean().backward()
+    assert (q.double() - ref).abs().max().item() < TOL
+    for a, p in zip(g1, net.parameters()):
+        assert (a.double() - p.grad).abs().max().item() < 2e-5 * max(1.0, p.grad.abs().max().item())
