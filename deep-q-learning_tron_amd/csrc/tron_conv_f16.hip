@@ -118,12 +118,17 @@ __global__ void k_split_weights(const float *__restrict__ w, int cout, int cin, 
 
 // SMALL = the conv1 instantiation (cin 3 or 4: one chunk whose absent channels are zero; input = int8 observation
 // codes when in_codes, else the f32 planes).  NT 16-channel tiles per wave: cout = 32 * NT.
-template <int S, int NT, bool SMALL>
+// PERSIST (12x12, an even number of chunks): a workgroup walks image groups blockIdx.x, + gridDim.x, ... and stages the
+// NEXT group's first chunk during the current group's last one — a group then starts on operands that are already in
+// LDS instead of waiting for its first loads (12 % of a workgroup's life, stamped).
+template <int S, int NT, bool SMALL, bool PERSIST>
 __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     const void *__restrict__ in, const f16 *__restrict__ ws, const float *__restrict__ bias,
     const float *__restrict__ res, float *__restrict__ out, float *__restrict__ pre_out, int B, int cin, float plane4,
-    int apply_mish, int in_fmt, unsigned char *__restrict__ out_s16, const float *__restrict__ absmax, int n_absmax)
+    int apply_mish, int in_fmt, unsigned char *__restrict__ out_s16, const float *__restrict__ absmax, int n_absmax,
+    int ngroups)
 {
+    static_assert(!PERSIST || (!SMALL && Cfg<S>::NB == 1), "persistent groups: one band, chunked input");
     const int in_codes = in_fmt == 1;
     const bool in_s16 = !SMALL && in_fmt == 2;
     using C = Cfg<S>;
@@ -147,8 +152,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     // waves w and w + 4 share a SIMD: the second N half walks the M slots backwards, so a SIMD gets 5 + 4 tiles
     const int wn = wave / NWM, wm = wn ? NWM - 1 - (wave & (NWM - 1)) : (wave & (NWM - 1));
     const int li = lane & 15, g = lane >> 4, tsel = g >> 1, oct = g & 1;
-    const int img0 = (blockIdx.x / C::NB) * C::P;
-    const int band = blockIdx.x % C::NB;                                // neighbours in the grid share an image: halo rows hit L2
+    int grp = blockIdx.x;                                               // image group (x band): PERSIST walks grp += gridDim.x
+    int img0 = (grp / C::NB) * C::P;
+    const int band = grp % C::NB;                                       // neighbours in the grid share an image: halo rows hit L2
     const int r0 = band ? C::SPLIT : 0, rows = C::NB == 1 ? S : (band ? S - C::SPLIT : C::SPLIT);
     const int rpx = rows * S;                                           // pixels of one image in this region
     const int npx = C::P * rpx;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     const int tile0 = wm * t_base + (wm < t_rem ? wm : t_rem);           // first M tile of this wave
     const int my_mt = t_base + (wm < t_rem ? 1 : 0);
     const int nchunks = SMALL ? 1 : cin / CIC;
-    const int last_img = B - 1 - img0;
+    int last_img = B - 1 - img0;
     const int cout = COUT;
 
 #ifdef TRON_CONV_STAMPS     // diagnostic build only: pre_out is a stamp buffer u64[blocks][6], never an output
@@ -207,11 +213,15 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     };
     const int b_base = (tsel * COUT + wn * 16 * NT + li) * PITCH + oct * 16;
 
-    const size_t wg_base = (size_t)img0 * cout * C::SS;
+    size_t wg_base = (size_t)img0 * cout * C::SS;
     const float *in_wg = (SMALL && in_codes) ? nullptr : reinterpret_cast<const float *>(in) + (size_t)img0 * cin * C::SS;
     // the split-f16 activation image ("S16"): per image [16-channel chunk][hi | lo][pixel][16 ci] f16 — as many bytes as
     // the f32 tensor, laid out so that a chunk's rows are copied into the padded LDS planes 16 bytes at a time
     const unsigned char *in16_wg = reinterpret_cast<const unsigned char *>(in) + (size_t)img0 * cin * C::SS * 4;
+    // what the staging macros read from: the current group's images, or (PERSIST, last chunk) the next group's
+    const float *ld_in_wg = in_wg;
+    const unsigned char *ld_in16 = in16_wg;
+    int ld_last = last_img;
 
     f32x4 acc0[C::MT][NT], acc1[C::MT][NT];
 #pragma unroll
@@ -260,8 +270,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
                 const int re_ = r2_ / npr, pc_ = r2_ - re_ * npr;                                                     \
                 int gr_ = r0 - 1 + re_;                                                                               \
                 gr_ = gr_ < 0 ? 0 : (gr_ >= S ? S - 1 : gr_);                                                         \
-                const int ims_ = im_ < last_img ? im_ : last_img;                                                     \
-                rin[j] = *reinterpret_cast<const f32x4 *>(in16_wg + ((size_t)ims_ * cin * C::SS * 4 +                 \
+                const int ims_ = im_ < ld_last ? im_ : ld_last;                                                     \
+                rin[j] = *reinterpret_cast<const f32x4 *>(ld_in16 + ((size_t)ims_ * cin * C::SS * 4 +                 \
                                                                       ((c_) * 2 + h_) * C::SS * 32 + gr_ * S * 32 + pc_ * 16)); \
             }                                                                                                         \
         } else {                                                                                                      \
@@ -273,8 +283,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
             const int re_ = p_ / S, xx_ = p_ - re_ * S;                                                               \
             int gr_ = r0 - 1 + re_;                                       /* image row; clamped: dropped at the write */ \
             gr_ = gr_ < 0 ? 0 : (gr_ >= S ? S - 1 : gr_);                                                             \
-            const int ims_ = im_ < last_img ? im_ : last_img;                                                         \
-            const float *src_ = in_wg + ((ims_ * cin + (c_) * CIC + quad_ * 4) * C::SS + gr_ * S + xx_);              \
+            const int ims_ = im_ < ld_last ? im_ : ld_last;                                                         \
+            const float *src_ = ld_in_wg + ((ims_ * cin + (c_) * CIC + quad_ * 4) * C::SS + gr_ * S + xx_);              \
             rin[j] = (f32x4){src_[0], src_[C::SS], src_[2 * C::SS], src_[3 * C::SS]};                                 \
         }                                                                                                             \
         }                                                                                                             \
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
             const int im_ = TRON_DIV(r_, m_ernpr), r2_ = r_ - im_ * (erows * npr);                                       \
             const int re_ = r2_ / npr, pc_ = r2_ - re_ * npr;                                                         \
             const int gr_ = r0 - 1 + re_;                                                                             \
-            const bool ok_ = q_ < n_items && gr_ >= 0 && gr_ < S && im_ <= last_img;                                  \
+            const bool ok_ = q_ < n_items && gr_ >= 0 && gr_ < S && im_ <= ld_last;                                  \
             const int off_ = h_ * C::IN_HALF + (im_ * C::PLANE + re_ * C::SP + 1) * PITCH + pc_ * 16;                 \
             *reinterpret_cast<f32x4 *>(ok_ ? (ib_) + off_ : dump + lane * 16) = rin[j_];   /* branch-free: see dump */  \
         } else {                                                                                                      \
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         f16x4 h_, l_;                                                                                                 \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                               \
             f16 hh_, ll_;                                                                                             \
-            split((im_ <= last_img ? rin[j_][e] : 0.0f) * act_scale, hh_, ll_);                                       \
+            split((im_ <= ld_last ? rin[j_][e] : 0.0f) * act_scale, hh_, ll_);                                       \
             h_[e] = hh_;                                                                                              \
             l_[e] = ll_;                                                                                              \
         }                                                                                                             \
@@ -328,15 +338,15 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     } while (0)
 
     // ---- one chunk: 5 slabs x up to MT tile-steps; STAGE_: also bring chunk c+1 into the other buffers ---------------
-#define TRON_CHUNK(STAGE_, c_)                                                                                       \
+#define TRON_CHUNK(STAGE_, c_, cn_)                                                                                    \
     do {                                                                                                              \
         const unsigned char *in_h = lds + ((c_) & 1) * IN_BUF, *in_l = in_h + C::IN_HALF;                             \
         const unsigned char *w_h = lds + 2 * IN_BUF + ((c_) & 1) * W_BUF, *w_l = w_h + W_HALF;                        \
         unsigned char *nxt_in_ = lds + (((c_) + 1) & 1) * IN_BUF;                                                     \
         unsigned char *nxt_w_ = lds + 2 * IN_BUF + (((c_) + 1) & 1) * W_BUF;                                          \
         if (STAGE_ && TRON_F16_ABLATE != 1 && TRON_F16_ABLATE != 4) {                                                 \
-            TRON_LOAD_W((c_) + 1);                                                                                    \
-            TRON_LOAD_IN((c_) + 1);                                                                                   \
+            TRON_LOAD_W(cn_);                                                                                         \
+            TRON_LOAD_IN(cn_);                                                                                        \
         }                                                                                                             \
         _Pragma("unroll") for (int s = 0; s < SLABS; ++s) {                                                           \
             f16x8 bh[NT], bl[NT];                                                                                     \
@@ -435,11 +445,19 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     if (tid == 0) { stamps[2] = __builtin_amdgcn_s_memtime(); stamps[3] = __builtin_amdgcn_s_memrealtime(); }
 #endif
     // ---- the chunks: one barrier each (next chunk's buffers written, this chunk's buffers free again) ---------------
+    for (;;) {                                                          // image groups (one pass unless PERSIST)
     for (int c = 0; c + 1 < nchunks; ++c) {
-        TRON_CHUNK(true, c);
+        TRON_CHUNK(true, c, c + 1);
         __syncthreads();
     }
-    TRON_CHUNK(false, nchunks - 1);
+    const int grp_next = grp + (int)gridDim.x;
+    if (PERSIST) {                                                      // the last chunk brings in the next group's chunk 0
+        const int img0n = ((grp_next < ngroups ? grp_next : grp) / C::NB) * C::P;   // (past the end: this group's again, unused)
+        ld_in_wg = reinterpret_cast<const float *>(in) + (size_t)img0n * cin * C::SS;
+        ld_in16 = reinterpret_cast<const unsigned char *>(in) + (size_t)img0n * cin * C::SS * 4;
+        ld_last = B - 1 - img0n;
+    }
+    TRON_CHUNK(PERSIST, nchunks - 1, 0);
 
 #undef TRON_CHUNK
 #undef TRON_STORE_W
@@ -507,28 +525,51 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
             }
         }
     }
+    if (!PERSIST || grp_next >= ngroups) break;                         // (uniform over the workgroup)
+    // ---- next group: its chunk 0 is in LDS already (staged during the last chunk above) ----------------------------
+    grp = grp_next;
+    img0 = (grp / C::NB) * C::P;
+    last_img = B - 1 - img0;
+    wg_base = (size_t)img0 * cout * C::SS;
+    in_wg = ld_in_wg;
+    in16_wg = ld_in16;
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            acc0[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc1[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    __syncthreads();                                                    // the staged chunk is complete, the old buffers are free
+    }
 }
 
-template <int S, int NT, bool SMALL>
+template <int S, int NT, bool SMALL, bool PERSIST>
 int launch(const void *in, const f16 *ws, const float *bias, const float *res, float *out, float *pre_out, int64_t B,
            int cin, float plane4, int apply_mish, int in_fmt, void *out_s16, const float *absmax, int n_absmax, hipStream_t st)
 {
     using C = Cfg<S>;
     constexpr size_t LDS_BYTES = 4 * (size_t)C::IN_HALF + 4 * (size_t)TAPS_PAD * 32 * NT * PITCH + 1024;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    auto kern = k_conv3x3_f16<S, NT, SMALL>;
+    auto kern = k_conv3x3_f16<S, NT, SMALL, PERSIST>;
     static uint64_t prepared = 0;
+    static int cus[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
     if (!(prepared & (1ull << (dev & 63)))) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)LDS_BYTES) != hipSuccess)
             (void)hipGetLastError();
+        hipDeviceProp_t prop;
+        cus[dev & 63] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        (void)hipGetLastError();
         prepared |= 1ull << (dev & 63);
     }
     const int64_t groups = (B + C::P - 1) / C::P * C::NB;
-    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(THREADS), LDS_BYTES, st, in, ws, bias, res, out, pre_out, (int)B,
-                       cin, plane4, apply_mish, in_fmt, reinterpret_cast<unsigned char *>(out_s16), absmax, n_absmax);
+    // PERSIST: one workgroup per CU (the kernel's LDS allows no more) walking groups blockIdx.x, + grid, ...
+    const int64_t grid = PERSIST && groups > cus[dev & 63] ? cus[dev & 63] : groups;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, st, in, ws, bias, res, out, pre_out, (int)B,
+                       cin, plane4, apply_mish, in_fmt, reinterpret_cast<unsigned char *>(out_s16), absmax, n_absmax, (int)groups);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
@@ -552,19 +593,18 @@ int tron_conv3x3_f16x3(const void *in, int in_fmt, const float *weight, const fl
     const int nchunks = (cin + CIC - 1) / CIC;
     const int total = nchunks * TAPS_PAD * cout * CIC;
     hipLaunchKernelGGL(k_split_weights, dim3((total + 255) / 256), dim3(256), 0, st, weight, cout, cin, nchunks, dgrad, ws);
-#define TRON_F16_CASE(S_)                                                                                                 \
+    const bool persist = !small && nchunks % 2 == 0;                    // (12x12 only: the 26x26 bands alternate)
+#define TRON_F16_ARGS in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_fmt, out_split, grad_absmax, n_absmax, st
+#define TRON_F16_CASE(S_, PERSIST_OK_)                                                                                    \
     if (side == S_) {                                                                                                     \
-        if (small)                                                                                                        \
-            return launch<S_, 1, true>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_fmt,     \
-                                       out_split, grad_absmax, n_absmax, st);                                                                    \
-        if (cout == 64)                                                                                                   \
-            return launch<S_, 2, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_fmt,    \
-                                        out_split, grad_absmax, n_absmax, st);                                                                   \
-        return launch<S_, 1, false>(in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_fmt,        \
-                                    out_split, grad_absmax, n_absmax, st);                                                                       \
+        if (small) return launch<S_, 1, true, false>(TRON_F16_ARGS);                                                      \
+        if (PERSIST_OK_ && persist)                                                                                       \
+            return cout == 64 ? launch<S_, 2, false, PERSIST_OK_>(TRON_F16_ARGS) : launch<S_, 1, false, PERSIST_OK_>(TRON_F16_ARGS); \
+        return cout == 64 ? launch<S_, 2, false, false>(TRON_F16_ARGS) : launch<S_, 1, false, false>(TRON_F16_ARGS);      \
     }
-    TRON_F16_CASE(12)
-    TRON_F16_CASE(26)
+    TRON_F16_CASE(12, true)
+    TRON_F16_CASE(26, false)
 #undef TRON_F16_CASE
+#undef TRON_F16_ARGS
     return TRON_ERR_UNSUPPORTED;
 }

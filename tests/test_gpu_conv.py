@@ -35,7 +35,7 @@ def _ref(x, conv, res, act):
 
 
 @pytest.mark.parametrize("math", ["f32", "f16x3"])
-@pytest.mark.parametrize("S,B", [(12, 1), (12, 7), (12, 260), (26, 1), (26, 3), (26, 130)])
+@pytest.mark.parametrize("S,B", [(12, 1), (12, 7), (12, 260), (12, 1555), (26, 1), (26, 3), (26, 130)])   # 1555: several image groups per persistent workgroup, ragged
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64), (64, 32)])
 def test_conv3x3_matches_float64_reference(fused, S, B, cin, cout, math, monkeypatch):
     """Both arithmetic modes of tron_conv3x3_fwd: the exact-f32 MFMA kernel and the split-f16 one (12x12 boards; at
@@ -172,7 +172,7 @@ def test_training_conv_gradients_match_float64(fused, S, B, cin, cout, with_res)
         close(res.grad, rd.grad, "residual")
 
 
-@pytest.mark.parametrize("S,B", [(12, 1), (12, 131), (26, 2), (26, 65)])
+@pytest.mark.parametrize("S,B", [(12, 1), (12, 131), (12, 1031), (26, 2), (26, 65)])
 def test_split16_chain_equals_unchained_layers(fused, S, B):
     """Layers chained through the split-f16 image (TRON_CONV_IN_SPLIT16 / out_split) give bit-for-bit what the same
     split kernel gives when every layer re-splits the previous layer's f32 output: the image IS that split."""
