@@ -197,23 +197,26 @@ def dqn_record(envs, width, steps, warmup, batch, repeats, world, rank):
             "policy_rollout": {"metric": "env-steps/sec with the greedy CNN policy in the loop, no learning",
                                "value": envs * steps * world / pol_s,
                                "tflops": f_fwd * 2 * envs * steps * world / pol_s / 1e12,
-                               "frac_of_f32_matrix_peak": f_fwd * 2 * envs * steps * world / pol_s / 1e12 / F32_MATRIX_PEAK_TFLOPS},
+                               "frac_of_f16x3_peak": f_fwd * 2 * envs * steps * world / pol_s / 1e12 / (F16_MATRIX_PEAK_TFLOPS / 3)},
             "steps": steps, "repeats": repeats, "seconds_min_med_max": [runs[0][0], sec, runs[-1][0]],
             "learn_batch": batch, "learn_every_env_steps": 2, "dtype": "f32",
             "config": {"workload": f"{envs} parallel {width}x{width} self-play envs per GPU, DDQN + target net, "
                                    f"1M-slot HBM replay, learn batch {batch} every 2 env-steps, eps-greedy policy = "
                                    f"the 7-conv CNN (Net/DQNNet.py) on the int8 observations",
                        "parallelism": f"env-shard + replay-shard x{world}, gradient all-reduce per learn step"},
-            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MATRIX_PEAK_TFLOPS,
-                         "achieved": flops / sec / 1e12, "frac": flops / sec / 1e12 / F32_MATRIX_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "unit": "TFLOP/s (f32-equivalent)", "peak": F16_MATRIX_PEAK_TFLOPS / 3,
+                         "achieved": flops / sec / 1e12, "frac": flops / sec / 1e12 / (F16_MATRIX_PEAK_TFLOPS / 3),
                          "flops_forward_per_sample": f_fwd,
-                         "peak_f16x3": F16_MATRIX_PEAK_TFLOPS / 3,
-                         "frac_of_f16x3_peak": flops / sec / 1e12 / (F16_MATRIX_PEAK_TFLOPS / 3),
-                         "note": "f32 results like the reference (Q within 1e-5).  peak = the f32-input MFMA rate (= f32 "
-                                 "vector rate), what exact-f32 arithmetic can reach; the 3x3 convolutions run as three f16 "
-                                 "MFMAs per f32 product (csrc/tron_conv_f16.hip: v = hi + lo 2^-11), whose ceiling is the dense "
-                                 "f16 peak / 3 (peak_f16x3).  Whole-loop time incl. env step, replay push/sample, optimizer; "
-                                 "weight gradients, conv7 and the linear layers are still f32 library kernels"}}
+                         "f32_matrix_peak": F32_MATRIX_PEAK_TFLOPS,
+                         "vs_f32_matrix_peak": flops / sec / 1e12 / F32_MATRIX_PEAK_TFLOPS,
+                         "note": "f32 results like the reference (Q within 1e-5).  Every product of the CNN runs on the f16 matrix "
+                                 "cores as three MFMAs per f32 product (v = hi + lo 2^-11: csrc/tron_conv_f16.hip, "
+                                 "tron_conv_wgrad.hip, tron_head.hip), so the ceiling is the dense f16 peak / 3 (`peak`); "
+                                 "f32_matrix_peak is what exact-f32 MFMA arithmetic could reach (the loop runs above it).  "
+                                 "Whole-loop time incl. env step, replay push / sample, optimizer; the four linear layers of "
+                                 "the learner's forward / backward and conv7's dense GEMMs are f32 library GEMMs; per-kernel "
+                                 "HBM rates: profiles/r02_dqn_conv_hbm.json (the conv kernels move 2.2-3.1 TB/s: not "
+                                 "memory-bound)"}}
 
 
 def main():
