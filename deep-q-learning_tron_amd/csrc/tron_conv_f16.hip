@@ -121,6 +121,10 @@ __global__ void k_split_weights(const float *__restrict__ w, int cout, int cin, 
 // PERSIST (12x12, an even number of chunks): a workgroup walks image groups blockIdx.x, + gridDim.x, ... and stages the
 // NEXT group's first chunk during the current group's last one — a group then starts on operands that are already in
 // LDS instead of waiting for its first loads (12 % of a workgroup's life, stamped).
+#ifdef TRON_CONV_WAVE_STAMPS  // diagnostic build only (scripts/conv_wave_stamps.py): per-wave cycles, read back by tron_conv_wave_stamps
+__device__ unsigned long long g_wave_stamps[256 * 8 * 4];
+#endif
+
 template <int S, int NT, bool SMALL, bool PERSIST>
 __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     const void *__restrict__ in, const f16 *__restrict__ ws, const float *__restrict__ bias,
@@ -445,10 +449,22 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     if (tid == 0) { stamps[2] = __builtin_amdgcn_s_memtime(); stamps[3] = __builtin_amdgcn_s_memrealtime(); }
 #endif
     // ---- the chunks: one barrier each (next chunk's buffers written, this chunk's buffers free again) ---------------
+#ifdef TRON_CONV_WAVE_STAMPS
+    unsigned long long ws_loop = 0, ws_bar = 0, ws_epi = 0, ws_groups = 0;
+#endif
     for (;;) {                                                          // image groups (one pass unless PERSIST)
+#ifdef TRON_CONV_WAVE_STAMPS
+    const unsigned long long ws_t0 = __builtin_amdgcn_s_memtime();
+#endif
     for (int c = 0; c + 1 < nchunks; ++c) {
         TRON_CHUNK(true, c, c + 1);
+#ifdef TRON_CONV_WAVE_STAMPS
+        const unsigned long long ws_b0 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
+#ifdef TRON_CONV_WAVE_STAMPS
+        ws_bar += __builtin_amdgcn_s_memtime() - ws_b0;
+#endif
     }
     const int grp_next = grp + (int)gridDim.x;
     if (PERSIST) {                                                      // the last chunk brings in the next group's chunk 0
@@ -469,6 +485,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
 
 #ifdef TRON_CONV_STAMPS
     if (tid == 0) { stamps[4] = __builtin_amdgcn_s_memtime(); stamps[5] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+#ifdef TRON_CONV_WAVE_STAMPS
+    const unsigned long long ws_t1 = __builtin_amdgcn_s_memtime();
+    ws_loop += ws_t1 - ws_t0;
 #endif
     // ---- epilogue (as tron_conv.hip): D row = 4 * (lane >> 4) + r (pixel), column = lane & 15 (channel) ------------
     int o[C::MT];
@@ -525,6 +545,14 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
             }
         }
     }
+#ifdef TRON_CONV_WAVE_STAMPS
+    ws_epi += __builtin_amdgcn_s_memtime() - ws_t1;
+    ws_groups += 1;
+    if (lane == 0 && blockIdx.x < 256) {
+        unsigned long long *d = g_wave_stamps + (blockIdx.x * 8 + wave) * 4;
+        d[0] = ws_loop; d[1] = ws_bar; d[2] = ws_epi; d[3] = ws_groups;
+    }
+#endif
     if (!PERSIST || grp_next >= ngroups) break;                         // (uniform over the workgroup)
     // ---- next group: its chunk 0 is in LDS already (staged during the last chunk above) ----------------------------
     grp = grp_next;
@@ -574,6 +602,13 @@ int launch(const void *in, const f16 *ws, const float *bias, const float *res, f
 }
 
 }  // namespace
+
+#ifdef TRON_CONV_WAVE_STAMPS
+extern "C" int tron_conv_wave_stamps(unsigned long long *host_dst)
+{
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_wave_stamps), sizeof(g_wave_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int64_t tron_conv3x3_f16x3_workspace(int cin, int cout)
 {
