@@ -118,7 +118,7 @@ __global__ void k_split_weights(const float *__restrict__ w, int cout, int cin, 
 
 // SMALL = the conv1 instantiation (cin 3 or 4: one chunk whose absent channels are zero; input = int8 observation
 // codes when in_codes, else the f32 planes).  NT 16-channel tiles per wave: cout = 32 * NT.
-// PERSIST (12x12, an even number of chunks): a workgroup walks image groups blockIdx.x, + gridDim.x, ... and stages the
+// PERSIST (an even number of chunks): a workgroup walks image groups blockIdx.x, + gridDim.x, ... and stages the
 // NEXT group's first chunk during the current group's last one — a group then starts on operands that are already in
 // LDS instead of waiting for its first loads (12 % of a workgroup's life, stamped).
 #ifdef TRON_CONV_WAVE_STAMPS  // diagnostic build only (scripts/conv_wave_stamps.py): per-wave cycles, read back by tron_conv_wave_stamps
@@ -132,7 +132,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     int apply_mish, int in_fmt, unsigned char *__restrict__ out_s16, const float *__restrict__ absmax, int n_absmax,
     int ngroups)
 {
-    static_assert(!PERSIST || (!SMALL && Cfg<S>::NB == 1), "persistent groups: one band, chunked input");
+    static_assert(!PERSIST || !SMALL, "persistent groups: chunked input");   // (NB > 1: the host keeps the grid a multiple of NB,
+                                                                             //  so a workgroup's band never changes)
     const int in_codes = in_fmt == 1;
     const bool in_s16 = !SMALL && in_fmt == 2;
     using C = Cfg<S>;
@@ -595,7 +596,7 @@ int launch(const void *in, const f16 *ws, const float *bias, const float *res, f
     }
     const int64_t groups = (B + C::P - 1) / C::P * C::NB;
     // PERSIST: one workgroup per CU (the kernel's LDS allows no more) walking groups blockIdx.x, + grid, ...
-    const int64_t grid = PERSIST && groups > cus[dev & 63] ? cus[dev & 63] : groups;
+    const int64_t grid = PERSIST && groups > cus[dev & 63] ? cus[dev & 63] / C::NB * C::NB : groups;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, st, in, ws, bias, res, out, pre_out, (int)B,
                        cin, plane4, apply_mish, in_fmt, reinterpret_cast<unsigned char *>(out_s16), absmax, n_absmax, (int)groups);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
@@ -628,7 +629,7 @@ int tron_conv3x3_f16x3(const void *in, int in_fmt, const float *weight, const fl
     const int nchunks = (cin + CIC - 1) / CIC;
     const int total = nchunks * TAPS_PAD * cout * CIC;
     hipLaunchKernelGGL(k_split_weights, dim3((total + 255) / 256), dim3(256), 0, st, weight, cout, cin, nchunks, dgrad, ws);
-    const bool persist = !small && nchunks % 2 == 0;                    // (12x12 only: the 26x26 bands alternate)
+    const bool persist = !small && nchunks % 2 == 0;
 #define TRON_F16_ARGS in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_fmt, out_split, grad_absmax, n_absmax, st
 #define TRON_F16_CASE(S_, PERSIST_OK_)                                                                                    \
     if (side == S_) {                                                                                                     \
@@ -638,7 +639,7 @@ int tron_conv3x3_f16x3(const void *in, int in_fmt, const float *weight, const fl
         return cout == 64 ? launch<S_, 2, false, false>(TRON_F16_ARGS) : launch<S_, 1, false, false>(TRON_F16_ARGS);      \
     }
     TRON_F16_CASE(12, true)
-    TRON_F16_CASE(26, false)
+    TRON_F16_CASE(26, true)
 #undef TRON_F16_CASE
 #undef TRON_F16_ARGS
     return TRON_ERR_UNSUPPORTED;

@@ -35,7 +35,7 @@ def _ref(x, conv, res, act):
 
 
 @pytest.mark.parametrize("math", ["f32", "f16x3"])
-@pytest.mark.parametrize("S,B", [(12, 1), (12, 7), (12, 260), (12, 1555), (26, 1), (26, 3), (26, 130)])   # 1555: several image groups per persistent workgroup, ragged
+@pytest.mark.parametrize("S,B", [(12, 1), (12, 7), (12, 260), (12, 1555), (26, 1), (26, 3), (26, 130), (26, 301)])   # 1555: several image groups per persistent workgroup, ragged
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64), (64, 32)])
 def test_conv3x3_matches_float64_reference(fused, S, B, cin, cout, math, monkeypatch):
     """Both arithmetic modes of tron_conv3x3_fwd: the exact-f32 MFMA kernel and the split-f16 one (12x12 boards; at
