@@ -86,6 +86,25 @@ __device__ __forceinline__ float mish1(float x)                         // as in
     return x > 20.0f ? x : y;
 }
 
+// Four values at once, written on vectors so that the compiler packs the arithmetic two per instruction (v_pk_*): the
+// epilogue is VALU-issue-bound.  No select for large x: e^x is capped at 1e18 (an unsigned integer min
+// on the bits — e is never negative — so no NaN-canonicalising v_max comes with it); n = e (e + 2) then stays finite
+// and n / (n + 2) is exactly 1 up there, so the product is x itself.  One rcp (1 ulp), no Newton step.
+__device__ __forceinline__ f32x4 mish4(f32x4 x)
+{
+    const f32x4 t = x * 1.44269504088896341f;
+    f32x4 e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t b = __float_as_uint(__builtin_amdgcn_exp2f(t[i]));
+        e[i] = __uint_as_float(b < 0x5D5E0B6Bu ? b : 0x5D5E0B6Bu);      // min(e, 1e18)
+    }
+    const f32x4 n = __builtin_elementwise_fma(e, e, e + e);
+    const f32x4 d = n + 2.0f;
+    const f32x4 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+    return x * (n * r);
+}
+
 // v -> (hi, lo): v = hi + lo * 2^-11 up to 2^-22 |v|
 __device__ __forceinline__ void split(float v, f16 &hi, f16 &lo)
 {
@@ -514,7 +533,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         for (int t = 0; t < C::MT; ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                r[t][n] = live[t] ? *reinterpret_cast<const f32x4 *>(res_wg + o[t] + n * 16 * C::SS) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                r[t][n] = live[t] ? *reinterpret_cast<const f32x4 *>(res_wg + (uint32_t)(o[t] + n * 16 * C::SS)) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < C::MT; ++t)
 #pragma unroll
@@ -531,17 +550,19 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             f32x4 v = acc0[t][n];
-            if (pre_wg) *reinterpret_cast<f32x4 *>(pre_wg + o[t] + n * 16 * C::SS) = v;
-            if (apply_mish) v = (f32x4){mish1(v[0]), mish1(v[1]), mish1(v[2]), mish1(v[3])};
-            if (out_wg) *reinterpret_cast<f32x4 *>(out_wg + o[t] + n * 16 * C::SS) = v;
+            const uint32_t ob = (uint32_t)(o[t] + n * 16 * C::SS);       // unsigned 32-bit offsets from a uniform base: no 64-bit address math per store
+            if (pre_wg) *reinterpret_cast<f32x4 *>(pre_wg + ob) = v;
+            if (apply_mish) v = mish4(v);
+            if (out_wg) *reinterpret_cast<f32x4 *>(out_wg + ob) = v;
             if (o16_wg) {                 // the same values as the next layer's operand halves: [chunk][hi | lo][pixel][16 ci]
-                unsigned char *d = o16_wg + (size_t)img * cout * C::SS * 4 + (size_t)((wn * NT + n) * 2) * C::SS * 32 + pg * 32 + li * 2;
+                unsigned char *d = o16_wg + (uint32_t)(img * cout * C::SS * 4 + ((wn * NT + n) * 2) * C::SS * 32 + pg * 32 + li * 2);
+                const f32x4 sv = v * ACT_SCALE;
+                const f16x4 hh = __builtin_convertvector(sv, f16x4);
+                const f16x4 ll = __builtin_convertvector((sv - __builtin_convertvector(hh, f32x4)) * LO_SCALE, f16x4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    f16 hh, ll;
-                    split(v[r] * ACT_SCALE, hh, ll);
-                    *reinterpret_cast<f16 *>(d + r * 32) = hh;
-                    *reinterpret_cast<f16 *>(d + C::SS * 32 + r * 32) = ll;
+                    *reinterpret_cast<f16 *>(d + r * 32) = hh[r];
+                    *reinterpret_cast<f16 *>(d + C::SS * 32 + r * 32) = ll[r];
                 }
             }
         }
