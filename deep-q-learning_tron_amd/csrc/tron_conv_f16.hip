@@ -32,7 +32,7 @@
 #include "../../include/tron_hip.h"
 #include "tron_conv.hpp"
 
-#ifndef TRON_F16_ABLATE      // diagnostic builds only: 1 = no staging of the next chunk, 2 = A fragments not re-read (wrong results)
+#ifndef TRON_F16_ABLATE      // diagnostic builds only (wrong results): 1 = no staging of the next chunk, 2 = A fragments not re-read, 5 = one split-image store per tile instead of eight
 #define TRON_F16_ABLATE 0
 #endif
 
@@ -53,10 +53,19 @@ constexpr float ACT_SCALE = 1.0f / 64.0f, ACT_UNSCALE = 64.0f, LO_SCALE = 2048.0
 
 // A workgroup's region: P whole images (small boards) or one row band of one image (NB bands; larger boards).  A band
 // starts on an even row, so its first pixel's offset (row * S, S even) is a multiple of 4: epilogue float4s stay aligned.
+#ifndef TRON_F16_PRIO       // 0: leave the issue arbitration to wave age (A/B switch for measurements)
+#define TRON_F16_PRIO 1
+#endif
+
 template <int S_>
 struct Cfg {
     static constexpr int S = S_;
-    static constexpr int SP = S + 2;
+    // Row pitch of the padded LDS planes, in pixels (32 bytes each): column 0 and columns S+1 .. SP-1 are zero halo.  A
+    // 16-pixel M tile spans two or three image rows, and a ds_read_b128 lane group holds eight lanes of one 16-byte
+    // column: their pixels must differ mod 8 to sit on different banks, so every jump a tile makes (row to row: SP - S,
+    // image to image: 3 SP - S at 12x12) has to be a multiple of 8 pixels.  S + 2 (the minimal halo) made most fragment
+    // reads two-way bank conflicts.
+    static constexpr int SP = S + 8;
     static constexpr int SS = S * S;
     static constexpr int P = (S * S <= 144) ? (288 / (S * S)) : 1;     // images per workgroup
     static constexpr int NB = (S * S <= 400) ? 1 : 2;                   // row bands per image
@@ -164,8 +173,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     constexpr int W_BUF = 2 * W_HALF;
     constexpr int STEPS = SLABS * C::MT_MIN;                            // tile-steps every wave runs per chunk
     // steps that store weight pieces / input float4s: late enough for the loads issued at the chunk's start to have landed
-    constexpr int STAGE_W0 = STEPS - C::IN_LD - W_LD, STAGE_IN0 = STAGE_W0 + W_LD;
-    static_assert(STAGE_W0 >= 6, "give the global loads time");
+    constexpr int STAGE_IN0 = STEPS - C::IN_LD;                         // (the weights go global -> LDS directly: TRON_DMA_W)
+    static_assert(STAGE_IN0 >= 6, "give the global loads time");
     static_assert(STAGE_IN0 + C::IN_LD <= STEPS, "one staged piece per tile-step");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     // LDS: in[0] (hi|lo) | in[1] (hi|lo) | w[0] (hi|lo) | w[1] (hi|lo) | dump (1 KB: where surplus threads' staging
@@ -257,7 +266,6 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         }
 
     f32x4 rin[C::IN_LD];
-    f32x4 rw[W_LD];                                                     // raw 16-byte pieces (native vector: no scratch)
     const int epx = (rows + 2) * S;                                     // a band's pixels plus its two halo rows
     const int n_items = C::P * epx * (CIC / 4);                         // f32 input: (pixel, quad) items; S16 input: as many 16-byte pieces
     const int erows = rows + 2, npr = 2 * S, nph = C::P * erows * npr;  // S16: pieces per row, per half
@@ -346,19 +354,20 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         }                                                                                                             \
     } while (0)
     // weight chunk c_: a linear copy of its pre-split image, piece j_
-#define TRON_LOAD_W(c_)                                                                                              \
+    // Weight chunk c_ -> LDS buffer wb_: its pre-split image is copied as it is, so it goes global -> LDS directly
+    // (global_load_lds_dwordx4: per-lane source, destination = a wave-uniform base + 16 * lane) — no staging registers,
+    // no ds_write_b128 (the slow store path: 13 cycles per wave-instruction), nothing to schedule into the MFMA loop.
+    // A copy is retired by the issuing wave's vmcnt(0) followed by the chunk barrier (__syncthreads emits both).
+#define TRON_DMA_W(wb_, c_)                                                                                          \
     do {                                                                                                              \
         _Pragma("unroll") for (int j = 0; j < W_LD; ++j) {                                                            \
-            int q_ = tid + j * THREADS;                                                                               \
-            q_ = q_ < W_Q ? q_ : W_Q - 1;                                                                             \
-            rw[j] = reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(ws) + (size_t)(c_) * W_BUF)[q_]; \
+            if ((j + 1) * THREADS <= W_Q || wave * 64 + j * THREADS < W_Q) {   /* whole waves in or out: W_Q % 64 == 0 */ \
+                __builtin_amdgcn_global_load_lds(                                                                     \
+                    (const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(ws) +    \
+                                                                     (size_t)(c_) * W_BUF + (size_t)(tid + j * THREADS) * 16), \
+                    (__attribute__((address_space(3))) void *)((wb_) + (wave * 64 + j * THREADS) * 16), 16, 0, 0);    \
+            }                                                                                                         \
         }                                                                                                             \
-    } while (0)
-#define TRON_STORE_W(wb_, j_)                                                                                        \
-    do {                                                                                                              \
-        const int q_ = tid + (j_) * THREADS;                                                                          \
-        const bool ok_ = ((j_) + 1) * THREADS <= W_Q || q_ < W_Q;                                                     \
-        *reinterpret_cast<f32x4 *>(ok_ ? (wb_) + q_ * 16 : dump + lane * 16) = rw[j_];                                \
     } while (0)
 
     // ---- one chunk: 5 slabs x up to MT tile-steps; STAGE_: also bring chunk c+1 into the other buffers ---------------
@@ -369,10 +378,17 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         unsigned char *nxt_in_ = lds + (((c_) + 1) & 1) * IN_BUF;                                                     \
         unsigned char *nxt_w_ = lds + 2 * IN_BUF + (((c_) + 1) & 1) * W_BUF;                                          \
         if (STAGE_ && TRON_F16_ABLATE != 1 && TRON_F16_ABLATE != 4) {                                                 \
-            TRON_LOAD_W(cn_);                                                                                         \
+            TRON_DMA_W(nxt_w_, cn_);                                                                                  \
             TRON_LOAD_IN(cn_);                                                                                        \
         }                                                                                                             \
         _Pragma("unroll") for (int s = 0; s < SLABS; ++s) {                                                           \
+            /* Vector issue goes to the older wave of a SIMD first: left alone, waves 0-3 run each chunk ahead of waves  */ \
+            /* 4-7 and then wait ~1.5 K cycles at its barrier while those finish alone.  The two waves of a SIMD swap    */ \
+            /* priority every slab, so neither gets more than a slab ahead.                                              */ \
+            if (TRON_F16_PRIO) {                                                                                      \
+                if (wn) { if (s & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }             \
+                else    { if (s & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }             \
+            }                                                                                                         \
             f16x8 bh[NT], bl[NT];                                                                                     \
             _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                          \
                 const int bo = b_base + (2 * s * COUT + n * 16) * PITCH;                                              \
@@ -398,11 +414,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
                 if (STAGE_ && t < C::MT_MIN && TRON_F16_ABLATE != 1 && TRON_F16_ABLATE != 3) { /* staging rides in the shadow of this tile's MFMAs */ \
                     const int step = s * C::MT_MIN + t;                                                               \
-                    if (step >= STAGE_W0 && step < STAGE_W0 + W_LD) TRON_STORE_W(nxt_w_, step - STAGE_W0);            \
                     if (step >= STAGE_IN0 && step < STAGE_IN0 + C::IN_LD) TRON_STORE_IN(nxt_in_, step - STAGE_IN0);   \
                 }                                                                                                     \
                 if (STAGE_ && t < C::MT_MIN && TRON_F16_ABLATE != 1 && TRON_F16_ABLATE != 3 &&                        \
-                    s * C::MT_MIN + t >= STAGE_W0 && s * C::MT_MIN + t < STAGE_IN0 + C::IN_LD) {                      \
+                    s * C::MT_MIN + t >= STAGE_IN0 && s * C::MT_MIN + t < STAGE_IN0 + C::IN_LD) {                     \
                     /* spread the piece's VALU / LDS-write instructions between this tile's MFMAs */                  \
                     _Pragma("unroll") for (int i = 0; i < 3 * NT; ++i) {                                              \
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
@@ -460,9 +475,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
 #pragma unroll
         for (int j = 0; j < C::IN_LD; ++j) TRON_STORE_IN(lds, j);
     }
-    TRON_LOAD_W(0);
-#pragma unroll
-    for (int j = 0; j < W_LD; ++j) TRON_STORE_W(lds + 2 * IN_BUF, j);
+    TRON_DMA_W(lds + 2 * IN_BUF, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
 #ifdef TRON_CONV_STAMPS
@@ -481,7 +495,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
 #ifdef TRON_CONV_WAVE_STAMPS
         const unsigned long long ws_b0 = __builtin_amdgcn_s_memtime();
 #endif
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's weight copies (LDS-DMA) have landed ...
+        __syncthreads();                                                // ... and after the barrier everybody's have
 #ifdef TRON_CONV_WAVE_STAMPS
         ws_bar += __builtin_amdgcn_s_memtime() - ws_b0;
 #endif
@@ -496,8 +511,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     TRON_CHUNK(PERSIST, nchunks - 1, 0);
 
 #undef TRON_CHUNK
-#undef TRON_STORE_W
-#undef TRON_LOAD_W
+#undef TRON_DMA_W
 #undef TRON_STORE_IN
 #undef TRON_DIV
 #undef TRON_LOAD_IN
@@ -559,10 +573,16 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
                 const f32x4 sv = v * ACT_SCALE;
                 const f16x4 hh = __builtin_convertvector(sv, f16x4);
                 const f16x4 ll = __builtin_convertvector((sv - __builtin_convertvector(hh, f32x4)) * LO_SCALE, f16x4);
+                if (TRON_F16_ABLATE == 5) {   /* diagnostic: one store instead of eight, every value still computed */
+                    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+                    const u16x4 a = __builtin_bit_cast(u16x4, hh), b = __builtin_bit_cast(u16x4, ll);
+                    *reinterpret_cast<unsigned short *>(d) = (unsigned short)(a[0] ^ a[1] ^ a[2] ^ a[3] ^ b[0] ^ b[1] ^ b[2] ^ b[3]);
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     *reinterpret_cast<f16 *>(d + r * 32) = hh[r];
                     *reinterpret_cast<f16 *>(d + C::SS * 32 + r * 32) = ll[r];
+                }
                 }
             }
         }
@@ -590,6 +610,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
             acc0[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc1[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (the next group's weight chunk 0: LDS-DMA)
     __syncthreads();                                                    // the staged chunk is complete, the old buffers are free
     }
 }

@@ -14,7 +14,7 @@
 //     k_gemm_f16x3      C = act(A W^T + bias), A and W split f16 row-major; C as f32 and / or split f16
 //     k_q_head          actor2 (64 -> 4) in f32 + argmax
 // GEMM tile: 128 x 64 per 8-wave workgroup (wave = 32 x 32 = 2 x 2 MFMA tiles), K in chunks of 64 staged by 16-byte
-// copies into single-buffered LDS (55 KB: two to three workgroups share a CU and cover each other's barriers).
+// copies into single-buffered LDS (60 KB: two workgroups share a CU and cover each other's barriers).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -199,10 +199,11 @@ __global__ void k_dense7(const float *__restrict__ src, float *__restrict__ dst,
 }
 
 constexpr int GM = 128, GN = 64, GK = 64;          // workgroup tile, K chunk
-constexpr int GPITCH = GK * 2 + 16;                // bytes per LDS row (16 bytes of padding spread the banks)
+constexpr int GPITCH = GK * 2 + 32;                // bytes per LDS row: 32 mod 64 is conflict-free for ds_read_b128 by (row = lane % 16,
+                                                   // column = lane / 16) with the instruction's lane groups; 16 mod 32 (144) is two-way
 constexpr int G_THREADS = 512;
 constexpr int A_HALF = GM * GPITCH, W_HALF = GN * GPITCH;
-constexpr int G_LDS = 2 * A_HALF + 2 * W_HALF;     // 55 296 bytes
+constexpr int G_LDS = 2 * A_HALF + 2 * W_HALF;     // 61 440 bytes
 
 // C[M][N] = act((A W^T) * 64 + bias[n / bias_div]); A = Ah + Al 2^-11 (pre-scaled by 2^-6), W = Wh + Wl 2^-11, all f16
 // row-major with K contiguous.  N % 64 == 0, K % 64 == 0.  out_f32 and / or (out_h, out_l) (pre-scaled by 2^-6 again).
@@ -275,14 +276,20 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_f16x3(const f16 *__restri
                 bh[t] = *reinterpret_cast<const f16x8 *>(w_h + b_off + t * 16 * GPITCH + s * 64);
                 bl[t] = *reinterpret_cast<const f16x8 *>(w_l + b_off + t * 16 * GPITCH + s * 64);
             }
+            // hi*lo, hi*hi, lo*hi over the four tiles each: the lo*hi MFMA adds to the accumulator the hi*lo one wrote,
+            // and a dependent MFMA issues 48 cycles after its producer — eight MFMAs apart nobody waits
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc0[t][n], 0, 0, 0);
-                    acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc1[t][n], 0, 0, 0);
-                    acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc1[t][n], 0, 0, 0);
-                }
+                for (int n = 0; n < 2; ++n) acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc1[t][n], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc0[t][n], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc1[t][n], 0, 0, 0);
         }
         __syncthreads();                                                 // everyone is done reading this chunk
         if (kc + 1 < nk) {
