@@ -32,7 +32,7 @@
 #include "../../include/tron_hip.h"
 #include "tron_conv.hpp"
 
-#ifndef TRON_F16_ABLATE      // diagnostic builds only (wrong results): 1 = no staging of the next chunk, 2 = A fragments not re-read, 5 = one split-image store per tile instead of eight
+#ifndef TRON_F16_ABLATE      // diagnostic builds only (wrong results): 1 = no staging of the next chunk, 2 = A fragments not re-read, 5 = one split-image store per tile instead of eight, 6 = no weight copies, 7 = no input loads
 #define TRON_F16_ABLATE 0
 #endif
 
@@ -357,7 +357,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     // Weight chunk c_ -> LDS buffer wb_: its pre-split image is copied as it is, so it goes global -> LDS directly
     // (global_load_lds_dwordx4: per-lane source, destination = a wave-uniform base + 16 * lane) — no staging registers,
     // no ds_write_b128 (the slow store path: 13 cycles per wave-instruction), nothing to schedule into the MFMA loop.
-    // A copy is retired by the issuing wave's vmcnt(0) followed by the chunk barrier (__syncthreads emits both).
+    // A copy is retired by the issuing wave's vmcnt(0) followed by the chunk barrier.  (Tried on top of this and dropped:
+    // input pieces two chunks ahead in a second register set — with a DMA in flight, and across the chunk loop's back
+    // edge, hipcc waits vmcnt(0) at the first use of any staged register, which drains the younger loads as well, so the
+    // deeper prefetch buys nothing short of hand-placed waits around inline-asm loads: 1.26 -> 1.33 ms for the trunk.)
 #define TRON_DMA_W(wb_, c_)                                                                                          \
     do {                                                                                                              \
         _Pragma("unroll") for (int j = 0; j < W_LD; ++j) {                                                            \
@@ -378,8 +381,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         unsigned char *nxt_in_ = lds + (((c_) + 1) & 1) * IN_BUF;                                                     \
         unsigned char *nxt_w_ = lds + 2 * IN_BUF + (((c_) + 1) & 1) * W_BUF;                                          \
         if (STAGE_ && TRON_F16_ABLATE != 1 && TRON_F16_ABLATE != 4) {                                                 \
-            TRON_DMA_W(nxt_w_, cn_);                                                                                  \
-            TRON_LOAD_IN(cn_);                                                                                        \
+            if (TRON_F16_ABLATE != 6) TRON_DMA_W(nxt_w_, cn_);                                                        \
+            if (TRON_F16_ABLATE != 7) TRON_LOAD_IN(cn_);                                                              \
         }                                                                                                             \
         _Pragma("unroll") for (int s = 0; s < SLABS; ++s) {                                                           \
             /* Vector issue goes to the older wave of a SIMD first: left alone, waves 0-3 run each chunk ahead of waves  */ \
@@ -527,9 +530,11 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     // ---- epilogue (as tron_conv.hip): D row = 4 * (lane >> 4) + r (pixel), column = lane & 15 (channel) ------------
     int o[C::MT];
     bool live[C::MT];
-#pragma unroll
+    int g_e = g;                                                        // (an opaque copy: in the persistent variant the output
+    asm volatile("" : "+v"(g_e));                                       //  offsets below are loop-invariant, and hoisted they
+#pragma unroll                                                          //  would sit in registers across the whole MFMA loop)
     for (int t = 0; t < C::MT; ++t) {
-        const int px = 16 * (tile0 + t) + 4 * g;                         // npx is a multiple of 4: all four pixels or none
+        const int px = 16 * (tile0 + t) + 4 * g_e;                       // npx is a multiple of 4: all four pixels or none
         const int img = px / rpx, p = px - img * rpx;
         live[t] = t < my_mt && px < npx && img <= last_img;
         o[t] = (img * cout + wn * 16 * NT + li) * C::SS + r0 * S + p;
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
 #pragma unroll
     for (int t = 0; t < C::MT; ++t) {
         if (!live[t]) continue;
-        const int px = 16 * (tile0 + t) + 4 * g;
+        const int px = 16 * (tile0 + t) + 4 * g_e;
         const int img = px / rpx, pg = r0 * S + (px - img * rpx);        // image, pixel within the image
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
