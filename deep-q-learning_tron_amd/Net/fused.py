@@ -35,8 +35,31 @@ class Split16:
         self.buf = torch.empty(batch * channels * side * side * 4, dtype=torch.uint8, device=device)
 
 
+def split_weights(convs):
+    """The split-f16 weight images of several layers in ONE launch (tron_conv3x3_split_weights): a list of uint8 workspace
+    views, one per layer, to hand to conv3x3(..., presplit=ws).  Built afresh by every forward pass — nothing is cached."""
+    import ctypes as C
+    L = nat.lib()
+    n = len(convs)
+    dev = convs[0].weight.device
+    sizes = [(int(L.tron_conv3x3_workspace(c.in_channels, c.out_channels)) + 255) // 256 * 256 for c in convs]
+    buf = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+    views, off = [], 0
+    for sz in sizes:
+        views.append(buf[off:off + sz])
+        off += sz
+    ws = [c.weight.detach() if c.weight.is_contiguous() else c.weight.detach().contiguous() for c in convs]
+    wp = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
+    vp = (C.c_void_p * n)(*[v.data_ptr() for v in views])
+    ci = (C.c_int32 * n)(*[c.in_channels for c in convs])
+    co = (C.c_int32 * n)(*[c.out_channels for c in convs])
+    with torch.cuda.device(dev):
+        nat.check(L.tron_conv3x3_split_weights(wp, ci, co, vp, n, nat.stream_ptr()), "tron_conv3x3_split_weights")
+    return views
+
+
 def conv3x3_raw(x, weight, bias=None, residual=None, act=True, codes=False, plane4=0.0, want_pre=False, math=None,
-                want_f32=True, want_split=False):
+                want_f32=True, want_split=False, presplit=None):
     """act(conv3x3(x, weight, padding=1) + bias + residual) on tensors: weight f32 [Cout, Cin, 3, 3] as nn.Conv2d keeps
     it; x f32 [B, Cin, S, S], or (codes=True) int8 observation codes [B, S, S] standing for Cin pop_up planes, or a
     Split16 from the previous layer.  Returns the f32 output (None if want_f32=False), then — when asked — the
@@ -68,7 +91,9 @@ def conv3x3_raw(x, weight, bias=None, residual=None, act=True, codes=False, plan
         w = w.contiguous()
     m = MATH[math or default_math]
     ws = None
-    if m == nat.CONV_F16X3:        # scratch for the split weights, rewritten by every call
+    if m == nat.CONV_F16X3 and presplit is not None:      # this forward pass split its weights already (split_weights)
+        m, ws = nat.CONV_F16X3_PRESPLIT, presplit
+    elif m == nat.CONV_F16X3:      # scratch for the split weights, rewritten by every call
         ws = torch.empty(int(nat.lib().tron_conv3x3_workspace(cin, cout)), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         nat.check(nat.lib().tron_conv3x3_fwd(nat.ptr(xin), in_fmt, nat.ptr(w), nat.ptr(b), nat.ptr(res),
@@ -84,9 +109,10 @@ def conv3x3_raw(x, weight, bias=None, residual=None, act=True, codes=False, plan
 
 
 def conv3x3(x, conv, residual=None, act=True, codes=False, plane4=0.0, want_pre=False, math=None, want_f32=True,
-            want_split=False):
+            want_split=False, presplit=None):
     """conv3x3_raw on an nn.Conv2d module."""
-    return conv3x3_raw(x, conv.weight, conv.bias, residual, act, codes, plane4, want_pre, math, want_f32, want_split)
+    return conv3x3_raw(x, conv.weight, conv.bias, residual, act, codes, plane4, want_pre, math, want_f32, want_split,
+                       presplit)
 
 
 def trunk(net, x, codes=False, plane4=0.0, math=None):
@@ -102,12 +128,13 @@ def trunk(net, x, codes=False, plane4=0.0, math=None):
         idx = x
         x = conv3x3(x, net.conv5, math=math)
         return conv3x3(x, net.conv6, residual=idx, math=math)
-    idx, s = conv3x3(x, net.conv1, codes=codes, plane4=plane4, math=math, want_split=True)
-    _, s = conv3x3(s, net.conv2, math=math, want_f32=False, want_split=True)
-    _, s = conv3x3(s, net.conv3, residual=idx, math=math, want_f32=False, want_split=True)
-    idx, s = conv3x3(s, net.conv4, math=math, want_split=True)
-    _, s = conv3x3(s, net.conv5, math=math, want_f32=False, want_split=True)
-    return conv3x3(s, net.conv6, residual=idx, math=math)
+    w = split_weights([net.conv1, net.conv2, net.conv3, net.conv4, net.conv5, net.conv6])      # one launch for all six
+    idx, s = conv3x3(x, net.conv1, codes=codes, plane4=plane4, math=math, want_split=True, presplit=w[0])
+    _, s = conv3x3(s, net.conv2, math=math, want_f32=False, want_split=True, presplit=w[1])
+    _, s = conv3x3(s, net.conv3, residual=idx, math=math, want_f32=False, want_split=True, presplit=w[2])
+    idx, s = conv3x3(s, net.conv4, math=math, want_split=True, presplit=w[3])
+    _, s = conv3x3(s, net.conv5, math=math, want_f32=False, want_split=True, presplit=w[4])
+    return conv3x3(s, net.conv6, residual=idx, math=math, presplit=w[5])
 
 
 def conv3x3_dgrad(gp, weight, absmax=None):

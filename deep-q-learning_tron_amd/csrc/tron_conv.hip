@@ -439,7 +439,9 @@ extern "C" int tron_conv3x3_fwd(const void *in, int32_t in_fmt, const float *wei
     const int in_is_codes = in_fmt == TRON_CONV_IN_CODES;
     // the split-f16 activation image exists only between layers of the split kernel
     const bool needs_f16 = in_fmt == TRON_CONV_IN_SPLIT16 || out_split != nullptr;
-    if (needs_f16 && (math != TRON_CONV_F16X3 || !workspace || (side != 12 && side != 26) || cout % 16 != 0 ||
+    const bool f16x3 = math == TRON_CONV_F16X3 || math == TRON_CONV_F16X3_PRESPLIT;
+    if (math == TRON_CONV_F16X3_PRESPLIT && !workspace) return TRON_ERR_BAD_ARG;
+    if (needs_f16 && (!f16x3 || !workspace || (side != 12 && side != 26) || cout % 16 != 0 ||
                       (in_fmt == TRON_CONV_IN_SPLIT16 && cin % 16 != 0)))
         return TRON_ERR_UNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(out_split) & 15u) return TRON_ERR_BAD_ARG;
@@ -452,12 +454,12 @@ extern "C" int tron_conv3x3_fwd(const void *in, int32_t in_fmt, const float *wei
     if (in_is_codes && !small) return TRON_ERR_BAD_ARG;
     if (small ? cout != 32 : (cin % CIC != 0)) return TRON_ERR_UNSUPPORTED;
     if (batch > (1ll << 24)) return TRON_ERR_UNSUPPORTED;
-    if (math != TRON_CONV_F32 && math != TRON_CONV_F16X3) return TRON_ERR_BAD_ARG;
+    if (math != TRON_CONV_F32 && !f16x3) return TRON_ERR_BAD_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (math == TRON_CONV_F16X3) {      // shapes the split kernel has no instantiation for take the f32 kernel
+    if (f16x3) {                        // shapes the split kernel has no instantiation for take the f32 kernel
         if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15u)) return TRON_ERR_BAD_ARG;
         const int rc = tron_conv3x3_f16x3(in, in_fmt, weight, bias, residual, out, pre_out, batch, cin, cout, side,
-                                          plane4, apply_mish, workspace, out_split, 0, nullptr, 0, st);
+                                          plane4, apply_mish, workspace, out_split, 0, nullptr, 0, math == TRON_CONV_F16X3_PRESPLIT, st);
         if (rc != TRON_ERR_UNSUPPORTED || needs_f16) return rc;
     }
 #define TRON_CONV_CASE(S_)                                                                                                \
@@ -485,7 +487,7 @@ extern "C" int tron_conv3x3_dgrad(const float *grad_pre, const float *weight, co
     if (batch == 0) return TRON_OK;
     if ((cin != 32 && cin != 64) || cout % CIC != 0 || cout < CIC || cout > 64 || batch > (1ll << 24)) return TRON_ERR_UNSUPPORTED;
     return tron_conv3x3_f16x3(grad_pre, TRON_CONV_IN_F32, weight, nullptr, nullptr, grad_in, nullptr, batch, cout, cin, side, 0.0f,
-                              0, workspace, nullptr, 1, grad_absmax, n_absmax, reinterpret_cast<hipStream_t>(stream));
+                              0, workspace, nullptr, 1, grad_absmax, n_absmax, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t tron_conv3x3_workspace(int32_t cin, int32_t cout) { return tron_conv3x3_f16x3_workspace(cin, cout); }

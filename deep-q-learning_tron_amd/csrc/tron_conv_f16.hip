@@ -144,6 +144,33 @@ __global__ void k_split_weights(const float *__restrict__ w, int cout, int cin, 
     }
 }
 
+// the same for up to SPLIT_MAX layers in one launch (blockIdx.y = layer): a forward pass splits all its weights at once
+constexpr int SPLIT_MAX = 8;
+struct SplitJobs {
+    const float *w[SPLIT_MAX];
+    f16 *ws[SPLIT_MAX];
+    int cout[SPLIT_MAX], cin[SPLIT_MAX];
+};
+__global__ void k_split_weights_multi(SplitJobs jobs)
+{
+    const int k = blockIdx.y, cout = jobs.cout[k], cin = jobs.cin[k], nchunks = (cin + CIC - 1) / CIC;
+    const float *__restrict__ w = jobs.w[k];
+    f16 *__restrict__ ws = jobs.ws[k];
+    const int per_half = TAPS_PAD * cout * CIC;
+    const int total = nchunks * per_half;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i / per_half, r = i - c * per_half;
+        const int tap = r / (cout * CIC), r2 = r - tap * (cout * CIC);
+        const int co = r2 / CIC, cl = r2 - co * CIC;
+        const int ci = c * CIC + cl;
+        const float v = (tap < 9 && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.0f;
+        f16 h, l;
+        split(v, h, l);
+        ws[(size_t)c * 2 * per_half + r] = h;
+        ws[(size_t)c * 2 * per_half + per_half + r] = l;
+    }
+}
+
 // SMALL = the conv1 instantiation (cin 3 or 4: one chunk whose absent channels are zero; input = int8 observation
 // codes when in_codes, else the f32 planes).  NT 16-channel tiles per wave: cout = 32 * NT.
 // PERSIST (an even number of chunks): a workgroup walks image groups blockIdx.x, + gridDim.x, ... and stages the
@@ -658,6 +685,27 @@ extern "C" int tron_conv_wave_stamps(unsigned long long *host_dst)
 }
 #endif
 
+extern "C" int tron_conv3x3_split_weights(const float *const *weights, const int32_t *cins, const int32_t *couts,
+                                          void *const *workspaces, int32_t n, void *stream)
+{
+    if (!weights || !cins || !couts || !workspaces || n < 1 || n > SPLIT_MAX) return TRON_ERR_BAD_ARG;
+    SplitJobs jobs{};
+    int most = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!weights[k] || !workspaces[k] || cins[k] < 1 || couts[k] < 1 || cins[k] > 1024 || couts[k] > 1024 ||
+            (reinterpret_cast<uintptr_t>(workspaces[k]) & 15u))
+            return TRON_ERR_BAD_ARG;
+        jobs.w[k] = weights[k];
+        jobs.ws[k] = reinterpret_cast<f16 *>(workspaces[k]);
+        jobs.cin[k] = cins[k];
+        jobs.cout[k] = couts[k];
+        const int total = (cins[k] + CIC - 1) / CIC * TAPS_PAD * couts[k] * CIC;
+        most = total > most ? total : most;
+    }
+    hipLaunchKernelGGL(k_split_weights_multi, dim3((most + 255) / 256, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
 int64_t tron_conv3x3_f16x3_workspace(int cin, int cout)
 {
     const int64_t nchunks = (cin + CIC - 1) / CIC;
@@ -668,14 +716,15 @@ int64_t tron_conv3x3_f16x3_workspace(int cin, int cout)
 int tron_conv3x3_f16x3(const void *in, int in_fmt, const float *weight, const float *bias, const float *residual,
                        float *out, float *pre_out, int64_t batch, int cin, int cout, int side, float plane4,
                        int apply_mish, void *workspace, void *out_split, int dgrad, const float *grad_absmax,
-                       int n_absmax, hipStream_t st)
+                       int n_absmax, int presplit, hipStream_t st)
 {
     const bool small = cin == 3 || cin == 4;
     if ((side != 12 && side != 26) || (!small && cin % CIC != 0) || !workspace) return TRON_ERR_UNSUPPORTED;
     f16 *ws = reinterpret_cast<f16 *>(workspace);
     const int nchunks = (cin + CIC - 1) / CIC;
     const int total = nchunks * TAPS_PAD * cout * CIC;
-    hipLaunchKernelGGL(k_split_weights, dim3((total + 255) / 256), dim3(256), 0, st, weight, cout, cin, nchunks, dgrad, ws);
+    if (!presplit)
+        hipLaunchKernelGGL(k_split_weights, dim3((total + 255) / 256), dim3(256), 0, st, weight, cout, cin, nchunks, dgrad, ws);
     const bool persist = !small && nchunks % 2 == 0;
 #define TRON_F16_ARGS in, ws, bias, residual, out, pre_out, batch, cin, plane4, apply_mish, in_fmt, out_split, grad_absmax, n_absmax, st
 #define TRON_F16_CASE(S_, PERSIST_OK_)                                                                                    \

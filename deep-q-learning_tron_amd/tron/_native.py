@@ -21,7 +21,7 @@ STEP_NONREVERSING = 4
 ROLLOUT_PER_STEP = 8
 ROLLOUT_TWO_STREAMS = 16
 ROLLOUT_RESIDENT = 32
-CONV_F32, CONV_F16X3 = 0, 1
+CONV_F32, CONV_F16X3, CONV_F16X3_PRESPLIT = 0, 1, 3
 CONV_IN_F32, CONV_IN_CODES, CONV_IN_SPLIT16 = 0, 1, 2
 
 _vp, _i32, _i64, _u32, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_double
@@ -64,6 +64,7 @@ SIGNATURES = {
     "tron_synchronize": (C.c_int, [_vp]),
     "tron_conv3x3_fwd": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp]),
     "tron_conv3x3_workspace": (C.c_int64, [_i32, _i32]),
+    "tron_conv3x3_split_weights": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "tron_conv3x3_wgrad": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "tron_conv3x3_wgrad_workspace": (C.c_int64, [_i32, _i32]),
     "tron_conv3x3_dgrad": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),

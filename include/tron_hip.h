@@ -278,7 +278,7 @@ int tron_bias_mish_bwd(const float *y_pre, const float *grad_out, float *grad_pr
  * Shapes the split kernel does not cover (side 26) silently use the f32 kernel.  workspace: caller-owned device
  * scratch of at least tron_conv3x3_workspace(cin, cout) bytes for the split weights (written afresh by every call,
  * so nothing cached can go stale); only TRON_CONV_F16X3 needs it (NULL there means: use the f32 kernel).     */
-enum { TRON_CONV_F32 = 0, TRON_CONV_F16X3 = 1 };
+enum { TRON_CONV_F32 = 0, TRON_CONV_F16X3 = 1, TRON_CONV_F16X3_PRESPLIT = 3 };
 /* in_fmt: what `in` holds.  TRON_CONV_IN_SPLIT16 / out_split (may be NULL) chain layers of the split kernel without
  * re-splitting: out_split receives the layer's output as the operand halves the next layer stages — per image
  * [16-channel chunk][hi | lo][pixel][16 ci] f16, batch * cout * side * side * 4 bytes like the f32 tensor — and a
@@ -290,6 +290,12 @@ int tron_conv3x3_fwd(const void *in, int32_t in_fmt, const float *weight, const 
                      int32_t cout, int32_t side, float plane4, int32_t apply_mish, int32_t math, void *workspace,
                      void *out_split, void *stream);
 int64_t tron_conv3x3_workspace(int32_t cin, int32_t cout);
+/* A forward pass over several layers can split all their weights in ONE launch and hand each layer its workspace with
+ * math = TRON_CONV_F16X3_PRESPLIT (same arithmetic; the per-call split kernel is skipped): weights[k] f32[couts[k]]
+ * [cins[k]][3][3] -> workspaces[k] (>= tron_conv3x3_workspace(cins[k], couts[k]) bytes, 16-byte aligned), n <= 8 layers.
+ * The arrays are host arrays.  Still nothing cached: the caller splits again whenever it forwards again.            */
+int tron_conv3x3_split_weights(const float *const *weights, const int32_t *cins, const int32_t *couts,
+                               void *const *workspaces, int32_t n, void *stream);
 
 /* The weight gradient of the same convolutions (loss.backward() through conv1..conv6, DDQN.py:148):
  * grad_weight[co][ci][ky][kx] = sum over b, y, x of grad_pre[b][co][y][x] * in[b][ci][y+ky-1][x+kx-1], overwritten (not

@@ -354,3 +354,23 @@ def test_net_forward_uses_dense_tail_and_matches_plain_module(fused):
     assert (q.double() - ref).abs().max().item() < TOL
     for a, p in zip(g1, net.parameters()):
         assert (a.double() - p.grad).abs().max().item() < 2e-5 * max(1.0, p.grad.abs().max().item())
+
+
+def test_presplit_weights_give_the_same_bits(fused):
+    """tron_conv3x3_split_weights (all layers' weight images in one launch) + TRON_CONV_F16X3_PRESPLIT == the per-call
+    split: same kernel, same operands."""
+    torch.manual_seed(11)
+    convs = [torch.nn.Conv2d(4, 32, 3, padding=1).cuda(), torch.nn.Conv2d(32, 64, 3, padding=1).cuda(),
+             torch.nn.Conv2d(64, 64, 3, padding=1).cuda()]
+    ws = fused.split_weights(convs)
+    x = torch.randn(77, 4, 12, 12, device="cuda")
+    for conv, w in zip(convs, ws):
+        a = fused.conv3x3(x, conv, math="f16x3")
+        b = fused.conv3x3(x, conv, math="f16x3", presplit=w)
+        assert torch.equal(a, b)
+        x = a
+    from tron import _native as nat
+    import ctypes as C
+    one = (C.c_void_p * 1)(convs[0].weight.data_ptr())
+    assert nat.lib().tron_conv3x3_split_weights(one, (C.c_int32 * 1)(4), (C.c_int32 * 1)(32), (C.c_void_p * 1)(None), 1, None) == nat.ERR_BAD_ARG
+    assert nat.lib().tron_conv3x3_split_weights(one, (C.c_int32 * 1)(4), (C.c_int32 * 1)(32), (C.c_void_p * 1)(ws[0].data_ptr()), 9, None) == nat.ERR_BAD_ARG
