@@ -189,8 +189,9 @@ def pool_conv7_mish(pool, conv, x):
 
 
 def conv_bias_mish(conv, x, residual=None):
-    """mish(conv(x) + residual) with the bias add, the residual add and the activation fused behind the
-    (bias-free) MIOpen convolution when the tensors allow it; otherwise the plain composition."""
+    """mish(conv(x) + residual): the 3x3 layers on the hand-written convolution kernels (forward, input and weight
+    gradient: _ConvBiasMishHIP) where they cover the shape; otherwise the library convolution with the bias add, the
+    residual add and the activation fused behind it (_BiasMish), or the plain composition."""
     if (x.is_cuda and x.dtype == torch.float32 and conv.bias is not None and isinstance(conv, torch.nn.Conv2d)):
         from Net import fused
         if (fused.supported(conv, x.shape[-1]) and x.shape[-2] == x.shape[-1] and _aligned16(x, residual)

@@ -1,11 +1,14 @@
-"""Inference path of the reference's CNN trunk on the hand-written HIP kernels (csrc/tron_conv.hip): the six
-3x3 convolutions of Net/DQNNet.py:10-17,33-50 (and the identical stacks of Net/ACNet.py), each ONE launch that
-does convolution + bias + residual + mish on the fp32 matrix cores, with conv1 reading the env's int8
-observation codes directly (the f32 pop_up planes of util.py:11-37 are built inside the kernel).
+"""The CNN's gradient-free path on the hand-written HIP kernels: the six 3x3 convolutions of Net/DQNNet.py:10-17,33-50
+(and the identical stacks of Net/ACNet.py) — each ONE launch that does convolution + bias + residual + mish on the
+matrix cores (csrc/tron_conv_f16.hip: split-f16 arithmetic; csrc/tron_conv.hip: exact f32), conv1 reading the env's
+int8 observation codes directly (the f32 pop_up planes of util.py:11-37 are built inside the kernel), layers chained
+through the split-f16 image — and the rest of the net (pool, conv7, linear layers, arg-max: csrc/tron_head.hip).  Also the
+raw wrappers of the gradient kernels (tron_conv3x3_dgrad / _wgrad) that Net/activations.py's autograd functions call.
 
 Used for every forward that needs no gradient: the epsilon-greedy policy over 2N observations per env step
 (DDQN.py:90-110) and the two target-side forwards of a learn step (DDQN.py:129-142).  There is no fallback in
-here: unsupported shapes are reported by `supported()` and the callers keep the PyTorch modules for those.
+here: unsupported shapes are reported by `supported()` / `head_supported()` and the callers keep the PyTorch modules
+for those.
 """
 import torch
 
