@@ -18,6 +18,12 @@ from Net.activations import (mish as _mish, conv_bias_mish as _conv_bias_mish, p
                              pool_conv7_supported as _pool_conv7_supported)
 
 
+def _pool_is_reference(pool):
+    """AvgPool2d(kernel_size=3, padding=1, stride=2) as DQNNet.py:20 builds it."""
+    return (isinstance(pool, nn.AvgPool2d) and pool.kernel_size == 3 and pool.stride == 2 and pool.padding == 1
+            and pool.count_include_pad and not pool.ceil_mode and pool.divisor_override is None)
+
+
 def conv7_side(side):
     """Spatial side after avgpool(k3,s2,p1) then conv7(k7,s2,p3) (DQNNet.py:20,22)."""
     pooled = (side + 2 - 3) // 2 + 1
@@ -119,7 +125,10 @@ class Net(nn.Module):
             x = fused.trunk(self, x.reshape(-1, side, side) if codes else x, codes=codes, plane4=plane4)
             if fused.default_math == "f16x3" and fused.head_supported(self, side):
                 return fused.head(self, x, want_q=False, want_greedy=True)[1] if greedy else fused.head(self, x)
-            x = self.pool(x)
+            if side in (12, 26) and _pool_is_reference(self.pool):
+                x = fused.pool_s2(x)                                     # (torch's avg_pool2d runs at a quarter of the memory rate)
+            else:
+                x = self.pool(x)
             x = _conv_bias_mish(self.conv7, x)
             x = x.reshape(-1, self.flat)
             x = _mish(self.fc1(x))

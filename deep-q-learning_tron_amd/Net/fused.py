@@ -206,3 +206,15 @@ def head(net, x, want_q=True, want_greedy=False):
                                       net.actor2.weight.data_ptr(), net.actor2.bias.data_ptr(), ws.data_ptr(), ptr(q),
                                       ptr(g), torch.cuda.current_stream(x.device).cuda_stream), "tron_dqn_head_fwd")
     return (q, g) if want_greedy else q
+
+
+def pool_s2(x):
+    """AvgPool2d(3, stride 2, padding 1) of f32 [B, C, S, S], S 12 or 26 (tron_pool_s2; DQNNet.py:20,52)."""
+    B, C, S, _ = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and S in (12, 26)
+    y = torch.empty(B, C, S // 2, S // 2, dtype=torch.float32, device=x.device)
+    if B:
+        with torch.cuda.device(x.device):
+            nat.check(nat.lib().tron_pool_s2(x.data_ptr(), y.data_ptr(), B * C, S, torch.cuda.current_stream(x.device).cuda_stream),
+                      "tron_pool_s2")
+    return y

@@ -146,6 +146,36 @@ __global__ __launch_bounds__(256) void k_pool12(const float *__restrict__ x, int
     }
 }
 
+// The same pooling for the other board sizes (26 x 26 planes: the 24x24 boards' tail is pooling + library kernels): one
+// thread = one pooled row of one plane, the three input rows as 8-byte loads (a row of an even side is 8-byte aligned).
+template <int S>
+__global__ __launch_bounds__(256) void k_pool_rows(const float *__restrict__ x, int64_t rows, float *__restrict__ y)
+{
+    constexpr int PS = S / 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += stride) {
+        const int py = (int)(i % PS);
+        const float *p = x + (i / PS) * (S * S);
+        float col[S + 1];                                                // col[1 + xx] = sum over the 3 rows; col[0] = pad
+#pragma unroll
+        for (int k = 0; k <= S; ++k) col[k] = 0.0f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = 2 * py + dy;
+            if (yy < 0) continue;                                        // yy <= S - 1 always
+#pragma unroll
+            for (int q = 0; q < S / 2; ++q) {
+                const float2 v = *reinterpret_cast<const float2 *>(p + yy * S + 2 * q);
+                col[1 + 2 * q] += v.x;
+                col[2 + 2 * q] += v.y;
+            }
+        }
+        float *d = y + i * PS;
+#pragma unroll
+        for (int px = 0; px < PS; ++px) d[px] = (col[2 * px] + col[2 * px + 1] + col[2 * px + 2]) * (1.0f / 9.0f);
+    }
+}
+
 // its backward: gx[y][x] = (1/9) * sum of gy over the windows that contain (y, x) — rows (y+1)/2 and, for odd y, also
 // (y+2)/2... written per INPUT row: one thread = one input row of 12, 16-byte stores
 __global__ __launch_bounds__(256) void k_pool12_bwd(const float *__restrict__ gy, int64_t rows, float *__restrict__ gx)
@@ -447,6 +477,20 @@ extern "C" int tron_pool12(const float *x, float *y, int64_t planes, int32_t bac
     const unsigned blocks = (unsigned)((rows + 255) / 256 < (1 << 20) ? (rows + 255) / 256 : (1 << 20));
     if (backward) hipLaunchKernelGGL(k_pool12_bwd, dim3(blocks), dim3(256), 0, st, x, rows, y);
     else hipLaunchKernelGGL(k_pool12, dim3(blocks), dim3(256), 0, st, x, rows, y);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int tron_pool_s2(const float *x, float *y, int64_t planes, int32_t side, void *stream)
+{
+    if (!x || !y || planes < 0) return TRON_ERR_BAD_ARG;
+    if (planes == 0) return TRON_OK;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) return TRON_ERR_BAD_ARG;
+    if (side == 12) return tron_pool12(x, y, planes, 0, stream);
+    if (side != 26) return TRON_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t rows = planes * (side / 2);
+    const unsigned blocks = (unsigned)((rows + 255) / 256 < (1 << 20) ? (rows + 255) / 256 : (1 << 20));
+    hipLaunchKernelGGL(k_pool_rows<26>, dim3(blocks), dim3(256), 0, st, x, rows, y);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 

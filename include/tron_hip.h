@@ -340,6 +340,9 @@ int64_t tron_dqn_head_workspace(int64_t batch, int32_t side);
  * matrix f32[cout*9][cin*36] that maps a flattened 6x6 input to the flattened 3x3 output of the 7x7 / stride 2 / pad 3
  * convolution (DQNNet.py:22,53); fold 1: that matrix's gradient -> the weight's gradient.                          */
 int tron_pool12(const float *x, float *y, int64_t planes, int32_t backward, void *stream);
+/* The forward pooling for the other supported board size as well: side 12 or 26 (24x24 boards, whose tail is this plus
+ * library kernels) -> side/2; other sides TRON_ERR_UNSUPPORTED.                                                    */
+int tron_pool_s2(const float *x, float *y, int64_t planes, int32_t side, void *stream);
 int tron_conv7_dense(const float *src, float *dst, int32_t cout, int32_t cin, int32_t fold, void *stream);
 
 /* Wait for `stream` and report what the kernels queued on it did: launch_status-style calls above only

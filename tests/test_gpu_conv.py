@@ -374,3 +374,12 @@ def test_presplit_weights_give_the_same_bits(fused):
     one = (C.c_void_p * 1)(convs[0].weight.data_ptr())
     assert nat.lib().tron_conv3x3_split_weights(one, (C.c_int32 * 1)(4), (C.c_int32 * 1)(32), (C.c_void_p * 1)(None), 1, None) == nat.ERR_BAD_ARG
     assert nat.lib().tron_conv3x3_split_weights(one, (C.c_int32 * 1)(4), (C.c_int32 * 1)(32), (C.c_void_p * 1)(ws[0].data_ptr()), 9, None) == nat.ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("S,B", [(26, 3), (26, 130), (12, 5)])
+def test_pool_s2_matches_avg_pool2d(fused, S, B):
+    torch.manual_seed(S + B)
+    x = torch.randn(B, 64, S, S, device="cuda")
+    y = fused.pool_s2(x)
+    ref = F.avg_pool2d(x.double(), 3, stride=2, padding=1)
+    assert y.shape == ref.shape and (y.double() - ref).abs().max().item() < 1e-6
