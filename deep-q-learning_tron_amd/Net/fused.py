@@ -180,16 +180,18 @@ def conv3x3_wgrad(x, gp, absmax=None):
 
 
 def head_supported(net, side):
-    """tron_dqn_head_fwd covers the reference's own geometry: 12x12 observations, 64*3*3 into fc1 (DQNNet.py:24,55)."""
-    return (side == 12 and getattr(net, "flat", 0) == 576 and net.conv7.weight.shape == (64, 64, 7, 7)
-            and net.fc1.weight.shape == (256, 576) and net.fc2.weight.shape == (128, 256)
+    """tron_dqn_head_fwd covers the reference's own geometry — 12x12 observations, 64*3*3 into fc1 (DQNNet.py:24,55) — and
+    the 24x24 boards' (26x26 observations, 64*7*7)."""
+    flat = {12: 576, 26: 3136}.get(side)              # 64 x 3 x 3 (10x10 boards, the reference's own) / 64 x 7 x 7 (24x24)
+    return (flat is not None and getattr(net, "flat", 0) == flat and net.conv7.weight.shape == (64, 64, 7, 7)
+            and net.fc1.weight.shape == (256, flat) and net.fc2.weight.shape == (128, 256)
             and net.actor1.weight.shape == (64, 128) and net.actor2.weight.shape == (4, 64)
             and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in net.parameters()))
 
 
 def head(net, x, want_q=True, want_greedy=False):
     """pool -> conv7 -> flatten -> fc1 -> fc2 -> actor1 -> actor2 (DQNNet.py:52-63, eval mode) on the trunk's f32 output
-    [B, 64, 12, 12] in one library call (csrc/tron_head.hip).  Returns Q [B, 4] and / or the greedy action int8 [B]."""
+    [B, 64, 12, 12] or [B, 64, 26, 26] in one library call (csrc/tron_head.hip).  Returns Q [B, 4] and / or the greedy action int8 [B]."""
     L = nat.lib()
     B, side = x.shape[0], x.shape[-1]
     assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape[1:]) == (64, side, side), x.shape

@@ -228,6 +228,78 @@ __global__ void k_dense7(const float *__restrict__ src, float *__restrict__ dst,
     }
 }
 
+// ---- 24x24 boards: 26x26 trunk planes -> 13x13 pooled -> conv7 -> 7x7 ---------------------------------------------------
+// avg-pool 3/2/1 of x f32 [B][64][26][26] into the zero-haloed channels-last split image [B][19][19][64] (pooled pixel
+// (py, px) at padded (py + 3, px + 3)), pre-scaled by 2^-6.  One workgroup = one padded row of one image: the 64 x 13
+// results go through LDS so that the stores are contiguous 128-byte pixels; halo rows and columns are written as zeros.
+__global__ __launch_bounds__(256) void k_pool_split26(const float *__restrict__ x, f16 *__restrict__ oh, f16 *__restrict__ ol)
+{
+    constexpr int S = 26, PS = 13, C = 64;
+    __shared__ f16 th[PS * C], tl[PS * C];                               // [px][c]
+    const int r = blockIdx.x % 19, py = r - 3;
+    const int64_t b = blockIdx.x / 19;
+    if (py >= 0 && py < PS) {
+        const float *img = x + b * C * S * S;
+        for (int i = threadIdx.x; i < C * PS; i += 256) {
+            const int c = i / PS, px = i - c * PS;                       // lanes walk a row of one channel
+            const float *p = img + (size_t)c * S * S;
+            float sum = 0.0f;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = 2 * py + dy;
+                if (yy < 0) continue;                                    // yy <= 25 always
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = 2 * px + dx;
+                    if (xx >= 0) sum += p[yy * S + xx];                  // xx <= 25 always
+                }
+            }
+            f16 h, l;
+            split(sum * (1.0f / 9.0f) * ACT_SCALE, h, l);
+            th[px * C + c] = h;
+            tl[px * C + c] = l;
+        }
+    }
+    __syncthreads();
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const size_t row = ((size_t)b * 19 + r) * 19 * C;
+    for (int i = threadIdx.x; i < 19 * C / 2; i += 256) {               // two channels per thread: 4-byte stores
+        const int pix = (2 * i) / C, c = (2 * i) - pix * C, px = pix - 3;
+        const bool in = py >= 0 && py < PS && px >= 0 && px < PS;
+        const f16x2 h = in ? (f16x2){th[px * C + c], th[px * C + c + 1]} : (f16x2){(f16)0.0f, (f16)0.0f};
+        const f16x2 l = in ? (f16x2){tl[px * C + c], tl[px * C + c + 1]} : (f16x2){(f16)0.0f, (f16)0.0f};
+        *reinterpret_cast<f16x2 *>(oh + row + 2 * i) = h;
+        *reinterpret_cast<f16x2 *>(ol + row + 2 * i) = l;
+    }
+}
+
+// conv7's weight [64][64][7][7] -> [co][tap = 7 ky + kx][ci], split: the W matrix of the CONV7 GEMM
+__global__ void k_conv7w_split(const float *__restrict__ w, f16 *__restrict__ oh, f16 *__restrict__ ol)
+{
+    const int total = 64 * 49 * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i / (49 * 64), r = i - co * (49 * 64), tap = r / 64, ci = r - tap * 64;
+        f16 h, l;
+        split(w[((size_t)co * 64 + ci) * 49 + tap], h, l);
+        oh[i] = h;
+        ol[i] = l;
+    }
+}
+
+// fc1's weight [256][64 * 49] (columns in NCHW flatten order co * 49 + p) -> columns in the CONV7 GEMM's output order
+// p * 64 + co, split
+__global__ void k_fc1_split_nhwc(const float *__restrict__ w, f16 *__restrict__ oh, f16 *__restrict__ ol)
+{
+    const int total = 256 * 3136;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int n = i / 3136, k = i - n * 3136, p = k / 64, co = k - p * 64;
+        f16 h, l;
+        split(w[(size_t)n * 3136 + co * 49 + p], h, l);
+        oh[i] = h;
+        ol[i] = l;
+    }
+}
+
 constexpr int GM = 128, GN = 64, GK = 64;          // workgroup tile, K chunk
 constexpr int GPITCH = GK * 2 + 32;                // bytes per LDS row: 32 mod 64 is conflict-free for ds_read_b128 by (row = lane % 16,
                                                    // column = lane / 16) with the instruction's lane groups; 16 mod 32 (144) is two-way
@@ -237,6 +309,29 @@ constexpr int G_LDS = 2 * A_HALF + 2 * W_HALF;     // 61 440 bytes
 
 // C[M][N] = act((A W^T) * 64 + bias[n / bias_div]); A = Ah + Al 2^-11 (pre-scaled by 2^-6), W = Wh + Wl 2^-11, all f16
 // row-major with K contiguous.  N % 64 == 0, K % 64 == 0.  out_f32 and / or (out_h, out_l) (pre-scaled by 2^-6 again).
+//
+// CONV7 (24x24 boards): the same GEMM as the 7x7 / stride 2 / pad 3 convolution of 13x13 pooled planes — A is then the
+// zero-haloed channels-last split image [image][19 x 19 pixels][64 ci] (k_pool_split26), row m = (image, oy, ox) starts
+// at padded pixel (2 oy, 2 ox), and K chunk kc (64 channels of tap (ky, kx) = (kc / 7, kc % 7)) lies (19 ky + kx) pixels
+// further: an implicit GEMM whose im2col is two integer divisions per staged row.  W is conv7's weight as
+// [co][tap][ci] (k_conv7w_split); the output rows [image][oy][ox][co] are the next GEMM's A rows as they are.
+constexpr int P7_PIX = 19 * 19, O7 = 7, O7_PIX = O7 * O7;
+template <bool CONV7>
+__device__ __forceinline__ size_t a_row_bytes(int m, int K)
+{
+    if (!CONV7) return (size_t)m * K * 2;
+    const int b = m / O7_PIX, p = m - b * O7_PIX, oy = p / O7, ox = p - oy * O7;
+    return ((size_t)b * P7_PIX + (2 * oy) * 19 + 2 * ox) * 128;
+}
+template <bool CONV7>
+__device__ __forceinline__ int a_chunk_bytes(int kc)
+{
+    if (!CONV7) return kc * GK * 2;
+    const int ky = kc / 7, kx = kc - ky * 7;
+    return (ky * 19 + kx) * 128;
+}
+
+template <bool CONV7>
 __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_f16x3(const f16 *__restrict__ Ah, const f16 *__restrict__ Al,
                                                              const f16 *__restrict__ Wh, const f16 *__restrict__ Wl,
                                                              const float *__restrict__ bias, int bias_div, int M, int N,
@@ -259,7 +354,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_f16x3(const f16 *__restri
             int m = m0 + row;
             m = m < M ? m : M - 1;
             ra[j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(half ? Al : Ah) +
-                                                     ((size_t)m * K + (size_t)kc * GK) * 2 + pc * 16);
+                                                     a_row_bytes<CONV7>(m, K) + a_chunk_bytes<CONV7>(kc) + pc * 16);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -386,13 +481,13 @@ inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 struct HeadPlan {                      // byte offsets into the workspace
     int64_t a7h, a7l, d7h, d7l, c7h, c7l, w1h, w1l, c1h, c1l, w2h, w2l, c2h, c2l, w3h, w3l, c3, total;
 };
-HeadPlan plan(int64_t B, int K7, int N7)
+HeadPlan plan(int64_t B, int K7, int N7, int64_t a7_per_image = 0, int d7_rows = 0)
 {
     HeadPlan p{};
     int64_t o = 0;
     auto take = [&](int64_t bytes) { const int64_t at = o; o = align256(o + bytes); return at; };
-    p.a7h = take(B * K7 * 2); p.a7l = take(B * K7 * 2);
-    p.d7h = take((int64_t)N7 * K7 * 2); p.d7l = take((int64_t)N7 * K7 * 2);
+    p.a7h = take(B * (a7_per_image ? a7_per_image : K7) * 2); p.a7l = take(B * (a7_per_image ? a7_per_image : K7) * 2);
+    p.d7h = take((int64_t)(d7_rows ? d7_rows : N7) * K7 * 2); p.d7l = take((int64_t)(d7_rows ? d7_rows : N7) * K7 * 2);
     p.c7h = take(B * N7 * 2); p.c7l = take(B * N7 * 2);
     p.w1h = take(256ll * N7 * 2); p.w1l = take(256ll * N7 * 2);
     p.c1h = take(B * 256 * 2); p.c1l = take(B * 256 * 2);
@@ -404,6 +499,7 @@ HeadPlan plan(int64_t B, int K7, int N7)
     return p;
 }
 
+template <bool CONV7>
 int gemm(const f16 *Ah, const f16 *Al, const f16 *Wh, const f16 *Wl, const float *bias, int bias_div, int64_t M, int N, int K,
          int act, float *out_f32, f16 *out_h, f16 *out_l, hipStream_t st)
 {
@@ -411,14 +507,15 @@ int gemm(const f16 *Ah, const f16 *Al, const f16 *Wh, const f16 *Wl, const float
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
     if (!(prepared & (1ull << (dev & 63)))) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3<CONV7>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 G_LDS) != hipSuccess)
             (void)hipGetLastError();
         prepared |= 1ull << (dev & 63);
     }
+    if (M >= (1ll << 31) || N % GN != 0 || K % GK != 0) return TRON_ERR_UNSUPPORTED;
     const int64_t blocks = ((M + GM - 1) / GM) * (N / GN);
-    hipLaunchKernelGGL(k_gemm_f16x3, dim3((unsigned)blocks), dim3(G_THREADS), G_LDS, st, Ah, Al, Wh, Wl, bias, bias_div, (int)M,
-                       N, K, act, out_f32, out_h, out_l);
+    hipLaunchKernelGGL(k_gemm_f16x3<CONV7>, dim3((unsigned)blocks), dim3(G_THREADS), G_LDS, st, Ah, Al, Wh, Wl, bias, bias_div,
+                       (int)M, N, K, act, out_f32, out_h, out_l);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
@@ -426,7 +523,8 @@ int gemm(const f16 *Ah, const f16 *Al, const f16 *Wh, const f16 *Wl, const float
 
 extern "C" int64_t tron_dqn_head_workspace(int64_t batch, int32_t side)
 {
-    if (batch < 1 || side != 12) return 0;
+    if (batch < 1 || (side != 12 && side != 26)) return 0;
+    if (side == 26) return plan(batch, 64 * 49, 64 * 49, (int64_t)P7_PIX * 64, 64).total;   // (K7 = conv7's 49 taps x 64 ci)
     return plan(batch, 64 * 6 * 6, 64 * 3 * 3).total;
 }
 
@@ -439,10 +537,32 @@ extern "C" int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t 
         !actor2_w || !actor2_b || !workspace || (!q_out && !greedy_out) || batch < 0)
         return TRON_ERR_BAD_ARG;
     if (batch == 0) return TRON_OK;
-    if (side != 12 || batch > (1ll << 24)) return TRON_ERR_UNSUPPORTED;       // 6x6 pooled planes, 3x3 after conv7
+    if ((side != 12 && side != 26) || batch > (side == 12 ? (1ll << 24) : (1ll << 22))) return TRON_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(trunk_out) | reinterpret_cast<uintptr_t>(q_out)) & 15u)
         return TRON_ERR_BAD_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (side == 26) {                                                    // 13x13 pooled planes, 7x7 after conv7: fc1 takes 64 * 49
+        constexpr int K7 = 64 * 49, N1 = 64 * 49;
+        const HeadPlan p = plan(batch, K7, N1, (int64_t)P7_PIX * 64, 64);
+        unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+        auto H = [&](int64_t off) { return reinterpret_cast<f16 *>(ws + off); };
+        hipLaunchKernelGGL(k_pool_split26, dim3((unsigned)(batch * 19)), dim3(256), 0, st, trunk_out, H(p.a7h), H(p.a7l));
+        hipLaunchKernelGGL(k_conv7w_split, dim3((64 * K7 + 255) / 256), dim3(256), 0, st, conv7_w, H(p.d7h), H(p.d7l));
+        hipLaunchKernelGGL(k_fc1_split_nhwc, dim3((256 * N1 + 255) / 256), dim3(256), 0, st, fc1_w, H(p.w1h), H(p.w1l));
+        hipLaunchKernelGGL(k_split_rows, dim3((128 * 256 + 255) / 256), dim3(256), 0, st, fc2_w, 128 * 256, H(p.w2h), H(p.w2l));
+        hipLaunchKernelGGL(k_split_rows, dim3((64 * 128 + 255) / 256), dim3(256), 0, st, actor1_w, 64 * 128, H(p.w3h), H(p.w3l));
+        if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
+        // conv7 as the implicit GEMM [B * 49] x [64] over K = 49 taps x 64 channels; its output rows are fc1's input rows
+        int rc = gemm<true>(H(p.a7h), H(p.a7l), H(p.d7h), H(p.d7l), conv7_b, 1, batch * O7_PIX, 64, K7, 1, nullptr, H(p.c7h), H(p.c7l), st);
+        if (rc == TRON_OK) rc = gemm<false>(H(p.c7h), H(p.c7l), H(p.w1h), H(p.w1l), fc1_b, 1, batch, 256, N1, 1, nullptr, H(p.c1h), H(p.c1l), st);
+        if (rc == TRON_OK) rc = gemm<false>(H(p.c1h), H(p.c1l), H(p.w2h), H(p.w2l), fc2_b, 1, batch, 128, 256, 1, nullptr, H(p.c2h), H(p.c2l), st);
+        float *c3 = reinterpret_cast<float *>(ws + p.c3);
+        if (rc == TRON_OK) rc = gemm<false>(H(p.c2h), H(p.c2l), H(p.w3h), H(p.w3l), actor1_b, 1, batch, 64, 128, 1, c3, nullptr, nullptr, st);
+        if (rc != TRON_OK) return rc;
+        hipLaunchKernelGGL(k_q_head, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, c3, actor2_w, actor2_b, (int)batch, 64,
+                           q_out, greedy_out);
+        return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+    }
     constexpr int C = 64, PS = 6, OS = 3, K7 = C * PS * PS, N7 = C * OS * OS;
     const HeadPlan p = plan(batch, K7, N7);
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
@@ -454,11 +574,11 @@ extern "C" int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t 
     hipLaunchKernelGGL(k_split_rows, dim3((128 * 256 + 255) / 256), dim3(256), 0, st, fc2_w, 128 * 256, H(p.w2h), H(p.w2l));
     hipLaunchKernelGGL(k_split_rows, dim3((64 * 128 + 255) / 256), dim3(256), 0, st, actor1_w, 64 * 128, H(p.w3h), H(p.w3l));
     if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
-    int rc = gemm(H(p.a7h), H(p.a7l), H(p.d7h), H(p.d7l), conv7_b, OS * OS, batch, N7, K7, 1, nullptr, H(p.c7h), H(p.c7l), st);
-    if (rc == TRON_OK) rc = gemm(H(p.c7h), H(p.c7l), H(p.w1h), H(p.w1l), fc1_b, 1, batch, 256, N7, 1, nullptr, H(p.c1h), H(p.c1l), st);
-    if (rc == TRON_OK) rc = gemm(H(p.c1h), H(p.c1l), H(p.w2h), H(p.w2l), fc2_b, 1, batch, 128, 256, 1, nullptr, H(p.c2h), H(p.c2l), st);
+    int rc = gemm<false>(H(p.a7h), H(p.a7l), H(p.d7h), H(p.d7l), conv7_b, OS * OS, batch, N7, K7, 1, nullptr, H(p.c7h), H(p.c7l), st);
+    if (rc == TRON_OK) rc = gemm<false>(H(p.c7h), H(p.c7l), H(p.w1h), H(p.w1l), fc1_b, 1, batch, 256, N7, 1, nullptr, H(p.c1h), H(p.c1l), st);
+    if (rc == TRON_OK) rc = gemm<false>(H(p.c1h), H(p.c1l), H(p.w2h), H(p.w2l), fc2_b, 1, batch, 128, 256, 1, nullptr, H(p.c2h), H(p.c2l), st);
     float *c3 = reinterpret_cast<float *>(ws + p.c3);
-    if (rc == TRON_OK) rc = gemm(H(p.c2h), H(p.c2l), H(p.w3h), H(p.w3l), actor1_b, 1, batch, 64, 128, 1, c3, nullptr, nullptr, st);
+    if (rc == TRON_OK) rc = gemm<false>(H(p.c2h), H(p.c2l), H(p.w3h), H(p.w3l), actor1_b, 1, batch, 64, 128, 1, c3, nullptr, nullptr, st);
     if (rc != TRON_OK) return rc;
     hipLaunchKernelGGL(k_q_head, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, c3, actor2_w, actor2_b, (int)batch, 64,
                        q_out, greedy_out);

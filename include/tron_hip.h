@@ -327,8 +327,9 @@ int tron_conv3x3_dgrad(const float *grad_pre, const float *weight, const float *
  * [side] (conv6's output).  Weights are the nn.Module parameters as they are (conv7_w f32[64][64][7][7], fc1_w
  * f32[256][576], fc2_w f32[128][256], actor1_w f32[64][128], actor2_w f32[4][64]); they are split into `workspace`
  * afresh by every call.  q_out f32[batch][4] and / or greedy_out int8[batch] (first maximum, as torch.argmax).
- * side must be 12 (10x10 boards: the only size whose flatten is 64*3*3, what fc1 expects) else
- * TRON_ERR_UNSUPPORTED.  workspace: at least tron_dqn_head_workspace(batch, side) bytes, 16-byte aligned.        */
+ * side 12 (10x10 boards: flatten 64*3*3 = what the reference's fc1 expects) or 26 (24x24 boards: pooled 13x13, conv7 as
+ * an implicit GEMM over its 49 taps, flatten 64*7*7: fc1_w f32[256][3136]); other sides TRON_ERR_UNSUPPORTED.
+ * workspace: at least tron_dqn_head_workspace(batch, side) bytes, 16-byte aligned.                               */
 int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t side, const float *conv7_w,
                       const float *conv7_b, const float *fc1_w, const float *fc1_b, const float *fc2_w,
                       const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,

@@ -197,6 +197,20 @@ def test_split16_chain_equals_unchained_layers(fused, S, B):
     assert torch.equal(a, b) and s16.buf.numel() == a.numel() * 4
 
 
+def test_dqn_head_26_matches_float64_reference(fused):
+    """The 24x24 boards' head: pooled 13x13 planes, conv7 as the implicit GEMM over its 49 taps, fc1 on 64*7*7."""
+    from Net.DQNNet import Net
+    for B in (1, 3, 50, 131):
+        torch.manual_seed(B)
+        net = Net(3, 24).cuda()
+        x = torch.randn(B, 64, 26, 26, device="cuda") * 1.5
+        assert fused.head_supported(net, 26)
+        q, g = fused.head(net, x, want_greedy=True)
+        ref = _head_ref(net, x)
+        assert (q.double() - ref).abs().max().item() < TOL, (B, (q.double() - ref).abs().max().item())
+        assert torch.equal(g.long(), q.argmax(1))
+
+
 def _head_ref(net, x):
     d = lambda t: t.double()
     y = F.avg_pool2d(x.double(), 3, stride=2, padding=1)
@@ -237,13 +251,13 @@ def test_dqn_head_large_activations_and_bad_args(fused):
     ref = _head_ref(net, x)
     assert torch.isfinite(q).all() and ((q.double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
     L = nat.lib()
-    assert L.tron_dqn_head_workspace(16, 26) == 0
+    assert L.tron_dqn_head_workspace(16, 34) == 0
     ws = torch.empty(int(L.tron_dqn_head_workspace(4, 12)), dtype=torch.uint8, device="cuda")
     args = [net.conv7.weight, net.conv7.bias, net.fc1.weight, net.fc1.bias, net.fc2.weight, net.fc2.bias,
             net.actor1.weight, net.actor1.bias, net.actor2.weight, net.actor2.bias]
     ptrs = [t.data_ptr() for t in args]
     qo = torch.empty(4, 4, device="cuda")
-    assert L.tron_dqn_head_fwd(x.data_ptr(), 4, 26, *ptrs, ws.data_ptr(), qo.data_ptr(), None, None) == nat.ERR_UNSUPPORTED
+    assert L.tron_dqn_head_fwd(x.data_ptr(), 4, 34, *ptrs, ws.data_ptr(), qo.data_ptr(), None, None) == nat.ERR_UNSUPPORTED
     assert L.tron_dqn_head_fwd(x.data_ptr(), 4, 12, *ptrs, ws.data_ptr(), None, None, None) == nat.ERR_BAD_ARG
     assert L.tron_dqn_head_fwd(x.data_ptr(), 4, 12, *ptrs, None, qo.data_ptr(), None, None) == nat.ERR_BAD_ARG
     assert L.tron_dqn_head_fwd(x.data_ptr(), 0, 12, *ptrs, ws.data_ptr(), qo.data_ptr(), None, None) == 0
