@@ -235,25 +235,32 @@ __global__ void k_dense7(const float *__restrict__ src, float *__restrict__ dst,
 __global__ __launch_bounds__(256) void k_pool_split26(const float *__restrict__ x, f16 *__restrict__ oh, f16 *__restrict__ ol)
 {
     constexpr int S = 26, PS = 13, C = 64;
+    __shared__ float raw[C * 3 * S];                                     // [c][dy][x]: the three input rows of every channel
     __shared__ f16 th[PS * C], tl[PS * C];                               // [px][c]
     const int r = blockIdx.x % 19, py = r - 3;
     const int64_t b = blockIdx.x / 19;
     if (py >= 0 && py < PS) {
         const float *img = x + b * C * S * S;
+        // rows 2 py - 1 .. 2 py + 1 of all channels as 8-byte loads, consecutive lanes on consecutive pairs of a row
+        for (int i = threadIdx.x; i < C * 3 * (S / 2); i += 256) {
+            const int q = i % (S / 2), rowi = i / (S / 2), dy = rowi % 3, c = rowi / 3;
+            const int yy = 2 * py + dy - 1;
+            float2 v = make_float2(0.0f, 0.0f);
+            if (yy >= 0) v = *reinterpret_cast<const float2 *>(img + ((size_t)c * S + yy) * S + 2 * q);   // yy <= 25 always
+            raw[(c * 3 + dy) * S + 2 * q] = v.x;
+            raw[(c * 3 + dy) * S + 2 * q + 1] = v.y;
+        }
+        __syncthreads();
         for (int i = threadIdx.x; i < C * PS; i += 256) {
-            const int c = i / PS, px = i - c * PS;                       // lanes walk a row of one channel
-            const float *p = img + (size_t)c * S * S;
+            const int c = i % C, px = i / C;                             // lanes walk the channels: th / tl rows are contiguous
             float sum = 0.0f;
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int yy = 2 * py + dy;
-                if (yy < 0) continue;                                    // yy <= 25 always
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = -1; dx <= 1; ++dx) {
                     const int xx = 2 * px + dx;
-                    if (xx >= 0) sum += p[yy * S + xx];                  // xx <= 25 always
+                    if (xx >= 0) sum += raw[(c * 3 + dy) * S + xx];      // xx <= 25 always
                 }
-            }
             f16 h, l;
             split(sum * (1.0f / 9.0f) * ACT_SCALE, h, l);
             th[px * C + c] = h;
