@@ -35,7 +35,7 @@ for _ in range(10):
     q = net.infer(codes, codes=True)
 torch.cuda.synchronize()
 print(f"Net.infer: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms")
-if S == 12 and fused.head_supported(net, S):
+if fused.head_supported(net, S):
     x = fused.trunk(net, codes, codes=True)
 
     def lib_tail(x):
