@@ -258,11 +258,11 @@ int tron_bias_mish_fwd(float *y_pre, const float *bias, const float *residual, f
 int tron_bias_mish_bwd(const float *y_pre, const float *grad_out, float *grad_pre, float *bias_grad, float *scratch,
                        int64_t batch, int32_t channels, int32_t hw, void *stream);
 
-/* ---- the CNN's 3x3 convolutions on the fp32 matrix cores (Net/DQNNet.py:10-17,33-50 conv1..conv6; the same
+/* ---- the CNN's 3x3 convolutions on the matrix cores (Net/DQNNet.py:10-17,33-50 conv1..conv6; the same
  * stacks in Net/ACNet.py) ------------------------------------------------------------------------------ */
 /* out[b][co][y][x] = act(bias[co] + residual[b][co][y][x] + sum_{ci,ky,kx} W[co][ci][ky][kx] *
- * in[b][ci][y+ky-1][x+kx-1]) for a batch of side x side images, NCHW f32, exact fp32 arithmetic
- * (v_mfma_f32_16x16x4_f32): F.conv2d(padding=1) + bias + optional residual + optional mish in one launch.
+ * in[b][ci][y+ky-1][x+kx-1]) for a batch of side x side images, NCHW f32: F.conv2d(padding=1) + bias + optional
+ * residual + optional mish in one launch (arithmetic: `math`, below).
  * in_fmt TRON_CONV_IN_CODES: `in` is int8 observation codes [batch][side*side] (Map.state_for_player, map.py:67-84)
  * and the input channels are util.pop_up's planes (wall, my, enemy; util.py:11-37) built on the fly, plus the
  * constant `plane4` (Game.prob_map, game.py:124-132) when cin == 4 — conv1 straight from the env's output.
@@ -275,7 +275,7 @@ int tron_bias_mish_bwd(const float *y_pre, const float *grad_out, float *grad_pr
  * TRON_CONV_F16X3: every operand split into two f16 halves (v = hi + lo 2^-11) and three
  * v_mfma_f32_16x16x32_f16 per k-slab (hi*hi, hi*lo, lo*hi; f32 accumulation) — 5x less matrix-pipe time at an
  * error of 2^-22 per product instead of 2^-24 (still within 1e-5 on the Q-values, tests/test_gpu_conv.py).
- * Shapes the split kernel does not cover (side 26) silently use the f32 kernel.  workspace: caller-owned device
+ * Shapes the split kernel has no instantiation for (cin not a multiple of 16) silently use the f32 kernel.  workspace: caller-owned device
  * scratch of at least tron_conv3x3_workspace(cin, cout) bytes for the split weights (written afresh by every call,
  * so nothing cached can go stale); only TRON_CONV_F16X3 needs it (NULL there means: use the f32 kernel).     */
 enum { TRON_CONV_F32 = 0, TRON_CONV_F16X3 = 1, TRON_CONV_F16X3_PRESPLIT = 3 };
@@ -341,8 +341,8 @@ int64_t tron_dqn_head_workspace(int64_t batch, int32_t side);
  * matrix f32[cout*9][cin*36] that maps a flattened 6x6 input to the flattened 3x3 output of the 7x7 / stride 2 / pad 3
  * convolution (DQNNet.py:22,53); fold 1: that matrix's gradient -> the weight's gradient.                          */
 int tron_pool12(const float *x, float *y, int64_t planes, int32_t backward, void *stream);
-/* The forward pooling for the other supported board size as well: side 12 or 26 (24x24 boards, whose tail is this plus
- * library kernels) -> side/2; other sides TRON_ERR_UNSUPPORTED.                                                    */
+/* The forward pooling alone at both supported board sizes, side 12 or 26 -> side/2 (for a caller that keeps conv7 on a
+ * library: Net.infer in exact-f32 mode); other sides TRON_ERR_UNSUPPORTED.                                           */
 int tron_pool_s2(const float *x, float *y, int64_t planes, int32_t side, void *stream);
 int tron_conv7_dense(const float *src, float *dst, int32_t cout, int32_t cin, int32_t fold, void *stream);
 
