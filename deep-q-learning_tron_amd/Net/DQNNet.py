@@ -96,6 +96,8 @@ class Net(nn.Module):
         return self.actor2(self.activation(self.actor1(x)))
 
     def act(self, x, env_prob=None):              # DQNNet.py:64-66 (env_prob accepted for Game.main_loop)
+        if not self.training and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
+            return self.infer(x, greedy=True).long()      # eval mode: the gradient-free kernels, arg-max taken in the head
         return torch.argmax(self(x), dim=1)
 
     def infer(self, x, codes=False, plane4=0.0, greedy=False):

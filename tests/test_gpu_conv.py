@@ -397,3 +397,16 @@ def test_pool_s2_matches_avg_pool2d(fused, S, B):
     y = fused.pool_s2(x)
     ref = F.avg_pool2d(x.double(), 3, stride=2, padding=1)
     assert y.shape == ref.shape and (y.double() - ref).abs().max().item() < 1e-6
+
+
+def test_net_act_in_eval_mode_uses_infer_and_agrees_with_the_module(fused):
+    from Net.DQNNet import Net
+    torch.manual_seed(21)
+    net = Net(3, 10).cuda().eval()
+    x = torch.randn(300, 3, 12, 12, device="cuda")
+    with torch.no_grad():
+        q = net(x)
+    a = net.act(x)
+    top = q.topk(2, dim=1).values
+    clear = (top[:, 0] - top[:, 1]) > 1e-4                   # (the two paths agree to ~1e-6: near-ties may break either way)
+    assert a.dtype == torch.int64 and clear.sum() > 250 and torch.equal(a[clear], q.argmax(1)[clear])
