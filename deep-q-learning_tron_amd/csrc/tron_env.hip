@@ -1624,7 +1624,10 @@ int rollout_persistent(tron_env *h, int32_t k_steps, uint32_t flags, StepOut out
     allow_big_lds(reinterpret_cast<const void *>(k_obs_roll), h->device, prepared);
     if (!h->roll_E) h->roll_E = roll_tile_envs(h);
     // the resident variant is store-bound and measured best on the per-step tile (3.51 vs 3.21 G env-steps/s at 26)
-    const int E = env_e > 0 ? env_e : (flags & TRON_ROLLOUT_RESIDENT) ? h->E : h->roll_E;
+    // ... and so is a call that fits ONE launch (k_steps <= chunk): measured at 65 536 x 24x24, a single 20- / 64-step launch
+    // runs 2.71-2.74 / 2.92 G env-steps/s on 32-env tiles against 2.64-2.65 / 2.84 on 26-env ones, while five 64-step
+    // launches back to back run 3.00 against 3.05 — the full last round pays off when the next launch follows at once
+    const int E = env_e > 0 ? env_e : ((flags & TRON_ROLLOUT_RESIDENT) || k_steps <= chunk) ? h->E : h->roll_E;
     const size_t smem = ((size_t)E + 1u) * h->cpe * 16u + 4u * (size_t)E * 16u;
     if (smem > 160u * 1024u) return TRON_ERR_BAD_ARG;
     const int ntiles = (h->P.N + E - 1) / E;
