@@ -122,6 +122,8 @@ def trunk(net, x, codes=False, plane4=0.0, math=None):
     """conv1..conv6 with their two residual links (DQNNet.py:34-50): [B, 64, S, S].  With the split-f16 arithmetic the
     layers hand their outputs on as Split16 images (no re-splitting in the consumer); f32 tensors are written only where
     somebody reads them: conv1's and conv4's outputs (the residuals of conv3 and conv6) and conv6's."""
+    if MATH[math or default_math] == nat.CONV_F16X3 and codes and ws_supported(net, x.shape[-1]):
+        return trunk_px(net, x, plane4)
     if MATH[math or default_math] != nat.CONV_F16X3:
         x = conv3x3(x, net.conv1, codes=codes, plane4=plane4, math=math)
         idx = x
@@ -138,6 +140,111 @@ def trunk(net, x, codes=False, plane4=0.0, math=None):
     idx, s = conv3x3(s, net.conv4, math=math, want_split=True, presplit=w[3])
     _, s = conv3x3(s, net.conv5, math=math, want_f32=False, want_split=True, presplit=w[4])
     return conv3x3(s, net.conv6, residual=idx, math=math, presplit=w[5])
+
+
+# ---- the weight-stationary chain (csrc/tron_conv_ws.hip): activations as PX16 images between the layers ---------------
+use_ws = _os.environ.get("TRON_CONV_WS", "1") != "0"
+_WS_SHAPES = ((32, 32), (32, 64), (64, 64))
+
+
+class PX16:
+    """An activation tensor [batch, channels, side, side] as the pixel-major split-f16 image of include/tron_hip.h:
+    per image [hi | lo][channel octet][pixel][8 channels] f16, value / 64 = hi + lo 2^-11."""
+
+    def __init__(self, batch, channels, side, device):
+        self.shape = (batch, channels, side, side)
+        self.buf = torch.empty(batch * channels * side * side * 4, dtype=torch.uint8, device=device)
+
+    def float(self):
+        """The f32 NCHW tensor (tron_px16_to_f32)."""
+        B, C, S, _ = self.shape
+        out = torch.empty(self.shape, dtype=torch.float32, device=self.buf.device)
+        with torch.cuda.device(self.buf.device):
+            nat.check(nat.lib().tron_px16_to_f32(nat.ptr(self.buf), nat.ptr(out), B, C, S, nat.stream_ptr()), "tron_px16_to_f32")
+        return out
+
+
+def ws_supported(net, side):
+    """The weight-stationary chain covers the DQN trunk's shapes (DQNNet.py:10-15) on 12x12 and 26x26 observations."""
+    convs = [getattr(net, f"conv{i}", None) for i in range(1, 7)]
+    return (use_ws and side in (12, 26) and all(isinstance(c, torch.nn.Conv2d) for c in convs)
+            and convs[0].in_channels in (3, 4) and convs[0].out_channels == 32
+            and all(c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1)
+                    and c.groups == 1 and c.bias is not None and c.weight.is_cuda and c.weight.dtype == torch.float32
+                    and c.weight.is_contiguous() for c in convs)
+            and all((c.in_channels, c.out_channels) in _WS_SHAPES for c in convs[1:]))
+
+
+def ws_split_weights(convs):
+    """The MFMA fragment images of several layers' weights in ONE launch (tron_conv3x3_ws_split_weights): a list of uint8
+    workspace views to hand to conv_ws(..., wfrag=).  Built afresh by every forward pass — nothing is cached."""
+    import ctypes as C
+    L = nat.lib()
+    n = len(convs)
+    dev = convs[0].weight.device
+    sizes = [(int(L.tron_conv3x3_ws_workspace(c.in_channels, c.out_channels)) + 255) // 256 * 256 for c in convs]
+    buf = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+    views, off = [], 0
+    for sz in sizes:
+        views.append(buf[off:off + sz])
+        off += sz
+    ws = [c.weight.detach() if c.weight.is_contiguous() else c.weight.detach().contiguous() for c in convs]
+    wp = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
+    vp = (C.c_void_p * n)(*[v.data_ptr() for v in views])
+    ci = (C.c_int32 * n)(*[c.in_channels for c in convs])
+    co = (C.c_int32 * n)(*[c.out_channels for c in convs])
+    with torch.cuda.device(dev):
+        nat.check(L.tron_conv3x3_ws_split_weights(wp, ci, co, vp, n, nat.stream_ptr()), "tron_conv3x3_ws_split_weights")
+    return views
+
+
+def conv1_px16(codes, conv, plane4=0.0):
+    """mish(conv1(pop_up(codes)) + bias) from the env's int8 observation codes [B, S, S] -> PX16 with 32 channels."""
+    if codes.dtype != torch.int8 or codes.dim() != 3 or codes.shape[-1] != codes.shape[-2]:
+        raise TypeError("conv1_px16 takes int8 observation codes [B, S, S]")
+    c = codes.contiguous()
+    B, S = c.shape[0], c.shape[-1]
+    out = PX16(B, conv.out_channels, S, c.device)
+    w = conv.weight.detach()
+    with torch.cuda.device(c.device):
+        nat.check(nat.lib().tron_conv1_px16(nat.ptr(c), nat.ptr(w if w.is_contiguous() else w.contiguous()),
+                                            nat.ptr(conv.bias.detach()), conv.in_channels, float(plane4), B, S,
+                                            nat.ptr(out.buf), nat.stream_ptr()), "tron_conv1_px16")
+    return out
+
+
+def conv_ws(x, conv, wfrag, residual=None, act=True, want_px=True, want_f32=False, want_pre=False):
+    """act(conv3x3(x) + bias + residual) on PX16 images (tron_conv3x3_ws_fwd).  Returns the PX16 output and / or the f32
+    NCHW output / pre-activation, in that order, for what was asked."""
+    B, cin, S, _ = x.shape
+    cout = conv.out_channels
+    if cin != conv.in_channels or (residual is not None and residual.shape != (B, cout, S, S)):
+        raise TypeError("conv_ws: channel / shape mismatch")
+    dev = x.buf.device
+    out = PX16(B, cout, S, dev) if want_px else None
+    o32 = torch.empty(B, cout, S, S, dtype=torch.float32, device=dev) if want_f32 else None
+    pre = torch.empty(B, cout, S, S, dtype=torch.float32, device=dev) if want_pre else None
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().tron_conv3x3_ws_fwd(nat.ptr(x.buf), nat.ptr(wfrag), nat.ptr(conv.bias.detach()),
+                                                nat.ptr(None if residual is None else residual.buf),
+                                                nat.ptr(None if out is None else out.buf), nat.ptr(o32), nat.ptr(pre),
+                                                B, cin, cout, S, int(act), nat.stream_ptr()), "tron_conv3x3_ws_fwd")
+    ret = [t for t, want in ((out, want_px), (o32, want_f32), (pre, want_pre)) if want]
+    return ret[0] if len(ret) == 1 else tuple(ret)
+
+
+def trunk_px(net, codes, plane4=0.0, want="f32"):
+    """conv1..conv6 with their two residual links (DQNNet.py:34-50) from the env's int8 codes [B, S, S], the
+    activations staying PX16 images from conv1's output to conv6's.  want: "f32" -> [B, 64, S, S], "px16" -> PX16."""
+    w = ws_split_weights([net.conv2, net.conv3, net.conv4, net.conv5, net.conv6])          # one launch for all five
+    a = conv1_px16(codes, net.conv1, plane4)
+    b = conv_ws(a, net.conv2, w[0])
+    c = conv_ws(b, net.conv3, w[1], residual=a)
+    d = conv_ws(c, net.conv4, w[2])
+    e = conv_ws(d, net.conv5, w[3])
+    if want == "px16":
+        return conv_ws(e, net.conv6, w[4], residual=d)
+    return conv_ws(e, net.conv6, w[4], residual=d, want_px=False, want_f32=True)
 
 
 def conv3x3_dgrad(gp, weight, absmax=None):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TRON_ABI_VERSION 4
+#define TRON_ABI_VERSION 5
 
 typedef enum {
     TRON_OK = 0,
@@ -296,6 +296,35 @@ int64_t tron_conv3x3_workspace(int32_t cin, int32_t cout);
  * The arrays are host arrays.  Still nothing cached: the caller splits again whenever it forwards again.            */
 int tron_conv3x3_split_weights(const float *const *weights, const int32_t *cins, const int32_t *couts,
                                void *const *workspaces, int32_t n, void *stream);
+
+/* ---- the same convolutions, weight-stationary, for gradient-free forwards (csrc/tron_conv_ws.hip) ----------------
+ * The policy forward over 2N observations per env step (DDQN.py:90-110) and the two target forwards of a learn step
+ * (DDQN.py:129-142) run conv1..conv6 (DQNNet.py:33-50) as a chain whose activations never take the f32 NCHW form:
+ * PX16 = per image [hi | lo][channel octet][pixel][8 channels] f16, the value scaled by 2^-6 and split as
+ * TRON_CONV_F16X3 splits it (v / 64 = hi + lo 2^-11): tron_px16_bytes(batch, channels, side) bytes (4 per element).
+ * tron_conv1_px16: conv1 + bias + mish from the env's int8 observation codes [batch][side*side] (the planes of
+ *   util.pop_up, util.py:11-37, and the constant fourth plane `plane4` when cin == 4, game.py:124-132, are implied by
+ *   the codes: a table sum over the nine taps) -> PX16 with 32 channels.  weight f32[32][cin][3][3], cin 3 or 4;
+ *   side 12, 26 or 34.
+ * tron_conv3x3_ws_fwd: out = act(conv3x3(in, padding 1) + bias + residual): in / residual / out PX16 (residual
+ *   and bias may be NULL, residual has cout channels); out_f32 / pre_f32 (may be NULL) also receive the result / the
+ *   pre-activation as f32[batch][cout][side][side]; out_px16 may be NULL when one of them is given.  wfrag: the layer's
+ *   weights as MFMA fragments, written by tron_conv3x3_ws_split_weights (weights[k] f32[couts[k]][cins[k]][3][3] ->
+ *   workspaces[k], >= tron_conv3x3_ws_workspace(cin, cout) bytes; host arrays, n <= 8 layers, one launch; nothing is
+ *   cached: a forward pass splits again).  Same arithmetic and accuracy as TRON_CONV_F16X3.
+ *   Supported: side 12 or 26, (cin, cout) in {(32,32), (32,64), (64,64)}; anything else TRON_ERR_UNSUPPORTED.
+ * tron_px16_to_f32: a PX16 image -> f32[batch][channels][side][side].
+ * All buffers 16-byte aligned.                                                                                       */
+int64_t tron_px16_bytes(int64_t batch, int32_t channels, int32_t side);
+int tron_conv1_px16(const int8_t *codes, const float *weight, const float *bias, int32_t cin, float plane4,
+                    int64_t batch, int32_t side, void *out_px16, void *stream);
+int64_t tron_conv3x3_ws_workspace(int32_t cin, int32_t cout);
+int tron_conv3x3_ws_split_weights(const float *const *weights, const int32_t *cins, const int32_t *couts,
+                                  void *const *workspaces, int32_t n, void *stream);
+int tron_conv3x3_ws_fwd(const void *in_px16, const void *wfrag, const float *bias, const void *res_px16,
+                        void *out_px16, float *out_f32, float *pre_f32, int64_t batch, int32_t cin, int32_t cout,
+                        int32_t side, int32_t apply_mish, void *stream);
+int tron_px16_to_f32(const void *in_px16, float *out, int64_t batch, int32_t channels, int32_t side, void *stream);
 
 /* The weight gradient of the same convolutions (loss.backward() through conv1..conv6, DDQN.py:148):
  * grad_weight[co][ci][ky][kx] = sum over b, y, x of grad_pre[b][co][y][x] * in[b][ci][y+ky-1][x+kx-1], overwritten (not

@@ -1,0 +1,136 @@
+"""csrc/tron_conv_ws.hip — the weight-stationary 3x3 convolutions on PX16 images (gradient-free forwards: the policy
+and the DDQN target forwards, DDQN.py:90-110,129-142) — against a float64 torch reference of the same op
+(DQNNet.py:33-50), tolerance 1e-5 (the north star's bound for Q-values)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+F = torch.nn.functional
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def fused():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import config  # noqa: F401
+    from Net import fused
+    return fused
+
+
+def _codes(B, S, seed):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    vals = torch.tensor([1, -1, -2, -3, 10, -10], dtype=torch.int8, device="cuda")
+    return vals[torch.randint(0, 6, (B, S, S), device="cuda", generator=gen)]
+
+
+def _to_px16(fused, x):
+    """f32 [B, C, S, S] -> PX16 by the definition in include/tron_hip.h (host-side restatement for the tests)."""
+    B, C, S, _ = x.shape
+    s = (x.double() / 64.0)
+    hi = s.to(torch.float16)
+    lo = ((s - hi.double()) * 2048.0).to(torch.float16)
+    img = torch.stack([hi, lo], 1)                                       # [B, 2, C, S, S]
+    img = img.reshape(B, 2, C // 8, 8, S * S).permute(0, 1, 2, 4, 3).contiguous()   # [B, half, octet, pixel, 8]
+    px = fused.PX16(B, C, S, x.device)
+    px.buf.copy_(img.view(torch.uint8).reshape(-1))
+    return px
+
+
+@pytest.mark.parametrize("S,B,cin", [(12, 1, 3), (12, 777, 4), (26, 2, 3), (26, 130, 4), (34, 5, 3)])
+def test_conv1_px16_matches_float64(fused, S, B, cin):
+    """conv1 as a table sum over the codes (util.py:11-37 planes implied) == float64 conv of the pop_up planes."""
+    from tron.vec import pop_up_planes
+    torch.manual_seed(S + B + cin)
+    conv = torch.nn.Conv2d(cin, 32, 3, padding=1).cuda()
+    codes = _codes(B, S, S * B)
+    planes = pop_up_planes(codes)
+    if cin == 4:
+        planes = torch.cat([planes, torch.full((B, 1, S, S), 5.0, device="cuda")], 1)
+    ref = F.mish(F.conv2d(planes.double(), conv.weight.double(), conv.bias.double(), padding=1))
+    got = fused.conv1_px16(codes, conv, 5.0).float()
+    assert (got.double() - ref).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("S,B", [(12, 1), (12, 2), (12, 7), (12, 260), (12, 1555), (26, 1), (26, 3), (26, 130), (26, 301)])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64)])
+def test_conv_ws_matches_float64_reference(fused, S, B, cin, cout):
+    """Every instantiation, ragged batches (items of two images, more items than workgroups), with / without the
+    residual and the activation; PX16 output, f32 output and pre-activation all from one launch."""
+    torch.manual_seed(S * 1000 + B + cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
+    x = torch.randn(B, cin, S, S, device="cuda")
+    res = torch.randn(B, cout, S, S, device="cuda")
+    xp, rp = _to_px16(fused, x), _to_px16(fused, res)
+    assert (xp.float() - x).abs().max().item() < 1e-6                   # the format round-trips (2^-22 relative)
+    w = fused.ws_split_weights([conv])[0]
+    for r, rpx, act in ((res, rp, True), (None, None, True), (res, rp, False)):
+        out, o32, pre = fused.conv_ws(xp, conv, w, residual=rpx, act=act, want_f32=True, want_pre=True)
+        y = F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        if r is not None:
+            y = y + r.double()
+        ref = F.mish(y) if act else y
+        assert (pre.double() - y).abs().max().item() < TOL
+        assert (o32.double() - ref).abs().max().item() < TOL
+        assert (out.float().double() - ref).abs().max().item() < TOL
+    # asymmetric weights / one-hot inputs: a transposed tap or a swapped row/column cannot hide
+    with torch.no_grad():
+        conv.weight.copy_(torch.arange(conv.weight.numel(), device="cuda").reshape(conv.weight.shape).float() % 17 - 8)
+        conv.bias.zero_()
+    x = torch.zeros(B, cin, S, S, device="cuda")
+    x[:, 1, 2, 3] = 1.0
+    x[:, cin - 1, S - 1, 0] = 2.0
+    x[:, 9, 0, S - 1] = -1.0
+    w = fused.ws_split_weights([conv])[0]
+    got = fused.conv_ws(_to_px16(fused, x), conv, w, act=False, want_px=False, want_f32=True)
+    assert torch.equal(got, F.conv2d(x, conv.weight, None, padding=1))   # small integers: exact
+
+
+@pytest.mark.parametrize("W,B,cin", [(10, 513, 3), (10, 64, 4), (24, 37, 3), (24, 200, 4)])
+def test_trunk_px_matches_float64_module(fused, W, B, cin):
+    """The whole chain conv1..conv6 from the codes against the float64 module's trunk."""
+    from Net.DQNNet import Net
+    from tron.vec import pop_up_planes
+    torch.manual_seed(W + B)
+    S = W + 2
+    net = Net(cin, W).cuda()
+    assert fused.ws_supported(net, S)
+    codes = _codes(B, S, W * B)
+    planes = pop_up_planes(codes)
+    if cin == 4:
+        planes = torch.cat([planes, torch.full((B, 1, S, S), 5.0, device="cuda")], 1)
+    n64 = net.double()
+    with torch.no_grad():
+        x = F.mish(n64.conv1(planes.double()))
+        idx = x
+        x = F.mish(n64.conv2(x))
+        x = F.mish(n64.conv3(x) + idx)
+        x = F.mish(n64.conv4(x))
+        idx = x
+        x = F.mish(n64.conv5(x))
+        ref = F.mish(n64.conv6(x) + idx)
+    net.float()
+    got = fused.trunk_px(net, codes, 5.0)
+    assert (got.double() - ref).abs().max().item() < TOL
+    assert (fused.trunk_px(net, codes, 5.0, want="px16").float() - got).abs().max().item() < 1e-6   # PX16 holds 2^-22 relative
+    assert torch.equal(fused.trunk(net, codes, codes=True, plane4=5.0), got)         # the default gradient-free trunk
+
+
+def test_conv_ws_bad_args(fused):
+    from tron import _native as nat
+    L = nat.lib()
+    assert L.tron_conv3x3_ws_workspace(48, 32) == 0 and L.tron_conv3x3_ws_workspace(64, 64) == 4 * 18 * 2 * 1024
+    assert L.tron_px16_bytes(3, 64, 12) == 3 * 64 * 144 * 4
+    conv = torch.nn.Conv2d(64, 32, 3, padding=1).cuda()
+    x = fused.PX16(2, 64, 12, torch.device("cuda"))
+    w = fused.ws_split_weights([conv])[0]
+    with pytest.raises(nat.TronNativeError):                             # 64 -> 32 has no instantiation
+        fused.conv_ws(x, conv, w)
+    with pytest.raises(TypeError):
+        fused.conv_ws(fused.PX16(2, 32, 12, torch.device("cuda")), conv, w)
+    a = (x.buf.data_ptr(), w.data_ptr(), None, None)
+    assert L.tron_conv3x3_ws_fwd(*a, None, None, None, 2, 64, 64, 12, 1, None) == nat.ERR_BAD_ARG      # no output
+    assert L.tron_conv3x3_ws_fwd(*a, x.buf.data_ptr(), None, None, 0, 64, 64, 12, 1, None) == 0        # empty batch
+    assert L.tron_conv3x3_ws_fwd(*a, x.buf.data_ptr(), None, None, 2, 64, 64, 14, 1, None) == nat.ERR_UNSUPPORTED
