@@ -53,12 +53,14 @@ rows = [("conv1 codes->px16", lambda: fused.conv1_px16(codes, net.conv1), 3, 32)
         ("conv6 64->64 +res", raw(e, net.conv6, w[4], d, e.__class__(B, 64, S, e.buf.device)), 64, 64),
         ("conv6 64->64 +res -> f32", raw(e, net.conv6, w[4], d, None, o32), 64, 64),
         ("split weights (5 layers)", lambda: fused.ws_split_weights([net.conv2, net.conv3, net.conv4, net.conv5, net.conv6]), 0, 0)]
-tot = 0.0
+only = sys.argv[3] if len(sys.argv) > 3 else None
+if only:
+    rows = [r for r in rows if r[0].startswith(only)]
 for name, fn, ci, co in rows:
     t = timeit(fn)
     fl = 2.0 * B * S * S * 9 * ci * co
     print(f"{name:28s} {t:8.1f} us  {fl / t / 1e6:7.1f} TF/s f32-eq", flush=True)
-for math in ("f16x3",):
+for math in (() if only else ("f16x3",)):
     for ws in (True, False):
         fused.use_ws = ws
         t = timeit(lambda: fused.trunk(net, codes, codes=True, math=math), 10)
