@@ -100,13 +100,26 @@ class Net(nn.Module):
             return self.infer(x, greedy=True).long()      # eval mode: the gradient-free kernels, arg-max taken in the head
         return torch.argmax(self(x), dim=1)
 
+    def infer_path(self, x, codes=False):
+        """Which implementation `infer` runs for this input: "ws-chain" (csrc/tron_conv_ws.hip + tron_head.hip), "layer-kernels"
+        (csrc/tron_conv_f16.hip / tron_conv.hip, head on tron_head.hip or the libraries) or "module" (PyTorch-ROCm)."""
+        from Net import fused
+        side = x.shape[-1]
+        if not (x.is_cuda and fused.supported(self.conv1, side) and fused.supported(self.conv6, side)
+                and (codes or x.dtype == torch.float32)):
+            return "module"
+        if codes and fused.default_math == "f16x3" and fused.ws_supported(self, side) and fused.head_supported(self, side):
+            return "ws-chain"
+        return "layer-kernels"
+
     def infer(self, x, codes=False, plane4=0.0, greedy=False):
         """Q-values without autograd and without dropout (what `eval()` + `no_grad()` give, DDQN.py:90-110,129-142)
-        on the hand-written HIP path: the six 3x3 convolutions are csrc/tron_conv.hip launches (fp32 matrix cores,
-        bias + residual + mish fused, conv1 straight from the env's int8 observation codes when codes=True);
-        at 12x12 pooling, conv7 and the four linear layers are one csrc/tron_head.hip call (24x24 boards keep them on
-        the libraries).  Falls back to the module's own forward for shapes the kernels do not cover (odd sides, CPU
-        tensors).  greedy=True returns the arg-max action per row as int8 instead (`Net.act`, DQNNet.py:64-66), taken
+        on the hand-written HIP path.  From the env's int8 observation codes (codes=True) at 12x12 and 26x26: the
+        weight-stationary chain of csrc/tron_conv_ws.hip (conv1 as a table sum over the codes, conv2..conv6 on the split-f16
+        matrix cores with the weights in registers and the activations as PX16 images) into csrc/tron_head.hip (pooling,
+        conv7, the four linear layers, arg-max).  From f32 planes: csrc/tron_conv_f16.hip / tron_conv.hip layer by layer, then
+        the same head.  Falls back to the module's own forward for shapes the kernels do not cover (other sides, CPU
+        tensors) — `infer_path(x, codes)` says which of the three a call takes.  greedy=True returns the arg-max action per row as int8 instead (`Net.act`, DQNNet.py:64-66), taken
         inside the head kernel where that runs."""
         from Net import fused
         side = x.shape[-1]
@@ -124,6 +137,10 @@ class Net(nn.Module):
                     return self(x).argmax(1).to(torch.int8) if greedy else self(x)
                 finally:
                     self.train(was_training)
+            if codes and fused.default_math == "f16x3" and fused.ws_supported(self, side) and fused.head_supported(self, side):
+                # the weight-stationary chain: PX16 images from conv1's output to the head's pooling, no f32 activation tensor
+                x = fused.trunk_px(self, x.reshape(-1, side, side), plane4, want="px16")
+                return fused.head(self, x, want_q=False, want_greedy=True)[1] if greedy else fused.head(self, x)
             x = fused.trunk(self, x.reshape(-1, side, side) if codes else x, codes=codes, plane4=plane4)
             if fused.default_math == "f16x3" and fused.head_supported(self, side):
                 return fused.head(self, x, want_q=False, want_greedy=True)[1] if greedy else fused.head(self, x)

@@ -297,23 +297,30 @@ def head_supported(net, side):
 
 
 def head(net, x, want_q=True, want_greedy=False):
-    """pool -> conv7 -> flatten -> fc1 -> fc2 -> actor1 -> actor2 (DQNNet.py:52-63, eval mode) on the trunk's f32 output
-    [B, 64, 12, 12] or [B, 64, 26, 26] in one library call (csrc/tron_head.hip).  Returns Q [B, 4] and / or the greedy action int8 [B]."""
+    """pool -> conv7 -> flatten -> fc1 -> fc2 -> actor1 -> actor2 (DQNNet.py:52-63, eval mode) on the trunk's output — f32
+    [B, 64, 12, 12] or [B, 64, 26, 26], or the PX16 image the weight-stationary chain ends in — in one library call
+    (csrc/tron_head.hip).  Returns Q [B, 4] and / or the greedy action int8 [B]."""
     L = nat.lib()
+    px = isinstance(x, PX16)                      # conv6's output as the PX16 image: the pooling reads it as it is
     B, side = x.shape[0], x.shape[-1]
-    assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape[1:]) == (64, side, side), x.shape
-    q = torch.empty(B, 4, dtype=torch.float32, device=x.device) if want_q else None
-    g = torch.empty(B, dtype=torch.int8, device=x.device) if want_greedy else None
+    if px:
+        assert tuple(x.shape[1:]) == (64, side, side), x.shape
+        dev, fn, xp = x.buf.device, L.tron_dqn_head_fwd_px16, x.buf.data_ptr()
+    else:
+        assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape[1:]) == (64, side, side), x.shape
+        dev, fn, xp = x.device, L.tron_dqn_head_fwd, x.data_ptr()
+    q = torch.empty(B, 4, dtype=torch.float32, device=dev) if want_q else None
+    g = torch.empty(B, dtype=torch.int8, device=dev) if want_greedy else None
     if B == 0:
         return (q, g) if want_greedy else q
-    ws = torch.empty(int(L.tron_dqn_head_workspace(B, side)), dtype=torch.uint8, device=x.device)
+    ws = torch.empty(int(L.tron_dqn_head_workspace(B, side)), dtype=torch.uint8, device=dev)
     ptr = lambda t: None if t is None else t.data_ptr()
-    with torch.cuda.device(x.device):
-        nat.check(L.tron_dqn_head_fwd(x.data_ptr(), B, side, net.conv7.weight.data_ptr(), net.conv7.bias.data_ptr(),
+    with torch.cuda.device(dev):
+        nat.check(fn(xp, B, side, net.conv7.weight.data_ptr(), net.conv7.bias.data_ptr(),
                                       net.fc1.weight.data_ptr(), net.fc1.bias.data_ptr(), net.fc2.weight.data_ptr(),
                                       net.fc2.bias.data_ptr(), net.actor1.weight.data_ptr(), net.actor1.bias.data_ptr(),
                                       net.actor2.weight.data_ptr(), net.actor2.bias.data_ptr(), ws.data_ptr(), ptr(q),
-                                      ptr(g), torch.cuda.current_stream(x.device).cuda_stream), "tron_dqn_head_fwd")
+                                      ptr(g), torch.cuda.current_stream(dev).cuda_stream), "tron_dqn_head_fwd")
     return (q, g) if want_greedy else q
 
 

@@ -270,8 +270,9 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
             int img, pixg;
             const bool ok = locate(pt[k], li, p_ip, img, pixg);
             const uint32_t poff = (uint32_t)((2 * ct + (g >> 1)) * G::PLANEG + pixg * 16 + (g & 1) * 8);
-            pp[k] = ok ? out + (size_t)img * 2 * G::HALFG_OUT + poff : g_ws_dump + lane * 16;
-            if (!out || TRON_WS_ABLATE == 7) pp[k] = g_ws_dump + lane * 16;
+            unsigned char *po = out + (size_t)img * 2 * G::HALFG_OUT + poff;      // (img, pixg are 0 when !ok: a valid address either way)
+            pp[k] = (ok && out && TRON_WS_ABLATE != 7) ? po : g_ws_dump + lane * 16;
+            asm volatile("" : "+v"(pp[k]));
             if (F32OUT) pfo[k] = ok ? ((int64_t)img * G::COUT + co0) * G::SS + pixg : -1;
             if (RES) {
                 // this lane's 8 + 8 residual bytes from the wave's staged piece: [hi | lo][octet of the pair][pixel][16 B]
@@ -290,22 +291,26 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
                 const uint32_t b = __float_as_uint(__builtin_amdgcn_exp2f(t[i]));
                 pe[k][i] = __uint_as_float(b < 0x5D5E0B6Bu ? b : 0x5D5E0B6Bu);      // min(e^x, 1e18): see tron_conv_f16.hip
             }
+            asm volatile("" : "+v"(pe[k]));                              // (opaque: the stage stays on its slab instead of sinking to its use)
         } else if (stage == 2) {
             const f32x4 e = pe[k];
             const f32x4 n = __builtin_elementwise_fma(e, e, e + e);
             const f32x4 d = n + 2.0f;
             const f32x4 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
             pe[k] = n * r;
+            asm volatile("" : "+v"(pe[k]));
         } else if (stage == 3) {
-            if (apply_mish) pv[k] = pv[k] * pe[k];
+            if (!F32OUT || apply_mish) pv[k] = pv[k] * pe[k];           // (the fast variant is only launched with the activation on)
             if (F32OUT && out_f32 && pfo[k] >= 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) out_f32[pfo[k] + r * G::SS] = pv[k][r];
             }
             pv[k] = pv[k] * ACT_SCALE;
+            asm volatile("" : "+v"(pv[k]));
         } else if (stage == 4) {
             phh[k] = __builtin_convertvector(pv[k], f16x4);
             pv[k] = (pv[k] - __builtin_convertvector(phh[k], f32x4)) * LO_SCALE;
+            asm volatile("" : "+v"(pv[k]), "+v"(phh[k]));
         } else {
             const f16x4 ll = __builtin_convertvector(pv[k], f16x4);
             if (TRON_WS_ABLATE == 4) { asm volatile("" ::"v"(ll), "v"(phh[k]), "v"(pp[k])); return; }
@@ -390,17 +395,23 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
             f32x4 ah[TPS], ax[TPS], ay[TPS];
 #pragma unroll
             for (int k = 0; k < TPS; ++k) ah[k] = ax[k] = ay[k] = z;
-            // B fragments one slab ahead, tile by tile: tile k's fragments of slab s + 1 are requested right after its
-            // MFMAs of slab s were issued (lgkmcnt counts to 15: with more than that in flight the compiler waits for ALL)
-            f16x8 rbh[2][TPS], rbl[2][TPS];
+            // B fragments AHEAD slabs ahead, tile by tile: tile k's fragments of slab s + AHEAD are requested right after
+            // its MFMAs of slab s were issued.  lgkmcnt counts to 15 (with more in flight the compiler waits for ALL), so
+            // 2 TPS AHEAD reads stay below that: three slabs ahead with one tile per step (a slab is then only three
+            // MFMAs, 48 cycles — less than an LDS round trip), one slab ahead with three tiles.
+            constexpr int AHEAD = 1, RING = AHEAD + 1;                  // (three slabs ahead measured no faster: the LDS latency is not what the loop waits for)
+            static_assert(2 * TPS * AHEAD + 2 * TPS <= 15, "LDS reads in flight");
+            f16x8 rbh[RING][TPS], rbl[RING][TPS];
             auto fetch = [&](int s, int k) {
                 const int tap = s / NCB, cb = s % NCB, ky = tap / 3, kx = tap % 3;
                 const int imm = ky * G::ROWB + cb * G::CBLK;
-                rbh[s % 2][k] = *reinterpret_cast<const f16x8 *>(lds + b[k][kx] + imm);
-                rbl[s % 2][k] = *reinterpret_cast<const f16x8 *>(lds + b[k][kx] + imm + G::HALF);
+                rbh[s % RING][k] = *reinterpret_cast<const f16x8 *>(lds + b[k][kx] + imm);
+                rbl[s % RING][k] = *reinterpret_cast<const f16x8 *>(lds + b[k][kx] + imm + G::HALF);
             };
 #pragma unroll
-            for (int k = 0; k < TPS; ++k) fetch(0, k);
+            for (int s = 0; s < AHEAD; ++s)
+#pragma unroll
+                for (int k = 0; k < TPS; ++k) fetch(s, k);
             // which of the next item's pieces this step carries: piece j0 + s / DSTRIDE at slab s (wave-uniform: one
             // branch per step, none per slab — a branch around a DMA makes the compiler drain lgkmcnt at the join)
             const int j0 = (dma_in_loop && nxt < nitems && st < nsteps - 1) ? st * NS : G::DMA_PER_WAVE;
@@ -409,13 +420,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
                 for (int s = 0; s < NS; ++s) {
 #pragma unroll
                     for (int k = 0; k < TPS; ++k) {
-                        if (s + 1 < NS && TRON_WS_ABLATE != 2) fetch(s + 1, k);
+                        if (s + AHEAD < NS && TRON_WS_ABLATE != 2) fetch(s + AHEAD, k);
                         if (TRON_WS_ABLATE != 5) {
-                            ax[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], rbl[s % 2][k], ax[k], 0, 0, 0);
-                            ah[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], rbh[s % 2][k], ah[k], 0, 0, 0);
-                            ay[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], rbh[s % 2][k], ay[k], 0, 0, 0);
+                            ax[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], rbl[s % RING][k], ax[k], 0, 0, 0);
+                            ah[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], rbh[s % RING][k], ah[k], 0, 0, 0);
+                            ay[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], rbh[s % RING][k], ay[k], 0, 0, 0);
                         } else {
-                            asm volatile("" ::"v"(rbl[s % 2][k]), "v"(rbh[s % 2][k]));
+                            asm volatile("" ::"v"(rbl[s % RING][k]), "v"(rbh[s % RING][k]));
                         }
                     }
                     epi_at_slab(s);                                      // a stage of one pending tile's epilogue
@@ -473,56 +484,59 @@ __global__ __launch_bounds__(256) void k_conv1_px(const int8_t *__restrict__ cod
                                                   const float *__restrict__ bias, int cin, float plane4, int64_t B,
                                                   unsigned char *__restrict__ out)
 {
-    constexpr int SS = S * S, COUT = 32, ROW = 9 * COUT + 4;            // table row of one code (floats), padded against bank conflicts
-    __shared__ __attribute__((aligned(16))) float T[7 * ROW];
-    for (int i = threadIdx.x; i < 7 * 9 * COUT; i += blockDim.x) {
-        const int code = i / (9 * COUT), r = i - code * 9 * COUT, k = r / COUT, co = r - k * COUT;
+    // One thread = one pixel, all 32 channels: the nine neighbour codes are read and decoded once.  The table row of a
+    // code is indexed by the code's low nibble (1 -> 1, -1 -> 15, -2 -> 14, -3 -> 13, 10 -> 10, -10 -> 6: all
+    // different; row 0 = outside the image = zeros), so decoding a code is one AND.
+    constexpr int SS = S * S, COUT = 32, ROW = 9 * COUT + 4;            // table row (floats), padded: rows land on different banks
+    __shared__ __attribute__((aligned(16))) float T[16 * ROW];
+    for (int i = threadIdx.x; i < 16 * 9 * COUT; i += blockDim.x) {
+        const int nib = i / (9 * COUT), r = i - nib * 9 * COUT, k = r / COUT, co = r - k * COUT;
         const float *wc = w + (size_t)co * cin * 9 + k;
-        // code index: 0 = outside the image, 1 = EMPTY (1), 2 = WALL (-1), 3 = own body (-2), 4 = own head (10),
-        //             5 = enemy body (-3), 6 = enemy head (-10)            (map.py:67-81)
-        float v = 0.0f;
-        if (code == 2) v = wc[0];
-        else if (code == 3) v = wc[9];
-        else if (code == 4) v = 10.0f * wc[9];
-        else if (code == 5) v = wc[18];
-        else if (code == 6) v = 10.0f * wc[18];
-        if (code != 0 && cin == 4) v += plane4 * wc[27];
-        T[code * ROW + k * COUT + co] = v;
+        float v = 0.0f;                                                  // EMPTY (1) and the unused nibbles: no plane is set
+        if (nib == 15) v = wc[0];                                        // WALL -1      (map.py:67-81, util.py:18-27)
+        else if (nib == 14) v = wc[9];                                   // own body -2
+        else if (nib == 10) v = 10.0f * wc[9];                           // own head 10
+        else if (nib == 13) v = wc[18];                                  // enemy body -3
+        else if (nib == 6) v = 10.0f * wc[18];                           // enemy head -10
+        const bool real = nib == 1 || nib == 15 || nib == 14 || nib == 10 || nib == 13 || nib == 6;
+        if (real && cin == 4) v += plane4 * wc[27];
+        T[nib * ROW + k * COUT + co] = real ? v : 0.0f;
     }
     __syncthreads();
-    const int64_t total = B * SS * 4;                                    // (image, pixel, octet)
+    const int64_t total = B * SS;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t img = i / (SS * 4);
-        const int r = (int)(i - img * SS * 4), oct = r / SS, p = r - oct * SS;    // octet-major: a wave's stores are contiguous
+        const int64_t img = i / SS;
+        const int p = (int)(i - img * SS);
         const int y = p / S, x = p - y * S;
         const int8_t *c = codes + img * SS;
-        f32x4 a0 = *reinterpret_cast<const f32x4 *>(bias + oct * 8), a1 = *reinterpret_cast<const f32x4 *>(bias + oct * 8 + 4);
+        int row[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-            int code = 0;
-            if (yy >= 0 && yy < S && xx >= 0 && xx < S) {
-                const int v = c[yy * S + xx];
-                code = v == 1 ? 1 : v == -1 ? 2 : v == -2 ? 3 : v == 10 ? 4 : v == -3 ? 5 : v == -10 ? 6 : 1;
-            }
-            const float *t = T + code * ROW + k * COUT + oct * 8;
-            a0 += *reinterpret_cast<const f32x4 *>(t);
-            a1 += *reinterpret_cast<const f32x4 *>(t + 4);
+            const bool inside = yy >= 0 && yy < S && xx >= 0 && xx < S;
+            const int v = inside ? (int)c[yy * S + xx] : 0;
+            row[k] = (v & 15) * ROW + k * COUT;
         }
-        a0 = mish4(a0) * ACT_SCALE;
-        a1 = mish4(a1) * ACT_SCALE;
-        f16x8 hh, ll;
+        unsigned char *op = out + (size_t)img * 2 * 4 * SS * 16 + (size_t)p * 16;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f16 h, l;
-            split(a0[j], h, l);
-            hh[j] = h; ll[j] = l;
-            split(a1[j], h, l);
-            hh[4 + j] = h; ll[4 + j] = l;
+        for (int oct = 0; oct < 4; ++oct) {
+            f32x4 a0 = *reinterpret_cast<const f32x4 *>(bias + oct * 8), a1 = *reinterpret_cast<const f32x4 *>(bias + oct * 8 + 4);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float *t = T + row[k] + oct * 8;
+                a0 += *reinterpret_cast<const f32x4 *>(t);
+                a1 += *reinterpret_cast<const f32x4 *>(t + 4);
+            }
+            a0 = mish4(a0) * ACT_SCALE;
+            a1 = mish4(a1) * ACT_SCALE;
+            const f16x4 h0 = __builtin_convertvector(a0, f16x4), h1 = __builtin_convertvector(a1, f16x4);
+            const f16x4 l0 = __builtin_convertvector((a0 - __builtin_convertvector(h0, f32x4)) * LO_SCALE, f16x4);
+            const f16x4 l1 = __builtin_convertvector((a1 - __builtin_convertvector(h1, f32x4)) * LO_SCALE, f16x4);
+            const f16x8 hh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const f16x8 ll = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            *reinterpret_cast<f16x8 *>(op + (size_t)oct * SS * 16) = hh;
+            *reinterpret_cast<f16x8 *>(op + (size_t)(4 + oct) * SS * 16) = ll;
         }
-        unsigned char *op = out + (size_t)img * 2 * 4 * SS * 16 + (size_t)(oct * SS + p) * 16;
-        *reinterpret_cast<f16x8 *>(op) = hh;
-        *reinterpret_cast<f16x8 *>(op + 4 * SS * 16) = ll;
     }
 }
 
@@ -581,7 +595,7 @@ int launch_ws(const void *in, const void *wfrag, const float *bias, const void *
                            reinterpret_cast<const unsigned char *>(res), reinterpret_cast<unsigned char *>(out),      \
                            out_f32, pre_f32, (int)B, apply_mish, (int)nitems);                                        \
     } while (0)
-    const bool f32o = out_f32 || pre_f32;
+    const bool f32o = out_f32 || pre_f32 || !apply_mish || !out;       // anything but the chain's inner layers: the general variant
     if (res) { if (f32o) TRON_WS_LAUNCH(true, true); else TRON_WS_LAUNCH(true, false); }
     else     { if (f32o) TRON_WS_LAUNCH(false, true); else TRON_WS_LAUNCH(false, false); }
 #undef TRON_WS_LAUNCH
@@ -665,8 +679,8 @@ extern "C" int tron_conv1_px16(const int8_t *codes, const float *weight, const f
     if ((reinterpret_cast<uintptr_t>(out_px16) | reinterpret_cast<uintptr_t>(bias)) & 15u) return TRON_ERR_BAD_ARG;
     if (batch == 0) return TRON_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int64_t total = batch * side * side * 4;
-    const unsigned grid = (unsigned)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
+    const int64_t total = batch * side * side;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 256 * 8 ? (total + 255) / 256 : 256 * 8);
     if (side == 12) hipLaunchKernelGGL(k_conv1_px<12>, dim3(grid), dim3(256), 0, st, codes, weight, bias, cin, plane4, batch, reinterpret_cast<unsigned char *>(out_px16));
     else if (side == 26) hipLaunchKernelGGL(k_conv1_px<26>, dim3(grid), dim3(256), 0, st, codes, weight, bias, cin, plane4, batch, reinterpret_cast<unsigned char *>(out_px16));
     else if (side == 34) hipLaunchKernelGGL(k_conv1_px<34>, dim3(grid), dim3(256), 0, st, codes, weight, bias, cin, plane4, batch, reinterpret_cast<unsigned char *>(out_px16));

@@ -280,6 +280,94 @@ __global__ __launch_bounds__(256) void k_pool_split26(const float *__restrict__ 
     }
 }
 
+// ---- the same two poolings reading the trunk's output as the PX16 image of csrc/tron_conv_ws.hip ----------------------
+// PX16: per image [hi | lo][channel octet][pixel][8 channels] f16, value / 64 = hi + lo 2^-11 — already in this file's
+// scale, so the pooled value is the average of (hi + lo 2^-11) over the window, split again.
+typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void px16_window_sum(const unsigned char *img, int S, int half_bytes, int oct, int py, int px, float (&sum)[8])
+{
+    // all 18 loads are issued before the first use: positions outside the image are clamped and weighted 0
+    f16x8h h[9], l[9];
+    float wgt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = 2 * py + t / 3 - 1, xx = 2 * px + t % 3 - 1;
+        const bool in = yy >= 0 && yy < S && xx >= 0 && xx < S;
+        const int yc = yy < 0 ? 0 : (yy >= S ? S - 1 : yy), xc = xx < 0 ? 0 : (xx >= S ? S - 1 : xx);
+        const unsigned char *p = img + ((size_t)oct * S * S + yc * S + xc) * 16;
+        h[t] = *reinterpret_cast<const f16x8h *>(p);
+        l[t] = *reinterpret_cast<const f16x8h *>(p + half_bytes);
+        wgt[t] = in ? 1.0f : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float hs = 0.0f, ls = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            hs += wgt[t] * (float)h[t][j];
+            ls += wgt[t] * (float)l[t][j];
+        }
+        sum[j] = hs + ls * LO_UNSCALE;
+    }
+}
+
+// 12x12: rows [B][64 * 36] in NCHW-flatten order (what k_pool_split12 writes).  One workgroup walks images; a thread
+// pools one (octet, pooled pixel) — eight channels — into LDS, then the rows go out as contiguous 4-byte stores.
+__global__ __launch_bounds__(320) void k_pool_split12_px(const unsigned char *__restrict__ x, int64_t B, f16 *__restrict__ oh,
+                                                         f16 *__restrict__ ol)
+{
+    constexpr int S = 12, C = 64, HALF = (C / 8) * S * S * 16;
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    __shared__ float pooled[C * 36];
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        const int t = threadIdx.x;
+        if (t < 8 * 36) {
+            const int oct = t / 36, pp = t - oct * 36;
+            float sum[8];
+            px16_window_sum(x + (size_t)b * 2 * HALF, S, HALF, oct, pp / 6, pp % 6, sum);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pooled[(oct * 8 + j) * 36 + pp] = sum[j] * (1.0f / 9.0f);
+        }
+        __syncthreads();
+        for (int i = t; i < C * 36 / 2; i += 320) {
+            f16 h0, l0, h1, l1;
+            split(pooled[2 * i], h0, l0);
+            split(pooled[2 * i + 1], h1, l1);
+            *reinterpret_cast<f16x2 *>(oh + b * (C * 36) + 2 * i) = (f16x2){h0, h1};
+            *reinterpret_cast<f16x2 *>(ol + b * (C * 36) + 2 * i) = (f16x2){l0, l1};
+        }
+        __syncthreads();
+    }
+}
+
+// 26x26: the zero-haloed channels-last split image [B][19][19][64] (what k_pool_split26 writes).  One thread = one padded
+// pixel x one channel octet: a 16-byte store per half, zeros in the halo.
+__global__ __launch_bounds__(256) void k_pool_split26_px(const unsigned char *__restrict__ x, int64_t B, f16 *__restrict__ oh,
+                                                         f16 *__restrict__ ol)
+{
+    constexpr int S = 26, PS = 13, C = 64, HALF = (C / 8) * S * S * 16;
+    const int64_t total = B * 19 * 19 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int oct = (int)(i & 7);
+        const int64_t pix = i >> 3, b = pix / 361;
+        const int r = (int)(pix - b * 361), py = r / 19 - 3, px = r % 19 - 3;
+        f16x8h h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (py >= 0 && py < PS && px >= 0 && px < PS) {
+            float sum[8];
+            px16_window_sum(x + (size_t)b * 2 * HALF, S, HALF, oct, py, px, sum);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f16 hh, ll;
+                split(sum[j] * (1.0f / 9.0f), hh, ll);
+                h[j] = hh;
+                l[j] = ll;
+            }
+        }
+        *reinterpret_cast<f16x8h *>(oh + (size_t)pix * C + oct * 8) = h;
+        *reinterpret_cast<f16x8h *>(ol + (size_t)pix * C + oct * 8) = l;
+    }
+}
+
 // conv7's weight [64][64][7][7] -> [co][tap = 7 ky + kx][ci], split: the W matrix of the CONV7 GEMM
 __global__ void k_conv7w_split(const float *__restrict__ w, f16 *__restrict__ oh, f16 *__restrict__ ol)
 {
@@ -535,11 +623,13 @@ extern "C" int64_t tron_dqn_head_workspace(int64_t batch, int32_t side)
     return plan(batch, 64 * 6 * 6, 64 * 3 * 3).total;
 }
 
-extern "C" int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t side, const float *conv7_w,
-                                 const float *conv7_b, const float *fc1_w, const float *fc1_b, const float *fc2_w,
-                                 const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,
-                                 const float *actor2_b, void *workspace, float *q_out, int8_t *greedy_out, void *stream)
+static int head_fwd(const void *trunk, bool px16, int64_t batch, int32_t side, const float *conv7_w,
+                    const float *conv7_b, const float *fc1_w, const float *fc1_b, const float *fc2_w,
+                    const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,
+                    const float *actor2_b, void *workspace, float *q_out, int8_t *greedy_out, void *stream)
 {
+    const float *trunk_out = reinterpret_cast<const float *>(trunk);
+    const unsigned char *trunk_px = reinterpret_cast<const unsigned char *>(trunk);
     if (!trunk_out || !conv7_w || !conv7_b || !fc1_w || !fc1_b || !fc2_w || !fc2_b || !actor1_w || !actor1_b ||
         !actor2_w || !actor2_b || !workspace || (!q_out && !greedy_out) || batch < 0)
         return TRON_ERR_BAD_ARG;
@@ -553,7 +643,8 @@ extern "C" int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t 
         const HeadPlan p = plan(batch, K7, N1, (int64_t)P7_PIX * 64, 64);
         unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
         auto H = [&](int64_t off) { return reinterpret_cast<f16 *>(ws + off); };
-        hipLaunchKernelGGL(k_pool_split26, dim3((unsigned)(batch * 19)), dim3(256), 0, st, trunk_out, H(p.a7h), H(p.a7l));
+        if (px16) hipLaunchKernelGGL(k_pool_split26_px, dim3((unsigned)((batch * 361 * 8 + 255) / 256 < (1 << 20) ? (batch * 361 * 8 + 255) / 256 : (1 << 20))), dim3(256), 0, st, trunk_px, batch, H(p.a7h), H(p.a7l));
+        else hipLaunchKernelGGL(k_pool_split26, dim3((unsigned)(batch * 19)), dim3(256), 0, st, trunk_out, H(p.a7h), H(p.a7l));
         hipLaunchKernelGGL(k_conv7w_split, dim3((64 * K7 + 255) / 256), dim3(256), 0, st, conv7_w, H(p.d7h), H(p.d7l));
         hipLaunchKernelGGL(k_fc1_split_nhwc, dim3((256 * N1 + 255) / 256), dim3(256), 0, st, fc1_w, H(p.w1h), H(p.w1l));
         hipLaunchKernelGGL(k_split_rows, dim3((128 * 256 + 255) / 256), dim3(256), 0, st, fc2_w, 128 * 256, H(p.w2h), H(p.w2l));
@@ -575,7 +666,8 @@ extern "C" int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t 
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
     auto H = [&](int64_t off) { return reinterpret_cast<f16 *>(ws + off); };
     const int64_t nrows = batch * C * PS;
-    hipLaunchKernelGGL(k_pool_split12, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, trunk_out, nrows, H(p.a7h), H(p.a7l));
+    if (px16) hipLaunchKernelGGL(k_pool_split12_px, dim3((unsigned)(batch < 256 * 8 ? batch : 256 * 8)), dim3(320), 0, st, trunk_px, batch, H(p.a7h), H(p.a7l));
+    else hipLaunchKernelGGL(k_pool_split12, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, trunk_out, nrows, H(p.a7h), H(p.a7l));
     hipLaunchKernelGGL(k_dense7_split, dim3((N7 * K7 + 255) / 256), dim3(256), 0, st, conv7_w, C, C, PS, OS, H(p.d7h), H(p.d7l));
     hipLaunchKernelGGL(k_split_rows, dim3((256 * N7 + 255) / 256), dim3(256), 0, st, fc1_w, 256 * N7, H(p.w1h), H(p.w1l));
     hipLaunchKernelGGL(k_split_rows, dim3((128 * 256 + 255) / 256), dim3(256), 0, st, fc2_w, 128 * 256, H(p.w2h), H(p.w2l));
@@ -590,6 +682,25 @@ extern "C" int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t 
     hipLaunchKernelGGL(k_q_head, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, c3, actor2_w, actor2_b, (int)batch, 64,
                        q_out, greedy_out);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t side, const float *conv7_w,
+                                 const float *conv7_b, const float *fc1_w, const float *fc1_b, const float *fc2_w,
+                                 const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,
+                                 const float *actor2_b, void *workspace, float *q_out, int8_t *greedy_out, void *stream)
+{
+    return head_fwd(trunk_out, false, batch, side, conv7_w, conv7_b, fc1_w, fc1_b, fc2_w, fc2_b, actor1_w, actor1_b, actor2_w,
+                    actor2_b, workspace, q_out, greedy_out, stream);
+}
+
+extern "C" int tron_dqn_head_fwd_px16(const void *trunk_px16, int64_t batch, int32_t side, const float *conv7_w,
+                                      const float *conv7_b, const float *fc1_w, const float *fc1_b, const float *fc2_w,
+                                      const float *fc2_b, const float *actor1_w, const float *actor1_b,
+                                      const float *actor2_w, const float *actor2_b, void *workspace, float *q_out,
+                                      int8_t *greedy_out, void *stream)
+{
+    return head_fwd(trunk_px16, true, batch, side, conv7_w, conv7_b, fc1_w, fc1_b, fc2_w, fc2_b, actor1_w, actor1_b, actor2_w,
+                    actor2_b, workspace, q_out, greedy_out, stream);
 }
 
 // ---- training-path pieces of the same layers (Net/activations.py::_PoolConv7): pooling forward / backward on 12x12

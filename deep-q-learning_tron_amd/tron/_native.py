@@ -75,6 +75,7 @@ SIGNATURES = {
     "tron_conv3x3_ws_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "tron_px16_to_f32": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "tron_dqn_head_fwd": (C.c_int, [_vp, _i64, _i32] + [_vp] * 10 + [_vp, _vp, _vp, _vp]),
+    "tron_dqn_head_fwd_px16": (C.c_int, [_vp, _i64, _i32] + [_vp] * 10 + [_vp, _vp, _vp, _vp]),
     "tron_dqn_head_workspace": (C.c_int64, [_i64, _i32]),
     "tron_pool12": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "tron_pool_s2": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),

@@ -364,6 +364,12 @@ int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t side, const
                       const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,
                       const float *actor2_b, void *workspace, float *q_out, int8_t *greedy_out, void *stream);
 int64_t tron_dqn_head_workspace(int64_t batch, int32_t side);
+/* The same with the trunk's output handed over as the PX16 image conv6 of the weight-stationary chain writes
+ * (tron_conv3x3_ws_fwd; 64 channels): the pooling reads it directly, no f32 tensor in between.  Same workspace size. */
+int tron_dqn_head_fwd_px16(const void *trunk_px16, int64_t batch, int32_t side, const float *conv7_w,
+                           const float *conv7_b, const float *fc1_w, const float *fc1_b, const float *fc2_w,
+                           const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,
+                           const float *actor2_b, void *workspace, float *q_out, int8_t *greedy_out, void *stream);
 /* The same two layers on the training path (their products are library GEMMs on conv7's dense form):
  * tron_pool12: AvgPool2d(3, stride 2, padding 1) (Net/DQNNet.py:20,52) of `planes` 12x12 f32 planes -> 6x6 (backward 0),
  * or its gradient 6x6 -> 12x12 (backward 1).  tron_conv7_dense: fold 0: conv7's weight f32[cout][cin][7][7] -> the

@@ -68,3 +68,22 @@ for math in (() if only else ("f16x3",)):
         print(f"trunk ws={ws}: {t:.1f} us = {fl / t / 1e6:.1f} TF/s f32-equivalent", flush=True)
         t = timeit(lambda: net.infer(codes, codes=True, greedy=True), 10)
         print(f"Net.infer ws={ws}: {t:.1f} us", flush=True)
+if not only:
+    fused.use_ws = True
+    for sl in (512, 1024, 2048, 4096, B):
+        if sl > B:
+            continue
+        def sliced():
+            outs = []
+            w = fused.ws_split_weights([net.conv2, net.conv3, net.conv4, net.conv5, net.conv6])
+            for i in range(0, B, sl):
+                c_ = codes[i:i + sl]
+                a = fused.conv1_px16(c_, net.conv1)
+                b = fused.conv_ws(a, net.conv2, w[0])
+                c = fused.conv_ws(b, net.conv3, w[1], residual=a)
+                d = fused.conv_ws(c, net.conv4, w[2])
+                e = fused.conv_ws(d, net.conv5, w[3])
+                outs.append(fused.conv_ws(e, net.conv6, w[4], residual=d))
+            return outs
+        t = timeit(sliced, 10)
+        print(f"trunk (px16 out) in slices of {sl}: {t:.1f} us", flush=True)

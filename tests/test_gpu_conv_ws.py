@@ -134,3 +134,45 @@ def test_conv_ws_bad_args(fused):
     assert L.tron_conv3x3_ws_fwd(*a, None, None, None, 2, 64, 64, 12, 1, None) == nat.ERR_BAD_ARG      # no output
     assert L.tron_conv3x3_ws_fwd(*a, x.buf.data_ptr(), None, None, 0, 64, 64, 12, 1, None) == 0        # empty batch
     assert L.tron_conv3x3_ws_fwd(*a, x.buf.data_ptr(), None, None, 2, 64, 64, 14, 1, None) == nat.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("W,B", [(10, 1), (10, 777), (24, 3), (24, 140)])
+def test_head_from_px16_equals_head_from_f32(fused, W, B):
+    """tron_dqn_head_fwd_px16 (the pooling reads conv6's PX16 image) against the float64 reference of the tail
+    (DQNNet.py:52-63) and against the f32-input head on the same values."""
+    from Net.DQNNet import Net
+    torch.manual_seed(W * B)
+    S = W + 2
+    net = Net(3, W).cuda()
+    x = torch.randn(B, 64, S, S, device="cuda") * 1.5
+    xp = _to_px16(fused, x)
+    q_px, g_px = fused.head(net, xp, want_greedy=True)
+    q_f = fused.head(net, xp.float())
+    d = lambda t: t.double()
+    y = F.avg_pool2d(x.double(), 3, stride=2, padding=1)
+    y = F.mish(F.conv2d(y, d(net.conv7.weight), d(net.conv7.bias), stride=2, padding=3)).reshape(B, -1)
+    y = F.mish(F.linear(y, d(net.fc1.weight), d(net.fc1.bias)))
+    y = F.mish(F.linear(y, d(net.fc2.weight), d(net.fc2.bias)))
+    ref = F.linear(F.mish(F.linear(y, d(net.actor1.weight), d(net.actor1.bias))), d(net.actor2.weight), d(net.actor2.bias))
+    assert (q_px.double() - ref).abs().max().item() < TOL
+    assert (q_px - q_f).abs().max().item() < 2e-6
+    assert torch.equal(g_px.long(), q_px.argmax(1))
+
+
+@pytest.mark.parametrize("W", [10, 24])
+def test_infer_from_codes_takes_the_ws_chain(fused, W, monkeypatch):
+    """Net.infer(codes) runs conv1..conv6 + head without an f32 activation tensor; Net.infer_path reports the path; the
+    chunked layer kernels (TRON_CONV_WS=0) give the same Q to 1e-6."""
+    from Net.DQNNet import Net
+    torch.manual_seed(W)
+    S = W + 2
+    net = Net(3, W).cuda()
+    codes = _codes(300, S, W)
+    assert net.infer_path(codes, codes=True) == "ws-chain"
+    assert net.infer_path(torch.zeros(2, 3, S, S, device="cuda")) == "layer-kernels"
+    assert net.infer_path(torch.zeros(2, 3, 14, 14, device="cuda")) == "module"
+    q = net.infer(codes, codes=True)
+    monkeypatch.setattr(fused, "use_ws", False)
+    assert net.infer_path(codes, codes=True) == "layer-kernels"
+    q_old = net.infer(codes, codes=True)
+    assert (q - q_old).abs().max().item() < 2e-6
