@@ -91,7 +91,9 @@ class Brain(object):
         split = mb < B
         if split and self.acktr:
             self.optimizer.begin_accumulate(B)
-        noise = torch.randn(B, 1, device=self.device) if fisher else None     # value noise of the sampled Fisher
+        # value noise of the sampled Fisher: drawn from the HOST generator and moved, as the reference does (ACKTR.py:133-135) —
+        # the same torch.manual_seed then gives the same update on either device (tests/test_gpu_benchbatch.py)
+        noise = torch.randn(B, 1).to(self.device, non_blocking=True) if fisher else None
         sums = torch.zeros(5, device=self.device)     # value_loss, action_gain, entropy, logp, advantage
         grads = None
         for lo in range(0, B, mb):

@@ -134,7 +134,12 @@ def test_infer_equals_module_forward_and_codes_path(fused, W, B, cin):
     q_p = net.infer(planes)
     q_c = net.infer(codes, codes=True, plane4=5.0)
     assert (q_p.double() - ref).abs().max().item() < TOL
-    assert torch.equal(q_p, q_c)
+    assert (q_c.double() - ref).abs().max().item() < TOL       # (codes: the weight-stationary chain; planes: the layer kernels)
+    fused.use_ws = False
+    try:
+        assert torch.equal(q_p, net.infer(codes, codes=True, plane4=5.0))   # same kernels, two ways of staging conv1's input
+    finally:
+        fused.use_ws = True
 
 
 @pytest.mark.parametrize("S,B,cin,cout,with_res", [(12, 33, 32, 32, True), (12, 64, 32, 64, False), (12, 20, 64, 64, True),
