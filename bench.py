@@ -188,6 +188,34 @@ def dqn_record(envs, width, steps, warmup, batch, repeats, world, rank):
     pol_s = statistics.median(pol)
     learned = o["learn_steps"] * batch * world
     f_fwd = net_forward_flops(width)
+    # the learner alone, saturated: learn steps back to back on the warm ring (sample as int8 codes -> forward + backward
+    # of the local net, two target forwards, Adam, soft update, gradient all-reduce when world > 1) — what learn() can
+    # consume when the env side is not what paces it (the paced loop above learns `batch` of every
+    # 2 x envs x learn_every pushed transitions)
+    sat_steps = max(10, 2 * steps)
+    for _ in range(3):
+        brain.learn(brain.memory.sample_codes(), DDQN.GAMMA)
+    sat = []
+    for _ in range(repeats):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(sat_steps):
+            brain.learn(brain.memory.sample_codes(), DDQN.GAMMA)
+        torch.cuda.synchronize()
+        sat.append(max_over_ranks(time.perf_counter() - t0, world))
+    sat_s = statistics.median(sat)
+    sat_flops = f_fwd * batch * (3 + 2) * sat_steps * world
+    learner_saturated = {
+        "metric": "dqn-transitions/sec, learn() back to back on a warm replay ring (no env stepping in between)",
+        "value": sat_steps * batch * world / sat_s, "unit": "transitions/s", "learn_steps": sat_steps,
+        "ms_per_learn_step": sat_s / sat_steps * 1e3, "learn_batch": batch, "replay_slots_filled": len(brain.memory),
+        "roofline": {"bound": "mfma", "unit": "TFLOP/s (f32-equivalent)", "peak": F16_MATRIX_PEAK_TFLOPS / 3,
+                     "achieved": sat_flops / sat_s / 1e12, "frac": sat_flops / sat_s / 1e12 / (F16_MATRIX_PEAK_TFLOPS / 3),
+                     "flops_per_learn_step": f_fwd * batch * 5,
+                     "note": "forward + backward of the local net on s (3 x forward), forward-only local and target on s' "
+                             "(weight-stationary chain from the int8 codes)"}}
     # per iteration of the loop: the policy forward on 2N observations (eval, no grad); per learn step on a
     # batch B: forward + backward of the local net on s (~3x forward), forward-only local and target on s'
     flops = f_fwd * (2 * envs * steps + o["learn_steps"] * batch * (3 + 2)) * world
@@ -200,6 +228,11 @@ def dqn_record(envs, width, steps, warmup, batch, repeats, world, rank):
                                "frac_of_f16x3_peak": f_fwd * 2 * envs * steps * world / pol_s / 1e12 / (F16_MATRIX_PEAK_TFLOPS / 3)},
             "steps": steps, "repeats": repeats, "seconds_min_med_max": [runs[0][0], sec, runs[-1][0]],
             "learn_batch": batch, "learn_every_env_steps": 2, "dtype": "f32",
+            "replay_ratio": {"learned_per_pushed": batch / (2.0 * envs * 2),
+                             "note": f"the paced loop learns {batch} of the {2 * envs * 2} transitions pushed per 2 env-steps; "
+                                     "the reference learns 64 per 4 pushed (DDQN.py:73-88)"},
+            "learner_saturated": learner_saturated,
+            "policy_path": brain.qnetwork_local.infer_path(codes, codes=True),
             "config": {"workload": f"{envs} parallel {width}x{width} self-play envs per GPU, DDQN + target net, "
                                    f"1M-slot HBM replay, learn batch {batch} every 2 env-steps, eps-greedy policy = "
                                    f"the 7-conv CNN (Net/DQNNet.py) on the int8 observations",
@@ -242,6 +275,7 @@ def main():
                          "10x10; use --envs/--width/--batch/--dqn-steps for others)")
     ap.add_argument("--batch", type=int, default=4096, help="DQN record: learn batch")
     ap.add_argument("--dqn-steps", type=int, default=40, help="DQN record: env steps per timed region")
+    ap.add_argument("--dqn3-steps", type=int, default=8, help="config-3 DQN record (65 536 envs x 24x24): env steps per timed region")
     ap.add_argument("--dqn-envs", type=int, default=4096)
     ap.add_argument("--dqn-width", type=int, default=10)
     args = ap.parse_args()
@@ -357,7 +391,7 @@ def main():
     step_ms = ev_ms / args.steps
     kern_ms = ev_ms / n_launches                   # avg launch of the step kernel
 
-    dqn = None
+    dqn = dqn3 = None
     if not args.no_dqn and not args.incremental:
         env.close()
         del env
@@ -366,6 +400,12 @@ def main():
             dqn = dqn_record(args.dqn_envs, args.dqn_width, args.dqn_steps, 6, args.batch, 3, world, rank)
         except Exception as e:                     # the headline must survive a trainer-side failure
             dqn = {"error": f"{type(e).__name__}: {e}"}
+        try:                                       # BASELINE configs[2]: 65 536 envs x 24x24, 1M-slot replay
+            torch.cuda.empty_cache()
+            dqn3 = dqn_record(N_ENVS, WIDTH, args.dqn3_steps, 2, args.batch, 3, world, rank)
+        except Exception as e:
+            dqn3 = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
 
     if rank == 0:
         total_env_steps = args.envs * world * args.steps
@@ -463,6 +503,8 @@ def main():
                              "kernel": "k_obs_roll with TRON_ROLLOUT_RESIDENT"}}
         if dqn is not None:
             out["dqn"] = dqn
+        if dqn3 is not None:
+            out["dqn_config3"] = dqn3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.width)
         print(json.dumps(out), flush=True)

@@ -72,6 +72,11 @@ class ReplayBuffer:
     def sample(self):                              # DDQN.py:191-200
         return self.memory.sample(self.batch_size, self.channels, self.plane4, side=self.side)
 
+    def sample_codes(self):
+        """sample() with the states left as the ring stores them: int8 observation codes [batch, S, S] (a twelfth of
+        the bytes of the f32 planes).  Agent.learn takes either form."""
+        return self.memory.sample_codes(self.batch_size, side=self.side)
+
     def __len__(self):
         return len(self.memory)
 
@@ -149,20 +154,28 @@ class Agent():
         explore = torch.rand(greedy.shape, device=greedy.device) <= epsilon
         return torch.where(explore, rnd, greedy)
 
-    def targets(self, rewards, next_state, dones, gamma):
+    def targets(self, rewards, next_state, dones, gamma, plane4=0.0):
         """Double-DQN labels (DDQN.py:129-142): a* = argmax Q_local(s'), y = r + g Q_target(s', a*)(1-done).
-        Both forwards are gradient-free and in eval mode: Net.infer."""
-        actions_q_local = self.qnetwork_local.infer(next_state).max(1)[1].unsqueeze(1).long()
-        labels_next = self.qnetwork_target.infer(next_state).gather(1, actions_q_local)
+        Both forwards are gradient-free and in eval mode: Net.infer.  next_state: f32 planes, or int8 observation codes
+        [B, S, S] (then both forwards run the weight-stationary chain of csrc/tron_conv_ws.hip)."""
+        codes = next_state.dtype == torch.int8
+        actions_q_local = self.qnetwork_local.infer(next_state, codes=codes, plane4=plane4).max(1)[1].unsqueeze(1).long()
+        labels_next = self.qnetwork_target.infer(next_state, codes=codes, plane4=plane4).gather(1, actions_q_local)
         return rewards + (gamma * labels_next * (1 - dones))
 
     def learn(self, experiences, gamma):           # DDQN.py:115-151
+        """experiences: ReplayBuffer.sample() (f32 planes, as the reference hands them over) or .sample_codes() (int8
+        codes: conv1 reads them directly, forward and target forwards alike)."""
         states, actions, rewards, next_state, dones = experiences
         criterion = torch.nn.MSELoss()
         self.qnetwork_local.train()
         self.qnetwork_target.eval()
-        predicted_targets = self.qnetwork_local(states).gather(1, actions)
-        labels = self.targets(rewards, next_state, dones, gamma)
+        plane4 = self.memory.plane4 if self.memory is not None else 0.0
+        if states.dtype == torch.int8:
+            predicted_targets = self.qnetwork_local.forward_codes(states, plane4).gather(1, actions)
+        else:
+            predicted_targets = self.qnetwork_local(states).gather(1, actions)
+        labels = self.targets(rewards, next_state, dones, gamma, plane4)
         loss = criterion(predicted_targets, labels)
         self.totalloss += loss.detach()
         self.optimizer.zero_grad()
@@ -273,7 +286,7 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
         games_d += done.sum()
         if it % learn_every == learn_every - 1 and len(brain.memory) > batch_size:    # len(): a host counter
             brain.steps += 1
-            brain.learn(brain.memory.sample(), GAMMA)
+            brain.learn(brain.memory.sample_codes(), GAMMA)          # the batch as int8 codes: conv1 and the target chain read them
             learn_steps += 1
         # DDQN.py:313-315, once per finished 20-game cycle
         new_cycles = torch.div(games_d, GAME_CYCLE, rounding_mode="floor")

@@ -57,11 +57,29 @@ class Net(nn.Module):
         the composed form is three elementwise launches per activation."""
         return _mish(x)
 
+    def forward_codes(self, codes, plane4=0.0):
+        """forward() from the env's int8 observation codes [B, S, S] (Map.state_for_player, map.py:67-84) instead of
+        util.pop_up's f32 planes: conv1 builds the planes while it stages its input (the learner's batch comes out of
+        the replay ring as codes: tron_replay_sample_codes).  Where the HIP kernels do not cover the shape the planes
+        are built explicitly."""
+        from Net import fused
+        from Net.activations import conv1_codes_mish
+        side = codes.shape[-1]
+        if codes.is_cuda and fused.supported(self.conv1, side) and (self.activation is Net.mish or self.activation is self.mish):
+            return self._after_conv1(conv1_codes_mish(self.conv1, codes.reshape(-1, side, side), plane4))
+        from tron.vec import pop_up_planes
+        x = pop_up_planes(codes.reshape(-1, side, side))
+        if self.in_channels == 4:
+            x = torch.cat([x, torch.full_like(x[:, :1], plane4)], 1)
+        return self(x)
+
     def forward(self, x):                         # DQNNet.py:33-63
         x = x.to(self.conv1.weight.device)
         if self.activation is not Net.mish and self.activation is not self.mish:   # a caller swapped the activation
             return self._forward_plain(x)
-        x = _conv_bias_mish(self.conv1, x)
+        return self._after_conv1(_conv_bias_mish(self.conv1, x))
+
+    def _after_conv1(self, x):
         idx = x
         x = _conv_bias_mish(self.conv2, x)
         x = _conv_bias_mish(self.conv3, x, idx)

@@ -92,6 +92,50 @@ class _ConvBiasMishHIP(torch.autograd.Function):
         return gx, gw, (gb if ctx.needs_input_grad[2] else None), (gp if ctx.has_res else None)
 
 
+class _Conv1CodesHIP(torch.autograd.Function):
+    """mish(conv1(pop_up(codes)) + bias) for the learner, conv1 reading the env's / the replay ring's int8 observation
+    codes directly (TRON_CONV_IN_CODES: util.pop_up's planes, util.py:11-37, are built while the kernel stages them).
+    conv1 needs no input gradient; the weight gradient takes the f32 planes, which are built only in backward()."""
+
+    @staticmethod
+    def forward(ctx, codes, weight, bias, plane4):
+        from Net import fused
+        out, pre = fused.conv3x3_raw(codes, weight, bias, None, act=True, codes=True, plane4=plane4, want_pre=True)
+        ctx.save_for_backward(codes, weight, pre)
+        ctx.plane4 = plane4
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from Net import fused
+        from tron.vec import pop_up_planes
+        codes, weight, pre = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if not _aligned16(g):
+            g = g.clone(memory_format=torch.contiguous_format)
+        gp, gb, absmax = bias_mish_bwd(pre, g, want_absmax=True)
+        gw = None
+        if ctx.needs_input_grad[1]:
+            x = pop_up_planes(codes)
+            if weight.shape[1] == 4:
+                x = torch.cat([x, torch.full_like(x[:, :1], ctx.plane4)], 1)
+            if fused.wgrad_supported(weight, x.shape[-1]):
+                gw = fused.conv3x3_wgrad(x, gp, absmax)
+            else:
+                gw = torch.ops.aten.convolution_backward(gp, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
+        return None, gw, (gb if ctx.needs_input_grad[2] else None), None
+
+
+def conv1_codes_mish(conv, codes, plane4=0.0):
+    """mish(conv1(planes of `codes`)) with autograd for weight and bias: codes int8 [B, S, S] on the device."""
+    from Net import fused
+    if not (codes.is_cuda and codes.dtype == torch.int8 and codes.dim() == 3 and codes.shape[-1] == codes.shape[-2]
+            and fused.supported(conv, codes.shape[-1]) and conv.in_channels in (3, 4) and conv.bias is not None):
+        raise TypeError("conv1_codes_mish: int8 codes [B, S, S] on the device and a conv1 the HIP kernels cover")
+    return _Conv1CodesHIP.apply(codes.contiguous(), conv.weight, conv.bias, float(plane4))
+
+
 class _BiasMish(torch.autograd.Function):
     """mish(y + bias[c] (+ residual)) for a bias-free convolution output y [N, C, H, W]."""
 

@@ -240,7 +240,9 @@ def trunk_px(net, codes, plane4=0.0, want="f32"):
     a = conv1_px16(codes, net.conv1, plane4)
     b = conv_ws(a, net.conv2, w[0])
     c = conv_ws(b, net.conv3, w[1], residual=a)
+    del a, b                                      # (an image is 4 bytes per element: 23 GB for 131 072 x 64 x 26 x 26 — let the allocator reuse them)
     d = conv_ws(c, net.conv4, w[2])
+    del c
     e = conv_ws(d, net.conv5, w[3])
     if want == "px16":
         return conv_ws(e, net.conv6, w[4], residual=d)

@@ -154,6 +154,35 @@ __global__ __launch_bounds__(256) void k_sample_gather(const int64_t *__restrict
     }
 }
 
+// the same gather without the expansion: the rows stay int8 observation codes (what conv1's CODES staging and the
+// weight-stationary chain read) — 1 byte per cell out instead of 12 / 16
+__global__ __launch_bounds__(64) void k_sample_gather_codes(const int64_t *__restrict__ idx, int cells,
+                                                            const int8_t *__restrict__ states,
+                                                            const int8_t *__restrict__ next_states,
+                                                            const int8_t *__restrict__ actions,
+                                                            const float *__restrict__ rewards,
+                                                            const int8_t *__restrict__ dones, int8_t *__restrict__ o_s,
+                                                            int64_t *__restrict__ o_a, float *__restrict__ o_r,
+                                                            int8_t *__restrict__ o_s2, float *__restrict__ o_d)
+{
+    const int b = blockIdx.x >> 1, which = blockIdx.x & 1;
+    const int64_t slot = idx[b];
+    const int8_t *src = (which ? next_states : states) + (size_t)slot * cells;
+    int8_t *dst = (which ? o_s2 : o_s) + (size_t)b * cells;
+    if (!which && threadIdx.x == 0) {
+        o_a[b] = (int64_t)actions[slot];
+        o_r[b] = rewards[slot];
+        o_d[b] = (float)dones[slot];
+    }
+    if ((cells & 3) == 0) {                                              // (ring rows and output rows are 4-byte aligned then)
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+        uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
+        for (int i = threadIdx.x; i < (cells >> 2); i += blockDim.x) d32[i] = s32[i];
+    } else {
+        for (int i = threadIdx.x; i < cells; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
 __global__ void k_copy_i64(const int64_t *src, int64_t *dst, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -265,6 +294,24 @@ int tron_replay_sample(tron_replay_handle r, int32_t batch, int32_t channels, fl
     hipLaunchKernelGGL(k_sample_gather, dim3(2 * batch), dim3(256), 0, S_(stream), r->indices, batch, r->cells,
                        channels, plane4, r->states, r->next_states, r->actions, r->rewards, r->dones, states, actions,
                        rewards, next_states, dones);
+    return launch_status();
+}
+
+int tron_replay_sample_codes(tron_replay_handle r, int32_t batch, int8_t *states, int64_t *actions, float *rewards,
+                             int8_t *next_states, float *dones, void *stream)
+{
+    if (bad(r)) return r ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
+    if (batch < 1 || batch > r->max_batch) return TRON_ERR_BAD_ARG;
+    if (!states || !actions || !rewards || !next_states || !dones) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(states) | reinterpret_cast<uintptr_t>(next_states)) & 3u) return TRON_ERR_BAD_ARG;
+    if (r->size < batch) return TRON_ERR_BAD_ARG;       // random.sample raises ValueError likewise
+    const uint32_t call = r->calls++;                    // (the same draw sequence as tron_replay_sample: one permutation per call)
+    int half_bits = 1;
+    while (half_bits < 16 && (1ull << (2 * half_bits)) < (uint64_t)r->size) ++half_bits;
+    hipLaunchKernelGGL(k_sample_indices, dim3((batch + 255) / 256), dim3(256), 0, S_(stream), (uint64_t)r->size, batch,
+                       half_bits, r->seed, r->stream, call, r->indices);
+    hipLaunchKernelGGL(k_sample_gather_codes, dim3(2 * batch), dim3(64), 0, S_(stream), r->indices, r->cells, r->states,
+                       r->next_states, r->actions, r->rewards, r->dones, states, actions, rewards, next_states, dones);
     return launch_status();
 }
 

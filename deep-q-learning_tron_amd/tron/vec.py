@@ -341,6 +341,21 @@ class DeviceReplay:
                       "tron_replay_sample")
         return st, a, r, s2, d
 
+    def sample_codes(self, batch, side=None):
+        """The same draw with the states left as int8 observation codes [batch, S, S] (tron_replay_sample_codes): what
+        the learner's conv1 and the weight-stationary target forwards read — a twelfth of the bytes of the f32 planes."""
+        dev = self.device
+        S = side if side is not None else int(round(self.cells ** 0.5))
+        st = torch.empty(batch, S, S, dtype=torch.int8, device=dev)
+        s2 = torch.empty_like(st)
+        a = torch.empty(batch, 1, dtype=torch.int64, device=dev)
+        r = torch.empty(batch, 1, dtype=torch.float32, device=dev)
+        d = torch.empty(batch, 1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_replay_sample_codes(self._h, batch, nat.ptr(st), nat.ptr(a), nat.ptr(r), nat.ptr(s2),
+                                                         nat.ptr(d), nat.stream_ptr()), "tron_replay_sample_codes")
+        return st, a, r, s2, d
+
     def last_indices(self, batch):
         out = torch.empty(batch, dtype=torch.int64, device=self.device)
         with torch.cuda.device(self.device):

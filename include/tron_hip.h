@@ -207,6 +207,11 @@ int tron_replay_push(tron_replay_handle r, int64_t n, const int8_t *state, const
 int tron_replay_sample(tron_replay_handle r, int32_t batch, int32_t channels, float plane4,
                        float *states, int64_t *actions, float *rewards, float *next_states,
                        float *dones, void *stream);
+/* The same draw (random.sample semantics, one fresh permutation per call) with the states left as they are stored:
+ * states / next_states int8[batch][cells] observation codes (4-byte aligned) — what conv1's TRON_CONV_IN_CODES staging
+ * and tron_conv1_px16 read; 1 byte per cell instead of 12 or 16.                                                   */
+int tron_replay_sample_codes(tron_replay_handle r, int32_t batch, int8_t *states, int64_t *actions, float *rewards,
+                             int8_t *next_states, float *dones, void *stream);
 int tron_replay_size(tron_replay_handle r, int64_t *size, int64_t *capacity);
 /* The slots drawn by the last tron_replay_sample, i64[batch] (tests, logging). */
 int tron_replay_indices(tron_replay_handle r, int32_t batch, int64_t *indices_out, void *stream);

@@ -1,0 +1,96 @@
+"""The learner fed with int8 observation codes instead of f32 planes (DDQN.py:191-200 hands over what it stored; the ring
+stores codes): tron_replay_sample_codes against tron_replay_sample, Net.forward_codes against Net.forward on the planes
+(values and gradients), and a whole Agent.learn() step either way."""
+import copy
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+F = torch.nn.functional
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import config  # noqa: F401
+
+
+def _codes(B, S, seed):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    vals = torch.tensor([1, -1, -2, -3, 10, -10], dtype=torch.int8, device="cuda")
+    return vals[torch.randint(0, 6, (B, S, S), device="cuda", generator=gen)]
+
+
+@pytest.mark.parametrize("S,batch", [(12, 64), (12, 4096), (26, 257), (11, 33)])
+def test_sample_codes_is_sample_without_the_expansion(S, batch):
+    """Two rings with the same seed and contents draw the same slots; the codes rows are the planes rows' preimage."""
+    import tron.vec as tv
+    n = 5000
+    rings = [tv.DeviceReplay(6000, S * S, seed=9, rank=1) for _ in range(2)]
+    s, s2 = _codes(n, S, 1), _codes(n, S, 2)
+    a = (torch.arange(n, device="cuda") % 4).to(torch.int8)
+    r = torch.arange(n, device="cuda", dtype=torch.float32)
+    d = (torch.arange(n, device="cuda") % 7 == 0).to(torch.int8)
+    for rb in rings:
+        rb.add(s, a, r, s2, d)
+    for _ in range(2):
+        ps, pa, pr, ps2, pd = rings[0].sample(batch, channels=3, side=S)
+        cs, ca, cr, cs2, cd = rings[1].sample_codes(batch, side=S)
+        assert torch.equal(rings[0].last_indices(batch), rings[1].last_indices(batch))
+        assert cs.dtype == torch.int8 and cs.shape == (batch, S, S)
+        assert torch.equal(tv.pop_up_planes(cs), ps) and torch.equal(tv.pop_up_planes(cs2), ps2)
+        assert torch.equal(ca, pa) and torch.equal(cr, pr) and torch.equal(cd, pd)
+        idx = rings[1].last_indices(batch)
+        assert torch.equal(cs, s[idx]) and torch.equal(cs2, s2[idx])
+    from tron import _native as nat
+    with pytest.raises(nat.TronNativeError):
+        rings[1].sample_codes(6001, side=S)
+
+
+@pytest.mark.parametrize("W,cin,B", [(10, 3, 50), (10, 4, 129), (24, 3, 9)])
+def test_forward_codes_equals_forward_on_planes(W, cin, B):
+    """Same values (same kernel, two ways of staging conv1's input) and the same gradients for every parameter."""
+    from Net.DQNNet import Net
+    from tron.vec import pop_up_planes
+    torch.manual_seed(W + cin)
+    S = W + 2
+    net = Net(cin, W).cuda()
+    net.dropout.p = 0.0
+    codes = _codes(B, S, B)
+    planes = pop_up_planes(codes)
+    if cin == 4:
+        planes = torch.cat([planes, torch.full_like(planes[:, :1], 5.0)], 1)
+    q_c = net.forward_codes(codes, 5.0)
+    q_c.square().mean().backward()
+    g_c = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    q_p = net(planes)
+    q_p.square().mean().backward()
+    assert torch.equal(q_c, q_p)
+    for a, p in zip(g_c, net.parameters()):
+        assert (a - p.grad).abs().max().item() <= 1e-6 * max(1.0, p.grad.abs().max().item())
+
+
+def test_learn_on_codes_equals_learn_on_planes():
+    """Agent.learn (DDQN.py:115-151) with the batch as codes — conv1 from the codes, both target forwards on the
+    weight-stationary chain — against the same step fed with f32 planes: loss within 1e-5, updated weights within 1e-6."""
+    import DDQN
+    from tron.vec import pop_up_planes
+    torch.manual_seed(3)
+    B, W = 512, 10
+    base = DDQN.Agent(W, 3, device="cuda", make_memory=False)
+    base.qnetwork_local.dropout.p = 0.0
+    agents = [base, copy.deepcopy(base)]
+    agents[1].optimizer = torch.optim.Adam(agents[1].qnetwork_local.parameters())
+    s, s2 = _codes(B, W + 2, 1), _codes(B, W + 2, 2)
+    a = torch.randint(0, 4, (B, 1), device="cuda")
+    r = torch.randn(B, 1, device="cuda")
+    d = (torch.rand(B, 1, device="cuda") < 0.3).float()
+    loss_c = agents[0].learn((s, a, r, s2, d), DDQN.GAMMA)
+    loss_p = agents[1].learn((pop_up_planes(s), a, r, pop_up_planes(s2), d), DDQN.GAMMA)
+    assert abs(float(loss_c) - float(loss_p)) < 1e-5 * max(1.0, abs(float(loss_p)))
+    for pc, pp in zip(agents[0].qnetwork_local.parameters(), agents[1].qnetwork_local.parameters()):
+        assert (pc - pp).abs().max().item() < 2e-6
