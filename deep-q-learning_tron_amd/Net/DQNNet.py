@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 from config import MAP_WIDTH
 from Net.activations import (mish as _mish, conv_bias_mish as _conv_bias_mish, pool_conv7_mish as _pool_conv7_mish,
-                             pool_conv7_supported as _pool_conv7_supported)
+                             pool_conv7_supported as _pool_conv7_supported, pool_s2 as _pool_s2)
 
 
 def _pool_is_reference(pool):
@@ -90,7 +90,7 @@ class Net(nn.Module):
         if _pool_conv7_supported(self.pool, self.conv7, x):
             x = _pool_conv7_mish(self.pool, self.conv7, x)              # the two layers as GEMMs on conv7's dense form
         else:
-            x = self.pool(x)
+            x = _pool_s2(self.pool, x)                                   # (24x24 boards: the row kernels, both directions)
             x = _conv_bias_mish(self.conv7, x)
             x = x.reshape(-1, self.flat)
         x = self.dropout(self.activation(self.fc1(x)))

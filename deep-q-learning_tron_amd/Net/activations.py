@@ -218,6 +218,47 @@ class _PoolConv7(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _PoolS2(torch.autograd.Function):
+    """AvgPool2d(3, stride 2, padding 1) (DQNNet.py:20,52) of even-sided planes, both directions on csrc/tron_head.hip's
+    row kernels: torch's avg_pool2d backward takes 1.5 ms for 4 096 x 64 planes of 26x26 (one thread per INPUT element
+    looping over windows); this is one thread per input row."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from tron import _native as nat
+        x = x.contiguous()
+        N, C, S, _ = x.shape
+        y = torch.empty(N, C, S // 2, S // 2, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            nat.check(nat.lib().tron_pool_s2(nat.ptr(x), nat.ptr(y), N * C, S, nat.stream_ptr()), "tron_pool_s2")
+        ctx.shape = (N, C, S)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        from tron import _native as nat
+        N, C, S = ctx.shape
+        g = grad_y.contiguous()
+        if not _aligned16(g):
+            g = g.clone(memory_format=torch.contiguous_format)
+        gx = torch.empty(N, C, S, S, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            nat.check(nat.lib().tron_pool_s2_bwd(nat.ptr(g), nat.ptr(gx), N * C, S, nat.stream_ptr()), "tron_pool_s2_bwd")
+        return gx
+
+
+def pool_s2_supported(pool, x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] == x.shape[-2] and x.shape[-1] in (12, 26, 34)
+            and x.numel() > 0 and _aligned16(x) and isinstance(pool, torch.nn.AvgPool2d) and pool.kernel_size == 3
+            and pool.stride == 2 and pool.padding == 1 and pool.count_include_pad and not pool.ceil_mode
+            and pool.divisor_override is None)
+
+
+def pool_s2(pool, x):
+    """pool(x) with autograd, on the row kernels where they cover the shape."""
+    return _PoolS2.apply(x) if pool_s2_supported(pool, x) else pool(x)
+
+
 def pool_conv7_supported(pool, conv, x):
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] == 12 and x.shape[-2] == 12 and x.shape[0] > 0
             and _aligned16(x) and isinstance(pool, torch.nn.AvgPool2d) and pool.kernel_size == 3 and pool.stride == 2

@@ -198,6 +198,27 @@ __global__ __launch_bounds__(256) void k_pool12_bwd(const float *__restrict__ gy
     }
 }
 
+// the same backward for the other even sides (26: 24x24 boards, 34: 32x32): one thread = one input row, 8-byte stores
+template <int S>
+__global__ __launch_bounds__(256) void k_pool_rows_bwd(const float *__restrict__ gy, int64_t rows, float *__restrict__ gx)
+{
+    constexpr int PS = S / 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += stride) {
+        const int y = (int)(i % S);
+        const float *g = gy + (i / S) * (PS * PS);
+        const int p0 = y >> 1, p1 = (y & 1) ? p0 + 1 : -1;              // even y: window row y/2 only; odd y: (y-1)/2 and (y+1)/2
+        float r[PS + 1];
+#pragma unroll
+        for (int k = 0; k < PS; ++k) r[k] = g[p0 * PS + k] + ((p1 >= 0 && p1 < PS) ? g[p1 * PS + k] : 0.0f);
+        r[PS] = 0.0f;
+        float *d = gx + i * S;
+#pragma unroll
+        for (int q = 0; q < S / 2; ++q)                                  // x = 2q: column q; x = 2q + 1: columns q and q + 1
+            *reinterpret_cast<float2 *>(d + 2 * q) = make_float2(r[q] * (1.0f / 9.0f), (r[q] + r[q + 1]) * (1.0f / 9.0f));
+    }
+}
+
 // conv7 weight [Co][Ci][7][7] -> dense [Co*9][Ci*36] f32 (fold = 0), or the dense matrix's gradient -> the weight's:
 // dW[co][ci][ky][kx] = sum over the <= 9 outputs (oy, ox) whose tap (ky, kx) lands inside the 6x6 plane (fold = 1)
 __global__ void k_dense7(const float *__restrict__ src, float *__restrict__ dst, int Co, int Ci, int fold)
@@ -724,11 +745,27 @@ extern "C" int tron_pool_s2(const float *x, float *y, int64_t planes, int32_t si
     if (planes == 0) return TRON_OK;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) return TRON_ERR_BAD_ARG;
     if (side == 12) return tron_pool12(x, y, planes, 0, stream);
-    if (side != 26) return TRON_ERR_UNSUPPORTED;
+    if (side != 26 && side != 34) return TRON_ERR_UNSUPPORTED;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t rows = planes * (side / 2);
     const unsigned blocks = (unsigned)((rows + 255) / 256 < (1 << 20) ? (rows + 255) / 256 : (1 << 20));
-    hipLaunchKernelGGL(k_pool_rows<26>, dim3(blocks), dim3(256), 0, st, x, rows, y);
+    if (side == 26) hipLaunchKernelGGL(k_pool_rows<26>, dim3(blocks), dim3(256), 0, st, x, rows, y);
+    else hipLaunchKernelGGL(k_pool_rows<34>, dim3(blocks), dim3(256), 0, st, x, rows, y);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int tron_pool_s2_bwd(const float *grad_y, float *grad_x, int64_t planes, int32_t side, void *stream)
+{
+    if (!grad_y || !grad_x || planes < 0) return TRON_ERR_BAD_ARG;
+    if (planes == 0) return TRON_OK;
+    if ((reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(grad_x)) & 15u) return TRON_ERR_BAD_ARG;
+    if (side == 12) return tron_pool12(grad_y, grad_x, planes, 1, stream);
+    if (side != 26 && side != 34) return TRON_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t rows = planes * side;
+    const unsigned blocks = (unsigned)((rows + 255) / 256 < (1 << 20) ? (rows + 255) / 256 : (1 << 20));
+    if (side == 26) hipLaunchKernelGGL(k_pool_rows_bwd<26>, dim3(blocks), dim3(256), 0, st, grad_y, rows, grad_x);
+    else hipLaunchKernelGGL(k_pool_rows_bwd<34>, dim3(blocks), dim3(256), 0, st, grad_y, rows, grad_x);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 

@@ -80,6 +80,7 @@ SIGNATURES = {
     "tron_dqn_head_workspace": (C.c_int64, [_i64, _i32]),
     "tron_pool12": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "tron_pool_s2": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "tron_pool_s2_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "tron_conv7_dense": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
 }
 

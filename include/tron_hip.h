@@ -382,8 +382,11 @@ int tron_dqn_head_fwd_px16(const void *trunk_px16, int64_t batch, int32_t side, 
  * convolution (DQNNet.py:22,53); fold 1: that matrix's gradient -> the weight's gradient.                          */
 int tron_pool12(const float *x, float *y, int64_t planes, int32_t backward, void *stream);
 /* The forward pooling alone at both supported board sizes, side 12 or 26 -> side/2 (for a caller that keeps conv7 on a
- * library: Net.infer in exact-f32 mode); other sides TRON_ERR_UNSUPPORTED.                                           */
+ * library: Net.infer in exact-f32 mode), also 34 -> 17 (32x32 boards); other sides TRON_ERR_UNSUPPORTED.              */
 int tron_pool_s2(const float *x, float *y, int64_t planes, int32_t side, void *stream);
+/* ... and its gradient: grad_x f32[planes][side][side] from grad_y f32[planes][side/2][side/2] (what autograd needs of
+ * DQNNet.py:52 / ACNet.py's pooling on the training path).  side 12, 26 or 34 (tron_pool_s2 likewise).                */
+int tron_pool_s2_bwd(const float *grad_y, float *grad_x, int64_t planes, int32_t side, void *stream);
 int tron_conv7_dense(const float *src, float *dst, int32_t cout, int32_t cin, int32_t fold, void *stream);
 
 /* Wait for `stream` and report what the kernels queued on it did: launch_status-style calls above only

@@ -418,3 +418,21 @@ def test_net_act_in_eval_mode_uses_infer_and_agrees_with_the_module(fused):
     top = q.topk(2, dim=1).values
     clear = (top[:, 0] - top[:, 1]) > 1e-4                   # (the two paths agree to ~1e-6: near-ties may break either way)
     assert a.dtype == torch.int64 and clear.sum() > 250 and torch.equal(a[clear], q.argmax(1)[clear])
+
+
+@pytest.mark.parametrize("S,B", [(26, 3), (26, 130), (34, 7), (12, 5)])
+def test_pool_s2_backward_matches_autograd(fused, S, B):
+    """Net/activations.py::_PoolS2 (tron_pool_s2 / tron_pool_s2_bwd: DQNNet.py:20,52 on the training path at 24x24 and
+    32x32 boards) against autograd through float64 avg_pool2d."""
+    from Net.activations import pool_s2, pool_s2_supported
+    torch.manual_seed(S * B)
+    pool = torch.nn.AvgPool2d(kernel_size=3, padding=1, stride=2)
+    x = torch.randn(B, 64, S, S, device="cuda", requires_grad=True)
+    assert pool_s2_supported(pool, x)
+    y = pool_s2(pool, x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xd = x.detach().double().requires_grad_(True)
+    ref = F.avg_pool2d(xd, 3, stride=2, padding=1)
+    ref.backward(g.double())
+    assert (y.double() - ref).abs().max().item() < 1e-6 and (x.grad.double() - xd.grad).abs().max().item() < 1e-6
