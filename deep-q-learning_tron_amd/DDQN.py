@@ -67,6 +67,7 @@ class ReplayBuffer:
                         torch.tensor([int(bool(done))], dtype=torch.int8, device=dev))
 
     def add_batch(self, codes, actions, rewards, next_codes, dones):
+        """codes None: the state rows were written ahead with self.memory.add_states()."""
         self.memory.add(codes, actions, rewards, next_codes, dones)
 
     def sample(self):                              # DDQN.py:191-200
@@ -81,22 +82,42 @@ class ReplayBuffer:
         return len(self.memory)
 
 
-def average_gradients(model, group=None):
-    """One flattened RCCL all-reduce of the whole gradient per learn step (2.0 MB at 12x12:
-    latency-bound on xGMI, so a single bucket).  No-op without torch.distributed."""
+def _world(group=None):
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def all_reduce_mean_(flat, group=None):
+    """flat <- mean over the ranks of flat, in place: ONE collective for the whole gradient (2.0 MB at 12x12, 4.6 MB at
+    26x26: latency-bound on xGMI, so a single bucket).  RCCL for device tensors; the gloo rehearsal backend (several ranks
+    sharing one GPU) reduces through host memory.  No-op without torch.distributed."""
+    import torch.distributed as dist
+    world = _world(group)
+    if world == 1:
         return
-    grads = [p.grad for p in model.parameters() if p.grad is not None]
-    flat = torch.cat([g.reshape(-1) for g in grads])
     if dist.get_backend(group) == "gloo" and flat.is_cuda:
-        # the CPU rehearsal backend (several ranks sharing one GPU): reduce through host memory
         host = flat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
         flat.copy_(host)
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat /= dist.get_world_size(group)
+    flat /= world
+
+
+def average_gradients(model, group=None):
+    """The model's gradients averaged over the ranks.  When every .grad is a view of one flat buffer (Agent.flat_grads:
+    what the trainer sets up) that buffer is reduced as it is — no cat, no copy back; otherwise the gradients are
+    gathered into a temporary and scattered back."""
+    if _world(group) == 1:
+        return
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    flat = getattr(model, "_tron_flat_grads", None)
+    if flat is not None and sum(g.numel() for g in grads) == flat.numel() and all(
+            g.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for g in grads):
+        all_reduce_mean_(flat, group)
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    all_reduce_mean_(flat, group)
     off = 0
     for g in grads:
         n = g.numel()
@@ -163,9 +184,43 @@ class Agent():
         labels_next = self.qnetwork_target.infer(next_state, codes=codes, plane4=plane4).gather(1, actions_q_local)
         return rewards + (gamma * labels_next * (1 - dones))
 
-    def learn(self, experiences, gamma):           # DDQN.py:115-151
+    def flat_grads(self):
+        """One flat f32 buffer with every parameter's .grad a view into it (allocated once): the gradient all-reduce
+        is then a single collective on memory that is already contiguous, and zeroing the gradients is one fill."""
+        net = self.qnetwork_local
+        flat = getattr(net, "_tron_flat_grads", None)
+        params = list(net.parameters())
+        if flat is None or flat.numel() != sum(p.numel() for p in params) or flat.device != params[0].device:
+            flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=params[0].device)
+            net._tron_flat_grads = flat
+        off = 0
+        for p in params:
+            n = p.numel()
+            if p.grad is None or p.grad.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr():
+                p.grad = flat[off:off + n].view_as(p)
+            off += n
+        return flat
+
+    def finish_learn(self):
+        """The second half of a learn(..., defer=True): wait for the gradient all-reduce that went out on the side
+        stream, then optimizer step and soft update.  No-op when nothing is pending."""
+        if not getattr(self, "_pending", False):
+            return
+        torch.cuda.current_stream(self.device).wait_stream(self._side)
+        self.optimizer.step()
+        self.soft_update(self.qnetwork_local, self.qnetwork_target, TAU)
+        self._pending = False
+
+    def learn(self, experiences, gamma, defer=False):           # DDQN.py:115-151
         """experiences: ReplayBuffer.sample() (f32 planes, as the reference hands them over) or .sample_codes() (int8
-        codes: conv1 reads them directly, forward and target forwards alike)."""
+        codes: conv1 reads them directly, forward and target forwards alike).
+
+        One rank per GPU (torch.distributed initialised): the flat gradient is all-reduced on a side stream.  With
+        defer=True the call returns once that collective is queued and `finish_learn()` applies the update — the
+        trainer calls it after it has queued the next policy forward, so the collective's latency (xGMI ring: tens of
+        microseconds for 2-5 MB) hides under that forward; the policy then acts on weights one learn step old, on every
+        rank alike.  Single process, or defer=False: the reference's order, update applied before returning."""
+        self.finish_learn()
         states, actions, rewards, next_state, dones = experiences
         criterion = torch.nn.MSELoss()
         self.qnetwork_local.train()
@@ -178,9 +233,26 @@ class Agent():
         labels = self.targets(rewards, next_state, dones, gamma, plane4)
         loss = criterion(predicted_targets, labels)
         self.totalloss += loss.detach()
-        self.optimizer.zero_grad()
+        if self.device.type == "cuda":
+            flat = self.flat_grads()
+            flat.zero_()
+        else:
+            flat = None
+            self.optimizer.zero_grad()
         loss.backward()
-        average_gradients(self.qnetwork_local)     # RCCL over xGMI when run one-rank-per-GPU
+        if flat is not None and _world() > 1:      # RCCL over xGMI when run one-rank-per-GPU
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(self.device)
+            cur = torch.cuda.current_stream(self.device)
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                all_reduce_mean_(flat)
+            self._pending = True
+            if defer:
+                return loss.detach()
+            self.finish_learn()
+            return loss.detach()
+        average_gradients(self.qnetwork_local)
         self.optimizer.step()
         self.soft_update(self.qnetwork_local, self.qnetwork_target, TAU)
         return loss.detach()
@@ -255,7 +327,13 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
     dev = brain.device
     env = VecTron(n_envs, width, mode=None, seed=seed, rank=rank, obs_format="codes", reward="ddqn")
     S = width + 2
-    codes = env.reset().reshape(2 * n_envs, S, S).clone()
+    # mode None + int8 codes: the observation buffer IS the env state and every step overwrites it in place.  The state
+    # part of a transition is therefore written into the ring BEFORE the step (add_states) and the rest after it —
+    # no per-step clone of the 2N observations.
+    codes = env.reset().reshape(2 * n_envs, S, S)
+    in_place = env.obs_is_state
+    if not in_place:
+        codes = codes.clone()
     eps0 = float(EPSILON_START)
     if resume:
         eps0, _ = load_checkpoint(resume, brain)
@@ -275,18 +353,23 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
     t0 = time.perf_counter()
     for it in range(steps):
         actions = brain.act_batch(codes, eps_d.to(torch.float32), codes=True).reshape(n_envs, 2)   # conv1 reads the codes
+        brain.finish_learn()                       # (one rank per GPU: the previous learn step's all-reduce ran under this forward)
+        if in_place:
+            brain.memory.memory.add_states(codes)
         obs, reward, done, _ = env.step(actions, autoreset=not terminal_next_state)
         next_codes = obs.reshape(2 * n_envs, S, S)
-        brain.memory.add_batch(codes, actions.reshape(-1), reward.reshape(-1), next_codes,
+        brain.memory.add_batch(None if in_place else codes, actions.reshape(-1), reward.reshape(-1), next_codes,
                                done.repeat_interleave(2))
         transitions += 2 * n_envs
         if terminal_next_state:
             env.reset(mask=done)                   # finished games restart; obs now holds the new first states
-        codes = env.obs.reshape(2 * n_envs, S, S).clone()
+        codes = env.obs.reshape(2 * n_envs, S, S)
+        if not in_place:
+            codes = codes.clone()
         games_d += done.sum()
         if it % learn_every == learn_every - 1 and len(brain.memory) > batch_size:    # len(): a host counter
             brain.steps += 1
-            brain.learn(brain.memory.sample_codes(), GAMMA)          # the batch as int8 codes: conv1 and the target chain read them
+            brain.learn(brain.memory.sample_codes(), GAMMA, defer=True)   # the batch as int8 codes: conv1 and the target chain read them
             learn_steps += 1
         # DDQN.py:313-315, once per finished 20-game cycle
         new_cycles = torch.div(games_d, GAME_CYCLE, rounding_mode="floor")
@@ -300,6 +383,7 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
                 writer.add_scalar('Training loss', loss, games_seen)
                 writer.add_scalar('Duration', n_envs * (it + 1) / max(games_seen, 1), games_seen)
                 writer.add_scalar('Epsilon', epsilon, games_seen)
+    brain.finish_learn()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     games, epsilon = int(games_d), float(eps_d)

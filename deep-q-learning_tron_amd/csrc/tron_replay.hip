@@ -255,7 +255,7 @@ int tron_replay_push(tron_replay_handle r, int64_t n, const int8_t *state, const
                      const int8_t *next_state, const int8_t *done, void *stream)
 {
     if (bad(r)) return r ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
-    if (n < 0 || n > r->capacity || (n > 0 && (!state || !action || !reward || !next_state || !done)))
+    if (n < 0 || n > r->capacity || (n > 0 && (!action || !reward || !next_state || !done)))   // state NULL: tron_replay_push_states wrote it
         return TRON_ERR_BAD_ARG;
     int64_t row = 0;
     while (row < n) {                                   // at most two segments (ring wrap)
@@ -264,8 +264,9 @@ int tron_replay_push(tron_replay_handle r, int64_t n, const int8_t *state, const
         size_t blocks = (nbytes / 4 + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(k_push_planes, dim3((unsigned)blocks), dim3(256), 0, S_(stream), state + (size_t)row * r->cells,
-                           r->states + (size_t)r->head * r->cells, nbytes);
+        if (state)
+            hipLaunchKernelGGL(k_push_planes, dim3((unsigned)blocks), dim3(256), 0, S_(stream), state + (size_t)row * r->cells,
+                               r->states + (size_t)r->head * r->cells, nbytes);
         hipLaunchKernelGGL(k_push_planes, dim3((unsigned)blocks), dim3(256), 0, S_(stream),
                            next_state + (size_t)row * r->cells, r->next_states + (size_t)r->head * r->cells, nbytes);
         hipLaunchKernelGGL(k_push_scalars, dim3((unsigned)((seg + 255) / 256)), dim3(256), 0, S_(stream), seg,
@@ -275,6 +276,26 @@ int tron_replay_push(tron_replay_handle r, int64_t n, const int8_t *state, const
         row += seg;
         r->head = (r->head + seg) % r->capacity;
         r->size = (r->size + seg < r->capacity) ? r->size + seg : r->capacity;
+    }
+    return TRON_OK;
+}
+
+int tron_replay_push_states(tron_replay_handle r, int64_t n, const int8_t *state, void *stream)
+{
+    if (bad(r)) return r ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
+    if (n < 0 || n > r->capacity || (n > 0 && !state)) return TRON_ERR_BAD_ARG;
+    int64_t row = 0, head = r->head;                     // where the NEXT tron_replay_push will put its rows; not advanced here
+    while (row < n) {
+        const int64_t seg = (n - row < r->capacity - head) ? n - row : r->capacity - head;
+        const size_t nbytes = (size_t)seg * r->cells;
+        size_t blocks = (nbytes / 4 + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_push_planes, dim3((unsigned)blocks), dim3(256), 0, S_(stream), state + (size_t)row * r->cells,
+                           r->states + (size_t)head * r->cells, nbytes);
+        if (launch_status() != TRON_OK) return TRON_ERR_LAUNCH;
+        row += seg;
+        head = (head + seg) % r->capacity;
     }
     return TRON_OK;
 }

@@ -58,6 +58,7 @@ SIGNATURES = {
     "tron_replay_create": (C.c_int, [_i64, _i32, _u32, _u32, C.POINTER(_vp)]),
     "tron_replay_destroy": (C.c_int, [_vp]),
     "tron_replay_push": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tron_replay_push_states": (C.c_int, [_vp, _i64, _vp, _vp]),
     "tron_replay_sample": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tron_replay_sample_codes": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tron_replay_size": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -309,21 +309,31 @@ class DeviceReplay:
     def add(self, state, action, reward, next_state, done):
         """Batched ReplayBuffer.add: state/next_state int8 [n, cells...] codes, action int8 [n],
         reward f32 [n], done int8 [n]."""
-        n = state.shape[0]
+        n = next_state.shape[0]
         # every converted tensor stays bound to a local until the call returns: a temporary freed
         # right after nat.ptr() could be handed to the next conversion by the caching allocator
         # before the push kernel has read it
-        s = state.reshape(n, -1).to(torch.int8).contiguous()
         s2 = next_state.reshape(n, -1).to(torch.int8).contiguous()
+        s = s2 if state is None else state.reshape(n, -1).to(torch.int8).contiguous()     # None: add_states() wrote them
         a = action.reshape(n).to(torch.int8).contiguous()
         r = reward.reshape(n).to(torch.float32).contiguous()
         d = done.reshape(n).to(torch.int8).contiguous()
         if s.shape[1] != self.cells or s2.shape[1] != self.cells:
             raise ValueError(f"states must have {self.cells} cells per row, got {s.shape[1]} / {s2.shape[1]}")
         with torch.cuda.device(self.device):
-            nat.check(self._lib.tron_replay_push(self._h, n, nat.ptr(s), nat.ptr(a), nat.ptr(r), nat.ptr(s2),
-                                                 nat.ptr(d), nat.stream_ptr()), "tron_replay_push")
+            nat.check(self._lib.tron_replay_push(self._h, n, None if state is None else nat.ptr(s), nat.ptr(a), nat.ptr(r),
+                                                 nat.ptr(s2), nat.ptr(d), nat.stream_ptr()), "tron_replay_push")
         del s, s2, a, r, d
+
+    def add_states(self, state):
+        """The `state` rows of the next add(), written ahead of it (tron_replay_push_states): call before the env step
+        overwrites an observation buffer that is the env state, then add(None, action, reward, next_state, done)."""
+        n = state.shape[0]
+        s = state.reshape(n, -1)
+        if s.dtype != torch.int8 or not s.is_contiguous() or s.shape[1] != self.cells:
+            raise ValueError(f"add_states takes contiguous int8 rows of {self.cells} cells")
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.tron_replay_push_states(self._h, n, nat.ptr(s), nat.stream_ptr()), "tron_replay_push_states")
 
     def sample(self, batch, channels=3, plane4=0.0, side=None):
         """ReplayBuffer.sample(): (states, actions, rewards, next_states, dones) on the device,

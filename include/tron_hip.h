@@ -199,6 +199,10 @@ int tron_replay_destroy(tron_replay_handle r);
 int tron_replay_push(tron_replay_handle r, int64_t n, const int8_t *state, const int8_t *action,
                      const float *reward, const int8_t *next_state, const int8_t *done,
                      void *stream);
+/* The `state` rows of the NEXT tron_replay_push, written ahead of it (same ring position, nothing advanced): a trainer
+ * whose observation buffer IS the env state (tron_attach_obs_state) saves s here before the step overwrites it and
+ * then calls tron_replay_push(..., state = NULL, ...) with a, r, s', done — no clone of the observations.          */
+int tron_replay_push_states(tron_replay_handle r, int64_t n, const int8_t *state, void *stream);
 /* Uniform sample of `batch` DISTINCT slots (random.sample, DDQN.py:191-200) at any
  * batch <= size: slot j = pi(j) for a Philox-keyed permutation pi of the filled slots,
  * a fresh one per call.  Written as pop_up planes: states/next_states f32[batch][channels][cells]

@@ -94,3 +94,50 @@ def test_learn_on_codes_equals_learn_on_planes():
     assert abs(float(loss_c) - float(loss_p)) < 1e-5 * max(1.0, abs(float(loss_p)))
     for pc, pp in zip(agents[0].qnetwork_local.parameters(), agents[1].qnetwork_local.parameters()):
         assert (pc - pp).abs().max().item() < 2e-6
+
+
+def test_split_push_equals_push():
+    """add_states() + add(None, ...) (tron_replay_push_states: the state rows written ahead of the step that overwrites the
+    observation buffer) fills the ring exactly like add(state, ...), also across the ring's wrap."""
+    import tron.vec as tv
+    S, cap, n = 12, 1000, 384
+    rings = [tv.DeviceReplay(cap, S * S, seed=4) for _ in range(2)]
+    for k in range(4):                                                   # 1 536 rows through 1 000 slots: wraps
+        s, s2 = _codes(n, S, 10 + k), _codes(n, S, 20 + k)
+        a = ((torch.arange(n, device="cuda") + k) % 4).to(torch.int8)
+        r = torch.arange(n, device="cuda", dtype=torch.float32) + 1000 * k
+        d = ((torch.arange(n, device="cuda") + k) % 5 == 0).to(torch.int8)
+        rings[0].add(s, a, r, s2, d)
+        rings[1].add_states(s)
+        rings[1].add(None, a, r, s2, d)
+        assert len(rings[0]) == len(rings[1])
+    for _ in range(2):
+        x = rings[0].sample_codes(777, side=S)
+        y = rings[1].sample_codes(777, side=S)
+        assert all(torch.equal(p, q) for p, q in zip(x, y))
+
+
+def test_flat_gradient_buffer_and_deferred_update():
+    """Agent.flat_grads: every .grad is a view of one buffer and stays one across learn steps; learn(defer=True) +
+    finish_learn() in a single process is the plain learn()."""
+    import DDQN
+    torch.manual_seed(5)
+    B, W = 256, 10
+    a1 = DDQN.Agent(W, 3, device="cuda", make_memory=False)
+    a1.qnetwork_local.dropout.p = 0.0
+    a2 = copy.deepcopy(a1)
+    a2.optimizer = torch.optim.Adam(a2.qnetwork_local.parameters())
+    for step in range(3):
+        s, s2 = _codes(B, W + 2, step), _codes(B, W + 2, 50 + step)
+        act = torch.randint(0, 4, (B, 1), device="cuda")
+        r = torch.randn(B, 1, device="cuda")
+        d = (torch.rand(B, 1, device="cuda") < 0.3).float()
+        l1 = a1.learn((s, act, r, s2, d), DDQN.GAMMA)
+        l2 = a2.learn((s, act, r, s2, d), DDQN.GAMMA, defer=True)
+        a2.finish_learn()
+        assert torch.equal(l1, l2)
+        flat = a1.qnetwork_local._tron_flat_grads
+        assert all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in a1.qnetwork_local.parameters())
+        assert torch.equal(torch.cat([p.grad.reshape(-1) for p in a1.qnetwork_local.parameters()]), flat)
+    for p, q in zip(a1.qnetwork_local.parameters(), a2.qnetwork_local.parameters()):
+        assert torch.equal(p, q)
