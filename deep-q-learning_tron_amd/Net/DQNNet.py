@@ -141,6 +141,12 @@ class Net(nn.Module):
         inside the head kernel where that runs."""
         from Net import fused
         side = x.shape[-1]
+        # what the kernels assume about the input is checked here: they are handed raw pointers
+        if codes:
+            if x.dtype != torch.int8 or x.dim() < 2 or x.shape[-2] != side:
+                raise TypeError(f"infer(codes=True) takes int8 observation codes [..., S, S], got {tuple(x.shape)} {x.dtype}")
+        elif x.dim() != 4 or x.shape[-2] != side or x.shape[1] != self.conv1.in_channels:
+            raise TypeError(f"infer takes planes [B, {self.conv1.in_channels}, S, S], got {tuple(x.shape)}")
         with torch.no_grad():
             if not (x.is_cuda and fused.supported(self.conv1, side) and fused.supported(self.conv6, side)
                     and (codes or x.dtype == torch.float32)):

@@ -81,7 +81,11 @@ class _ConvBiasMishHIP(torch.autograd.Function):
         gp, gb, absmax = bias_mish_bwd(pre, g, want_absmax=True)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = fused.conv3x3_dgrad(gp, weight.detach(), absmax)
+            if weight.shape[1] in (32, 64):
+                gx = fused.conv3x3_dgrad(gp, weight.detach(), absmax)
+            else:                                 # conv1's planes asked for their gradient (saliency, a layer in front): the library
+                gx = torch.ops.aten.convolution_backward(gp, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
         gw = None
         if ctx.needs_input_grad[1]:
             if fused.wgrad_supported(weight, x.shape[-1]):

@@ -77,11 +77,11 @@ def conv3x3_raw(x, weight, bias=None, residual=None, act=True, codes=False, plan
         B, S = x.shape[0], x.shape[-1]
         xin, dev = x.contiguous(), x.device
         if codes:
-            if xin.dtype != torch.int8:
-                raise TypeError("codes=True takes the env's int8 observation codes")
+            if xin.dtype != torch.int8 or xin.dim() != 3 or xin.shape[-2] != S:
+                raise TypeError(f"codes=True takes the env's int8 observation codes [B, S, S], got {tuple(xin.shape)} {xin.dtype}")
             in_fmt = nat.CONV_IN_CODES
         else:
-            if xin.dtype != torch.float32 or xin.shape[1] != cin:
+            if xin.dtype != torch.float32 or xin.dim() != 4 or xin.shape[1] != cin or xin.shape[-2] != S:
                 raise TypeError(f"expected f32 [B, {cin}, S, S], got {tuple(xin.shape)} {xin.dtype}")
             in_fmt = nat.CONV_IN_F32
     out = torch.empty(B, cout, S, S, dtype=torch.float32, device=dev) if want_f32 else None

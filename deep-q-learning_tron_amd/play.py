@@ -86,8 +86,14 @@ def load_player(path=None, arch="dqn", width=None, device=None):
     else:
         net = {"map": A.MapNet, "test": A.TestNet, "net3": A.Net3, "net4": A.Net4, "mul": A.Mulnet}[arch](width)
     if sd is not None:
-        if any(k.endswith(".add_bias._bias") for k in sd):
-            split_biases(net)                                              # the checkpoint was saved under K-FAC
+        if any(k.endswith(".add_bias._bias") for k in sd):                 # the checkpoint was saved under K-FAC
+            if arch == "dqn":
+                # DQNNet.Net runs its layers through the HIP operators, which read conv.weight / conv.bias: fold the split
+                # keys back (`x.module.weight` -> `x.weight`, `x.add_bias._bias` [C, 1] -> `x.bias` [C]) instead of wrapping
+                sd = {k.replace(".module.", ".").replace(".add_bias._bias", ".bias"):
+                      (v.reshape(-1) if k.endswith(".add_bias._bias") else v) for k, v in sd.items()}
+            else:
+                split_biases(net)
         net.load_state_dict(sd)
     return net.to(device).eval()
 

@@ -140,7 +140,9 @@ int tron_step_encode(tron_handle h, const int8_t *actions, const float *uniforms
  * (tron_part_range gives the env range).  All buffers stay full-size and are indexed by the global env
  * number, so a caller can run slices as independent pipelines on different streams: while slice A is in the
  * env kernel, the policy network evaluates slice B's observations (envs never interact: ACKTR.py:183,285-289).
- * Not with TRON_STEP_INCREMENTAL, nor with f32 planes on an attached observation buffer.                    */
+ * Not with TRON_STEP_INCREMENTAL, nor with f32 planes on an attached observation buffer.                    
+ * A handle (and the library's per-device launch caches) is for ONE host thread at a time: the slice is passed through
+ * the handle, so two threads stepping two slices of one handle race; run the slices from one thread on two streams. */
 int tron_step_encode_part(tron_handle h, int32_t part, int32_t nparts, const int8_t *actions,
                           const float *uniforms, uint32_t flags, int32_t obs_fmt, void *obs, int8_t *out_done,
                           int8_t *out_winner, float *out_reward, void *stream);

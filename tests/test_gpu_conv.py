@@ -436,3 +436,20 @@ def test_pool_s2_backward_matches_autograd(fused, S, B):
     ref = F.avg_pool2d(xd, 3, stride=2, padding=1)
     ref.backward(g.double())
     assert (y.double() - ref).abs().max().item() < 1e-6 and (x.grad.double() - xd.grad).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("cin", [3, 4])
+def test_conv1_input_gradient_falls_back_to_the_library(fused, cin):
+    """conv1's planes asked for their gradient: tron_conv3x3_dgrad has no cin 3 / 4 instantiation, so
+    _ConvBiasMishHIP hands that one gradient to aten.convolution_backward instead of raising."""
+    from Net.activations import conv_bias_mish
+    torch.manual_seed(cin)
+    conv = torch.nn.Conv2d(cin, 32, 3, padding=1).cuda()
+    x = torch.randn(9, cin, 12, 12, device="cuda", requires_grad=True)
+    out = conv_bias_mish(conv, x)
+    assert type(out.grad_fn).__name__ == "_ConvBiasMishHIPBackward"
+    g = torch.randn_like(out)
+    out.backward(g)
+    xd = x.detach().double().requires_grad_(True)
+    F.mish(F.conv2d(xd, conv.weight.double(), conv.bias.double(), padding=1)).backward(g.double())
+    assert (x.grad.double() - xd.grad).abs().max().item() < 2e-5 * max(1.0, xd.grad.abs().max().item())

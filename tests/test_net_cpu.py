@@ -253,3 +253,40 @@ def test_play_loads_plain_and_kfac_checkpoints(tmp_path, arch):
     b = play.load_player(kfac, arch, device="cpu")
     assert torch.allclose(run(b), want, rtol=0, atol=1e-6)
     assert not b.training
+
+
+def test_infer_rejects_misshapen_inputs():
+    """The HIP kernels are handed raw pointers: Net.infer checks squareness / channel count / dtype first."""
+    import pytest
+    import torch
+    from Net.DQNNet import Net
+    net = Net(3, 10)
+    with pytest.raises(TypeError):
+        net.infer(torch.zeros(2, 3, 10, 12))
+    with pytest.raises(TypeError):
+        net.infer(torch.zeros(2, 4, 12, 12))
+    with pytest.raises(TypeError):
+        net.infer(torch.zeros(2, 12, 12), codes=True)                     # float codes
+    with pytest.raises(TypeError):
+        net.infer(torch.zeros(2, 10, 12, dtype=torch.int8), codes=True)
+    assert net.infer(torch.zeros(2, 3, 12, 12)).shape == (2, 4)           # CPU tensors: the module's own forward
+
+
+def test_load_player_dqn_from_kfac_layout_runs(tmp_path):
+    """A DQN state_dict saved in the K-FAC key layout (conv1.module.weight / conv1.add_bias._bias) loads into a net that
+    runs (the bias-split wrapper has no .weight for the HIP operators)."""
+    import torch
+    import play
+    from Net.DQNNet import Net
+    net = Net(3, 10)
+    sd = {}
+    for k, v in net.state_dict().items():
+        if k.endswith(".weight"):
+            sd[k.replace(".weight", ".module.weight")] = v
+        else:
+            sd[k.replace(".bias", ".add_bias._bias")] = v.reshape(-1, 1)
+    path = tmp_path / "dqn_kfac.bak"
+    torch.save(sd, path)
+    got = play.load_player(str(path), "dqn", 10, device="cpu")
+    x = torch.randn(3, 3, 12, 12)
+    assert torch.allclose(got(x), net.eval()(x))
