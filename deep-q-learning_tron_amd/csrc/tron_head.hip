@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void k_pool_split12(const float *__restrict__ 
 }
 
 // conv7 (Co x Ci x 7 x 7, stride 2, pad 3) on PS x PS planes as a dense [Co*OS*OS][Ci*PS*PS] matrix, split
-__global__ void k_dense7_split(const float *__restrict__ w, int Co, int Ci, int PS, int OS, f16 *__restrict__ oh,
+// (octets: the columns are ordered (channel octet, pixel, channel within the octet) — the order in which the PX16
+// pooling writes a row, 16 bytes per (octet, pixel) — instead of NCHW-flatten (channel, pixel))
+__global__ void k_dense7_split(const float *__restrict__ w, int Co, int Ci, int PS, int OS, int octets, f16 *__restrict__ oh,
                                f16 *__restrict__ ol)
 {
     const int K = Ci * PS * PS, N = Co * OS * OS;
@@ -93,7 +95,9 @@ __global__ void k_dense7_split(const float *__restrict__ w, int Co, int Ci, int 
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int n = i / K, k = i - n * K;
         const int co = n / (OS * OS), op = n - co * (OS * OS), oy = op / OS, ox = op - oy * OS;
-        const int ci = k / (PS * PS), ip = k - ci * (PS * PS), iy = ip / PS, ix = ip - iy * PS;
+        const int ci = octets ? (k / (PS * PS * 8)) * 8 + (k & 7) : k / (PS * PS);
+        const int ip = octets ? (k % (PS * PS * 8)) >> 3 : k - ci * (PS * PS);
+        const int iy = ip / PS, ix = ip - iy * PS;
         const int ky = iy - 2 * oy + 3, kx = ix - 2 * ox + 3;
         const float v = (ky >= 0 && ky < 7 && kx >= 0 && kx < 7) ? w[((size_t)(co * Ci + ci) * 7 + ky) * 7 + kx] : 0.0f;
         f16 h, l;
@@ -332,32 +336,28 @@ __device__ __forceinline__ void px16_window_sum(const unsigned char *img, int S,
     }
 }
 
-// 12x12: rows [B][64 * 36] in NCHW-flatten order (what k_pool_split12 writes).  One workgroup walks images; a thread
-// pools one (octet, pooled pixel) — eight channels — into LDS, then the rows go out as contiguous 4-byte stores.
-__global__ __launch_bounds__(320) void k_pool_split12_px(const unsigned char *__restrict__ x, int64_t B, f16 *__restrict__ oh,
+// 12x12: rows [B][64 * 36] with the columns in (octet, pooled pixel, channel) order (k_dense7_split's `octets` order): a
+// thread pools one (octet, pooled pixel) — eight channels — and writes their 16 bytes per half; no LDS, no barrier.
+__global__ __launch_bounds__(256) void k_pool_split12_px(const unsigned char *__restrict__ x, int64_t B, f16 *__restrict__ oh,
                                                          f16 *__restrict__ ol)
 {
     constexpr int S = 12, C = 64, HALF = (C / 8) * S * S * 16;
-    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    __shared__ float pooled[C * 36];
-    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
-        const int t = threadIdx.x;
-        if (t < 8 * 36) {
-            const int oct = t / 36, pp = t - oct * 36;
-            float sum[8];
-            px16_window_sum(x + (size_t)b * 2 * HALF, S, HALF, oct, pp / 6, pp % 6, sum);
+    const int64_t total = B * 288;                                       // (image, octet, pooled pixel)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / 288;
+        const int r = (int)(i - b * 288), oct = r / 36, pp = r - oct * 36;
+        float sum[8];
+        px16_window_sum(x + (size_t)b * 2 * HALF, S, HALF, oct, pp / 6, pp % 6, sum);
+        f16x8h h, l;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pooled[(oct * 8 + j) * 36 + pp] = sum[j] * (1.0f / 9.0f);
+        for (int j = 0; j < 8; ++j) {
+            f16 hh, ll;
+            split(sum[j] * (1.0f / 9.0f), hh, ll);
+            h[j] = hh;
+            l[j] = ll;
         }
-        __syncthreads();
-        for (int i = t; i < C * 36 / 2; i += 320) {
-            f16 h0, l0, h1, l1;
-            split(pooled[2 * i], h0, l0);
-            split(pooled[2 * i + 1], h1, l1);
-            *reinterpret_cast<f16x2 *>(oh + b * (C * 36) + 2 * i) = (f16x2){h0, h1};
-            *reinterpret_cast<f16x2 *>(ol + b * (C * 36) + 2 * i) = (f16x2){l0, l1};
-        }
-        __syncthreads();
+        *reinterpret_cast<f16x8h *>(oh + (size_t)i * 8) = h;
+        *reinterpret_cast<f16x8h *>(ol + (size_t)i * 8) = l;
     }
 }
 
@@ -687,9 +687,9 @@ static int head_fwd(const void *trunk, bool px16, int64_t batch, int32_t side, c
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
     auto H = [&](int64_t off) { return reinterpret_cast<f16 *>(ws + off); };
     const int64_t nrows = batch * C * PS;
-    if (px16) hipLaunchKernelGGL(k_pool_split12_px, dim3((unsigned)(batch < 256 * 8 ? batch : 256 * 8)), dim3(320), 0, st, trunk_px, batch, H(p.a7h), H(p.a7l));
+    if (px16) hipLaunchKernelGGL(k_pool_split12_px, dim3((unsigned)((batch * 288 + 255) / 256 < (1 << 20) ? (batch * 288 + 255) / 256 : (1 << 20))), dim3(256), 0, st, trunk_px, batch, H(p.a7h), H(p.a7l));
     else hipLaunchKernelGGL(k_pool_split12, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, trunk_out, nrows, H(p.a7h), H(p.a7l));
-    hipLaunchKernelGGL(k_dense7_split, dim3((N7 * K7 + 255) / 256), dim3(256), 0, st, conv7_w, C, C, PS, OS, H(p.d7h), H(p.d7l));
+    hipLaunchKernelGGL(k_dense7_split, dim3((N7 * K7 + 255) / 256), dim3(256), 0, st, conv7_w, C, C, PS, OS, px16 ? 1 : 0, H(p.d7h), H(p.d7l));
     hipLaunchKernelGGL(k_split_rows, dim3((256 * N7 + 255) / 256), dim3(256), 0, st, fc1_w, 256 * N7, H(p.w1h), H(p.w1l));
     hipLaunchKernelGGL(k_split_rows, dim3((128 * 256 + 255) / 256), dim3(256), 0, st, fc2_w, 128 * 256, H(p.w2h), H(p.w2l));
     hipLaunchKernelGGL(k_split_rows, dim3((64 * 128 + 255) / 256), dim3(256), 0, st, actor1_w, 64 * 128, H(p.w3h), H(p.w3l));
