@@ -275,6 +275,8 @@ def main():
                          "10x10; use --envs/--width/--batch/--dqn-steps for others)")
     ap.add_argument("--batch", type=int, default=4096, help="DQN record: learn batch")
     ap.add_argument("--dqn-steps", type=int, default=40, help="DQN record: env steps per timed region")
+    ap.add_argument("--acktr", action="store_true", help="print the ACKTR record instead (BASELINE configs[4]: 16 384 envs 32x32)")
+    ap.add_argument("--acktr-iterations", type=int, default=2)
     ap.add_argument("--dqn3-steps", type=int, default=8, help="config-3 DQN record (65 536 envs x 24x24): env steps per timed region")
     ap.add_argument("--dqn-envs", type=int, default=4096)
     ap.add_argument("--dqn-width", type=int, default=10)
@@ -302,6 +304,29 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.acktr:
+        # BASELINE configs[4]: the ACKTR.py path at 32x32 boards, 16 384 envs, K-FAC natural-gradient step on PyTorch-ROCm
+        import ACKTR
+        envs, width = args.envs or 16384, args.width or 32
+        torch.cuda.reset_peak_memory_stats()
+        ACKTR.train(n_envs=envs, width=width, model="mul", reward="3", iterations=1, acktr=True, log_every=0)   # warm-up (MIOpen find)
+        o = ACKTR.train(n_envs=envs, width=width, model="mul", reward="3", iterations=args.acktr_iterations, acktr=True, log_every=0)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "env-steps/sec (ACKTR trainer: 5-step A2C rollouts of both players + two K-FAC updates per iteration)",
+                "value": o["env_steps_per_s"] * world, "unit": "env-steps/s", "n_gpus": world, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "iterations": o["iterations"], "seconds": o["seconds"],
+                "kfac_update_seconds_per_iteration": o["update_seconds"] / o["iterations"],
+                "rollout_seconds_per_iteration": o["rollout_seconds"] / o["iterations"],
+                "samples_per_update": 5 * envs, "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9,
+                "config": {"workload": f"{envs} parallel {width}x{width} self-play envs (temper mode), Mulnet actor-critic, "
+                                       f"ACKTR: Fisher statistics + eigendecompositions every step (kfac.py:202-254), "
+                                       f"micro-batches of 8 192", "parallelism": f"env-shard x{world}"}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     if args.dqn:
         rec = dqn_record(args.envs or args.dqn_envs, args.width or args.dqn_width, args.dqn_steps if args.steps == 320

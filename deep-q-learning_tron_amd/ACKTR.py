@@ -172,6 +172,7 @@ def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterat
     probs = env_vectors()
     games, t0 = 0, time.perf_counter()
     stats = None
+    update_events = []                             # (start, end) of the two Brain.update calls of every iteration
     for it in range(iterations):
         for step in range(num_steps):
             if not is_map:
@@ -201,8 +202,12 @@ def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterat
                                       for i in range(0, n_envs, act_batch)]))
         for p in range(2):
             rollouts[p].compute_returns(nxt[p])
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
         stats = brain.update(rollouts[0], micro_batch)
         brain.update(rollouts[1], micro_batch)
+        ev[1].record()
+        update_events.append(ev)
         for p in range(2):
             rollouts[p].after_update()
         if log_every and it % log_every == log_every - 1:
@@ -213,8 +218,10 @@ def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterat
     if save_path:
         os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
         torch.save(brain.actor_critic.state_dict(), save_path)          # ACKTR.py:399
+    upd = sum(a.elapsed_time(b) for a, b in update_events) / 1e3
     return dict(iterations=iterations, env_steps=iterations * num_steps * n_envs, games=games, seconds=dt,
                 env_steps_per_s=iterations * num_steps * n_envs / dt, updates=2 * iterations, brain=brain,
+                update_seconds=upd, rollout_seconds=dt - upd,
                 last_stats=None if stats is None else [float(s) for s in stats])
 
 

@@ -268,12 +268,16 @@ def conv3x3_dgrad(gp, weight, absmax=None):
 
 
 def wgrad_supported(weight, side):
-    return (side == 12 and weight.shape[0] in (32, 64) and weight.shape[1] in (3, 4, 32, 64) and tuple(weight.shape[2:]) == (3, 3)
-            and weight.is_cuda and weight.dtype == torch.float32)
+    """tron_conv3x3_wgrad's shapes: every layer of the trunk at 12x12; conv2..conv6 at 26x26 (24x24 boards: the
+    row-streaming kernel; conv1's tiny gradient stays on the library there)."""
+    co, ci = weight.shape[0], weight.shape[1]
+    shape_ok = (side == 12 and ci in (3, 4, 32, 64)) or (side == 26 and (ci, co) in ((32, 32), (32, 64), (64, 64)))
+    return (shape_ok and co in (32, 64) and tuple(weight.shape[2:]) == (3, 3) and weight.is_cuda
+            and weight.dtype == torch.float32)
 
 
 def conv3x3_wgrad(x, gp, absmax=None):
-    """Weight gradient of conv3x3(x, W, padding=1): x f32 [B, Cin, 12, 12], gp f32 [B, Cout, 12, 12] -> f32 [Cout, Cin, 3, 3]
+    """Weight gradient of conv3x3(x, W, padding=1): x f32 [B, Cin, S, S], gp f32 [B, Cout, S, S] -> f32 [Cout, Cin, 3, 3]
     (tron_conv3x3_wgrad; absmax as in conv3x3_dgrad, None = the library finds the maximum itself)."""
     L = nat.lib()
     B, cin, side, _ = x.shape

@@ -431,6 +431,10 @@ extern "C" int tron_wgrad_stamps(unsigned long long *host_dst)
 }
 #endif
 
+// csrc/tron_conv_wgrad_rows.hip: the row-streaming kernel for images that do not fit one strip (26x26)
+int tron_wgrad_rows(const float *in, const float *gp, const float *absmax, int n_absmax, float *partial, int64_t batch, int cin,
+                    int cout, int side, int grid_max, int *nparts, hipStream_t st);
+
 extern "C" int64_t tron_conv3x3_wgrad_workspace(int32_t cin, int32_t cout)
 {
     if (cin < 1 || cin > 64 || cout < 1 || cout > 64) return 0;
@@ -446,17 +450,29 @@ extern "C" int tron_conv3x3_wgrad(const float *in, const float *grad_pre, const 
          reinterpret_cast<uintptr_t>(grad_weight)) & 15u)
         return TRON_ERR_BAD_ARG;
     const bool small = cin == 3 || cin == 4;
-    if (side != SIDE || !(small || cin == 32 || cin == 64) || !(cout == 32 || cout == 64) || batch > (1ll << 24))
+    const bool rows = side == 26 && (cin == 32 || cin == 64) && (cout == 32 || cout == 64) && !(cin == 64 && cout == 32);
+    if (!(side == SIDE || rows) || !(small || cin == 32 || cin == 64) || !(cout == 32 || cout == 64) || batch > (1ll << 24))
         return TRON_ERR_UNSUPPORTED;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (batch == 0) return hipMemsetAsync(grad_weight, 0, (size_t)cout * cin * 9 * 4, st) == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
     if (!grad_absmax) {
-        const size_t n4 = (size_t)batch * cout * HW / 4;
+        const size_t n4 = (size_t)batch * cout * side * side / 4;
         const unsigned blocks = (unsigned)((n4 + 255) / 256 < ABSMAX_BLOCKS ? (n4 + 255) / 256 : ABSMAX_BLOCKS);
         hipLaunchKernelGGL(k_absmax, dim3(blocks), dim3(256), 0, st, grad_pre, n4, reinterpret_cast<float *>(ws));
         grad_absmax = reinterpret_cast<const float *>(ws);
         n_absmax = (int32_t)blocks;
+    }
+    if (rows) {                                                          // 24x24 boards: rows streamed through LDS
+        const Plan p = plan(cin, cout);
+        const int W = cout * cin * 9;
+        float *partial = reinterpret_cast<float *>(ws + p.partial), *stage2 = reinterpret_cast<float *>(ws + p.stage2);
+        int nparts = 0;
+        const int rc = tron_wgrad_rows(in, grad_pre, grad_absmax, n_absmax, partial, batch, cin, cout, side, GRID_MAX, &nparts, st);
+        if (rc != TRON_OK) return rc;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 255) / 256, STAGE2), dim3(256), 0, st, partial, nparts, STAGE2, W, stage2);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 255) / 256, 1), dim3(256), 0, st, stage2, STAGE2, 1, W, grad_weight);
+        return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
     }
     if (small) return launch<1, 2>(in, grad_pre, grad_absmax, n_absmax, grad_weight, batch, cin, cout, ws, st);
     if (cin == 32) return launch<2, 1>(in, grad_pre, grad_absmax, n_absmax, grad_weight, batch, cin, cout, ws, st);

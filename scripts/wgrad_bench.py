@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the weight-gradient kernel (tron_conv3x3_wgrad) per layer shape against aten.convolution_backward (MIOpen);
-usage: wgrad_bench.py [B]"""
+usage: wgrad_bench.py [B] [side]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "deep-q-learning_tron_amd")]
@@ -8,6 +8,7 @@ import config, torch  # noqa
 from Net import fused
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 
 
 def timed(fn, n=10):
@@ -22,12 +23,12 @@ def timed(fn, n=10):
     return ev[0].elapsed_time(ev[1]) / n * 1e3
 
 
-for cin, cout in ((4, 32), (32, 32), (32, 64), (64, 64)):
-    x = torch.randn(B, cin, 12, 12, device="cuda")
-    gp = torch.randn(B, cout, 12, 12, device="cuda") * 1e-4
+for cin, cout in (((4, 32),) if S == 12 else ()) + ((32, 32), (32, 64), (64, 64)):
+    x = torch.randn(B, cin, S, S, device="cuda")
+    gp = torch.randn(B, cout, S, S, device="cuda") * 1e-4
     w = torch.randn(cout, cin, 3, 3, device="cuda")
     absmax = gp.abs().reshape(64, -1).amax(1).contiguous()
-    fl = 2 * B * 144 * 9 * cin * cout
+    fl = 2 * B * S * S * 9 * cin * cout
     t = timed(lambda: fused.conv3x3_wgrad(x, gp, absmax))
     t0 = timed(lambda: fused.conv3x3_wgrad(x, gp, None))
     ta = timed(lambda: torch.ops.aten.convolution_backward(gp, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
