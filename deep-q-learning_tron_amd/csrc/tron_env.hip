@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <new>
 
@@ -146,6 +147,15 @@ __device__ __forceinline__ uint32_t chunk_env(uint32_t i, uint32_t cpe, uint32_t
     return cpe == 1u ? i : __umulhi(i, cpe_magic);
 }
 
+// Game.get_rate (game.py:100-102) as a table: "temper" mode compares a float32 uniform with the float64 rate of
+// (degree, weight); for every (degree in [-30, 30], weight in [40, 101]) — the ranges Game.__init__ draws from
+// (game.py:83,87) — the table holds the largest float32 t with (double)t <= rate, so `u <= t` decides exactly what
+// `(double)u <= rate` decides, without two float64 divisions per player in the one-env-per-lane section of the step.
+// Filled once per process by tron_create (host arithmetic, same operation order); values assigned from outside the
+// ranges (tron_set_weight_degree) take the float64 path.
+constexpr int RATE_DEG = 61, RATE_W = 62;
+__device__ float g_rate_thr[RATE_DEG * RATE_W];
+
 struct EnvRegs {
     uint32_t pos, meta, eplen, tick;           // st4
     uint32_t envp, episode, nstart, nenvp;     // rs4
@@ -175,6 +185,18 @@ __device__ inline void lane_move(const Params &P, unsigned char *g, const EnvReg
     uint32_t res = 0u;
     rec_st = make_uint4(R.pos, R.meta, R.eplen, R.tick);
 
+    // "temper": both players' slide thresholds, requested before anything else so that they arrive under the cell reads
+    float thr[2] = {0.0f, 0.0f};
+    bool thr_ok[2] = {false, false};
+    if (P.mode == TRON_MODE_TEMPER) {
+        const uint32_t di = (uint32_t)((int)(int8_t)(R.envp >> 16) + 30);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const uint32_t wi = ((R.envp >> (8 * p)) & 0xFFu) - 40u;
+            thr_ok[p] = di < (uint32_t)RATE_DEG && wi < (uint32_t)RATE_W;
+            thr[p] = g_rate_thr[thr_ok[p] ? di * RATE_W + wi : 0u];
+        }
+    }
     if (!done) {
         res |= RES_STEPPED;
         const bool sliding = (P.mode != TRON_MODE_NONE);
@@ -220,10 +242,15 @@ __device__ inline void lane_move(const Params &P, unsigned char *g, const EnvReg
             int nr = r[p] + dr[p], nc = c[p] + dc[p];
             // the uniform is consulted only for an in-bounds EMPTY target (game.py:164-165)
             if (sliding && inb[p] && tile_at(n[p], tn[p], 2 + p) == TRON_EMPTY) {
-                const double rate = (P.mode == TRON_MODE_ICE)
-                                        ? R.slide
-                                        : get_rate((int)(int8_t)(R.envp >> 16), (int)((R.envp >> (8 * p)) & 0xFFu));
-                if ((double)u[p] <= rate) {                             // game.py:169
+                bool slides;                                             // game.py:169: random.random() <= rate
+                if (P.mode == TRON_MODE_ICE) {
+                    slides = (double)u[p] <= R.slide;
+                } else if (thr_ok[p]) {
+                    slides = u[p] <= thr[p];
+                } else {
+                    slides = (double)u[p] <= get_rate((int)(int8_t)(R.envp >> 16), (int)((R.envp >> (8 * p)) & 0xFFu));
+                }
+                if (slides) {
                     cells[2 + p] = n[p];
                     vals[2 + p] = (p == 0) ? TRON_P1_SLIDE : TRON_P2_SLIDE;
                     f[p] = sl[p];
@@ -1345,6 +1372,24 @@ int tron_create(int32_t n_envs, int32_t W, int32_t mode, int32_t fair, uint32_t 
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
 
+    {   // the slide-threshold table of "temper" mode (g_rate_thr): once per process and device
+        static uint64_t filled = 0;
+        if (!(filled & (1ull << (dev & 63)))) {
+            static float tab[RATE_DEG * RATE_W];
+            for (int d = 0; d < RATE_DEG; ++d)
+                for (int w = 0; w < RATE_W; ++w) {
+                    const double a = (double)((d - 30) - 30) * 0.6;      // game.py:100-102, operation by operation
+                    const double b = -a / 100.0;
+                    const double c = (double)(70 - (w + 40)) / 100.0;
+                    const double rate = b - c;
+                    float t = (float)rate;
+                    if ((double)t > rate) t = nextafterf(t, -INFINITY);
+                    tab[d * RATE_W + w] = t;
+                }
+            if (hipMemcpyToSymbol(HIP_SYMBOL(g_rate_thr), tab, sizeof(tab)) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_ALLOC; }
+            filled |= 1ull << (dev & 63);
+        }
+    }
     tron_env *h = new (std::nothrow) tron_env();
     if (!h) return TRON_ERR_ALLOC;
     Params &P = h->P;
