@@ -50,6 +50,7 @@ class Net(nn.Module):
         self.actor2 = nn.Linear(64, 4)
         self.dropout = nn.Dropout(p=0.2)
         self.activation = self.mish
+        self.fuse_trunk = True       # conv1..conv6 as one autograd node where the HIP kernels cover the shape (Net/activations.py)
 
     @staticmethod
     def mish(x):
@@ -63,10 +64,13 @@ class Net(nn.Module):
         the replay ring as codes: tron_replay_sample_codes).  Where the HIP kernels do not cover the shape the planes
         are built explicitly."""
         from Net import fused
-        from Net.activations import conv1_codes_mish
+        from Net.activations import conv1_codes_mish, trunk_mish, trunk_supported
         side = codes.shape[-1]
         if codes.is_cuda and fused.supported(self.conv1, side) and (self.activation is Net.mish or self.activation is self.mish):
-            return self._after_conv1(conv1_codes_mish(self.conv1, codes.reshape(-1, side, side), plane4))
+            codes = codes.reshape(-1, side, side)
+            if self.fuse_trunk and trunk_supported(self, codes):
+                return self._after_trunk(trunk_mish(self, codes, plane4))
+            return self._after_conv1(conv1_codes_mish(self.conv1, codes, plane4))
         from tron.vec import pop_up_planes
         x = pop_up_planes(codes.reshape(-1, side, side))
         if self.in_channels == 4:
@@ -77,6 +81,10 @@ class Net(nn.Module):
         x = x.to(self.conv1.weight.device)
         if self.activation is not Net.mish and self.activation is not self.mish:   # a caller swapped the activation
             return self._forward_plain(x)
+        if self.fuse_trunk and torch.is_grad_enabled():
+            from Net.activations import trunk_mish, trunk_supported
+            if trunk_supported(self, x):
+                return self._after_trunk(trunk_mish(self, x))
         return self._after_conv1(_conv_bias_mish(self.conv1, x))
 
     def _after_conv1(self, x):
@@ -87,6 +95,9 @@ class Net(nn.Module):
         idx = x
         x = _conv_bias_mish(self.conv5, x)
         x = _conv_bias_mish(self.conv6, x, idx)
+        return self._after_trunk(x)
+
+    def _after_trunk(self, x):
         if _pool_conv7_supported(self.pool, self.conv7, x):
             x = _pool_conv7_mish(self.pool, self.conv7, x)              # the two layers as GEMMs on conv7's dense form
         else:

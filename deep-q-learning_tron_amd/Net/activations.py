@@ -131,6 +131,110 @@ class _Conv1CodesHIP(torch.autograd.Function):
         return None, gw, (gb if ctx.needs_input_grad[2] else None), None
 
 
+class _TrunkHIP(torch.autograd.Function):
+    """conv1 .. conv6 with their two residual connections (DQNNet.py:33-50) as ONE autograd node.  Forward is the six
+    layer kernels `_ConvBiasMishHIP` runs.  Backward needs the node to see the whole chain: between two layers autograd
+    would run the convolution's input gradient, an elementwise add where a residual connection delivers a second
+    gradient, and the activation's backward + bias sum — three passes over the tensor; here the input-gradient kernel's
+    epilogue adds the residual term, multiplies by mish'(pre) of the layer below and leaves that layer's bias sums and
+    the scale of what it wrote (tron_conv3x3_dgrad_mish), so a gradient tensor is written once and read only by the
+    kernels that contract it.  x: f32 planes [B, C, S, S] or the env's int8 codes [B, S, S]."""
+
+    @staticmethod
+    def forward(ctx, x, plane4, *wb):
+        from Net import fused
+        w, b = wb[0::2], wb[1::2]
+        codes = x.dtype == torch.int8
+        a1, z1 = fused.conv3x3_raw(x, w[0], b[0], None, act=True, codes=codes, plane4=plane4, want_pre=True)
+        a2, z2 = fused.conv3x3_raw(a1, w[1], b[1], None, act=True, want_pre=True)
+        a3, z3 = fused.conv3x3_raw(a2, w[2], b[2], a1, act=True, want_pre=True)
+        a4, z4 = fused.conv3x3_raw(a3, w[3], b[3], None, act=True, want_pre=True)
+        a5, z5 = fused.conv3x3_raw(a4, w[4], b[4], None, act=True, want_pre=True)
+        a6, z6 = fused.conv3x3_raw(a5, w[5], b[5], a4, act=True, want_pre=True)
+        ctx.save_for_backward(x, a1, a2, a3, a4, a5, z1, z2, z3, z4, z5, z6, *w)
+        ctx.plane4 = plane4
+        return a6
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from Net import fused
+        x, a1, a2, a3, a4, a5, z1, z2, z3, z4, z5, z6, *w = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if not _aligned16(g):
+            g = g.clone(memory_format=torch.contiguous_format)
+        side = g.shape[-1]
+        need = ctx.needs_input_grad                                 # (x, plane4, w1, b1, ..., w6, b6)
+
+        def wgrad(layer, inp, gp, am):
+            if not need[2 + 2 * layer]:
+                return None
+            if fused.wgrad_supported(w[layer], side):
+                return fused.conv3x3_wgrad(inp, gp, am)
+            return torch.ops.aten.convolution_backward(gp, inp, w[layer], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                       [False, True, False])[1]
+
+        gb = [None] * 6
+        gw = [None] * 6
+        gp6, gb[5], am = bias_mish_bwd(z6, g, want_absmax=True)
+        del g
+        gw[5] = wgrad(5, a5, gp6, am)
+        gp5, gb[4], am5 = fused.conv3x3_dgrad_mish(gp6, w[5], am, z5)
+        gw[4] = wgrad(4, a4, gp5, am5)
+        gp4, gb[3], am4 = fused.conv3x3_dgrad_mish(gp5, w[4], am5, z4, extra=gp6)    # a4 also feeds conv6's residual
+        del gp5, gp6
+        gw[3] = wgrad(3, a3, gp4, am4)
+        gp3, gb[2], am3 = fused.conv3x3_dgrad_mish(gp4, w[3], am4, z3)
+        del gp4
+        gw[2] = wgrad(2, a2, gp3, am3)
+        gp2, gb[1], am2 = fused.conv3x3_dgrad_mish(gp3, w[2], am3, z2)
+        gw[1] = wgrad(1, a1, gp2, am2)
+        gp1, gb[0], am1 = fused.conv3x3_dgrad_mish(gp2, w[1], am2, z1, extra=gp3)    # a1 also feeds conv3's residual
+        del gp2, gp3
+        gx = None
+        planes = x
+        if x.dtype == torch.int8:
+            if need[2]:
+                from tron.vec import pop_up_planes
+                planes = pop_up_planes(x)
+                if w[0].shape[1] == 4:
+                    planes = torch.cat([planes, torch.full_like(planes[:, :1], ctx.plane4)], 1)
+        elif need[0]:                                               # the planes asked for their gradient (saliency): the library
+            gx = torch.ops.aten.convolution_backward(gp1, x, w[0], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        gw[0] = wgrad(0, planes, gp1, am1)
+        grads = [gx, None]
+        for k in range(6):
+            grads += [gw[k], gb[k] if need[3 + 2 * k] else None]
+        return tuple(grads)
+
+
+def trunk_supported(net, x):
+    """Can `_TrunkHIP` run conv1..conv6 of `net` on x (f32 planes [B, C, S, S] or int8 codes [B, S, S])?"""
+    from Net import fused
+    if not (torch.is_tensor(x) and x.is_cuda and fused.default_math == "f16x3" and x.numel() > 0):
+        return False
+    side = x.shape[-1]
+    convs = [net.conv1, net.conv2, net.conv3, net.conv4, net.conv5, net.conv6]
+    if x.dtype == torch.int8:
+        if x.dim() != 3 or x.shape[-2] != side or net.conv1.in_channels not in (3, 4):
+            return False
+    elif not (x.dtype == torch.float32 and x.dim() == 4 and x.shape[-2] == side and x.shape[1] == net.conv1.in_channels
+              and net.conv1.in_channels in (3, 4) and _aligned16(x)):
+        return False
+    chans = [(c.in_channels, c.out_channels) for c in convs[1:]]
+    return (chans == [(32, 32), (32, 32), (32, 64), (64, 64), (64, 64)] and net.conv1.out_channels == 32
+            and all(c.bias is not None and fused.supported(c, side) for c in convs)
+            and all(fused.dgrad_mish_supported(c.weight, side) for c in convs[1:]))
+
+
+def trunk_mish(net, x, plane4=0.0):
+    """mish-activated conv1..conv6 of a DQN `Net` (DQNNet.py:33-50) with autograd, as one node (`_TrunkHIP`)."""
+    wb = []
+    for c in (net.conv1, net.conv2, net.conv3, net.conv4, net.conv5, net.conv6):
+        wb += [c.weight, c.bias]
+    return _TrunkHIP.apply(x.contiguous(), float(plane4), *wb)
+
+
 def conv1_codes_mish(conv, codes, plane4=0.0):
     """mish(conv1(planes of `codes`)) with autograd for weight and bias: codes int8 [B, S, S] on the device."""
     from Net import fused

@@ -267,6 +267,39 @@ def conv3x3_dgrad(gp, weight, absmax=None):
     return gx
 
 
+def dgrad_mish_supported(weight, side):
+    """tron_conv3x3_dgrad_mish's shapes (conv2..conv6 of the DQN trunk at 12x12 and 26x26)."""
+    return (side in _SIDES and tuple(weight.shape[2:]) == (3, 3) and weight.shape[0] in (32, 64) and weight.shape[1] in (32, 64)
+            and weight.is_cuda and weight.dtype == torch.float32)
+
+
+def conv3x3_dgrad_mish(gp, weight, absmax, pre_below, extra=None):
+    """(dgrad(gp, weight) + extra) * mish'(pre_below) in one launch, with the bias gradient of the layer below and the
+    per-channel maxima of the result (tron_conv3x3_dgrad_mish): gp f32 [B, Cout, S, S], weight the FORWARD layer's
+    [Cout, Cin, 3, 3], pre_below / extra f32 [B, Cin, S, S] -> (grad_pre_below, bias_grad_below [Cin], absmax_below [Cin])."""
+    L = nat.lib()
+    B, cout, side, _ = gp.shape
+    cin = weight.shape[1]
+    assert gp.is_contiguous() and gp.dtype == torch.float32 and tuple(weight.shape) == (cout, cin, 3, 3)
+    assert pre_below.is_contiguous() and tuple(pre_below.shape) == (B, cin, side, side) and pre_below.dtype == torch.float32
+    assert extra is None or (extra.is_contiguous() and extra.shape == pre_below.shape and extra.dtype == torch.float32)
+    w = weight if weight.is_contiguous() else weight.contiguous()
+    dev = gp.device
+    out = torch.empty_like(pre_below)
+    gb = torch.empty(cin, dtype=torch.float32, device=dev)
+    am = torch.empty(cin, dtype=torch.float32, device=dev)
+    nbytes = int(L.tron_conv3x3_dgrad_mish_workspace(B, cin, cout, side))
+    if nbytes <= 0:
+        raise nat.TronNativeError(f"tron_conv3x3_dgrad_mish: no kernel for cin={cin} cout={cout} side={side}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(L.tron_conv3x3_dgrad_mish(gp.data_ptr(), w.data_ptr(), None if absmax is None else absmax.data_ptr(),
+                                            0 if absmax is None else absmax.numel(), None if extra is None else extra.data_ptr(),
+                                            pre_below.data_ptr(), out.data_ptr(), gb.data_ptr(), am.data_ptr(), B, cin, cout, side,
+                                            ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "tron_conv3x3_dgrad_mish")
+    return out, gb, am
+
+
 def wgrad_supported(weight, side):
     """tron_conv3x3_wgrad's shapes: every layer of the trunk at 12x12; conv2..conv6 at 26x26 (24x24 boards: the
     row-streaming kernel; conv1's tiny gradient stays on the library there)."""

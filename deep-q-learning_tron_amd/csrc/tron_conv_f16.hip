@@ -36,6 +36,10 @@
 #define TRON_F16_ABLATE 0
 #endif
 
+#ifndef TRON_MBWD_PREFETCH   // 0: A/B switch for measurements (the fused backward epilogue's operands not prefetched into L2)
+#define TRON_MBWD_PREFETCH 1
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -114,6 +118,25 @@ __device__ __forceinline__ f32x4 mish4(f32x4 x)
     return x * (n * r);
 }
 
+// gy * mish'(x) the same way (tron_nn.hip's mish_grad1 with exp2 / rcp): t = n / (n + 2), 1 - t^2 = (2 / (n + 2)) (1 + t),
+// mish' = t + x (1 - t^2) e / (1 + e).  With e capped at 1e18, t is exactly 1 and the second term 0 up there.
+__device__ __forceinline__ f32x4 mish_grad4(f32x4 x, f32x4 gy)
+{
+    const f32x4 t2 = x * 1.44269504088896341f;
+    f32x4 e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t b = __float_as_uint(__builtin_amdgcn_exp2f(t2[i]));
+        e[i] = __uint_as_float(b < 0x5D5E0B6Bu ? b : 0x5D5E0B6Bu);
+    }
+    const f32x4 n = __builtin_elementwise_fma(e, e, e + e);
+    const f32x4 d = n + 2.0f, e1 = e + 1.0f;
+    const f32x4 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+    const f32x4 q = {__builtin_amdgcn_rcpf(e1[0]), __builtin_amdgcn_rcpf(e1[1]), __builtin_amdgcn_rcpf(e1[2]), __builtin_amdgcn_rcpf(e1[3])};
+    const f32x4 t = n * r, u = r + r;
+    return gy * (t + x * (u * (1.0f + t)) * (e * q));
+}
+
 // v -> (hi, lo): v = hi + lo * 2^-11 up to 2^-22 |v|
 __device__ __forceinline__ void split(float v, f16 &hi, f16 &lo)
 {
@@ -180,12 +203,19 @@ __global__ void k_split_weights_multi(SplitJobs jobs)
 __device__ unsigned long long g_wave_stamps[256 * 8 * 4];
 #endif
 
-template <int S, int NT, bool SMALL, bool PERSIST>
+//
+// MBWD (the learner's backward, tron_conv3x3_dgrad_mish): the call is a data gradient whose result is carried through the
+// activation of the layer BELOW before it is written: out = (conv + res) * mish'(zprev) — res is then the gradient that
+// reaches the same tensor along a residual connection, zprev the layer below's pre-activation (laid out like out) — and
+// every wave keeps the sums and the largest magnitudes of what it wrote, per channel, in its own LDS slots and leaves them
+// in stats[2][workgroup][wave][16 NT] when it is done (k_mbwd_finish adds them up in a fixed order: the layer below's bias
+// gradient and the scale its consumers need).
+template <int S, int NT, bool SMALL, bool PERSIST, bool MBWD = false>
 __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     const void *__restrict__ in, const f16 *__restrict__ ws, const float *__restrict__ bias,
     const float *__restrict__ res, float *__restrict__ out, float *__restrict__ pre_out, int B, int cin, float plane4,
     int apply_mish, int in_fmt, unsigned char *__restrict__ out_s16, const float *__restrict__ absmax, int n_absmax,
-    int ngroups)
+    int ngroups, const float *__restrict__ zprev, float *__restrict__ stats)
 {
     static_assert(!PERSIST || !SMALL, "persistent groups: chunked input");   // (NB > 1: the host keeps the grid a multiple of NB,
                                                                              //  so a workgroup's band never changes)
@@ -207,6 +237,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     // LDS: in[0] (hi|lo) | in[1] (hi|lo) | w[0] (hi|lo) | w[1] (hi|lo) | dump (1 KB: where surplus threads' staging
     // writes go, so that the staging pieces are branch-free and can be scheduled between MFMAs)
     unsigned char *dump = lds + 2 * IN_BUF + 2 * W_BUF;
+    float *sacc = reinterpret_cast<float *>(dump + 1024);               // MBWD: [wave][sum | max][16 NT <= 32], touched by its wave only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // waves w and w + 4 share a SIMD: the second N half walks the M slots backwards, so a SIMD gets 5 + 4 tiles
@@ -251,6 +282,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
             act_unscale = __uint_as_float((uint32_t)(127 - 14 + e) << 23);
         }
     }
+    if (MBWD) sacc[tid] = 0.0f;                                         // (8 waves x 64 slots)
     // zero both input buffers once: halo pixels (and, for SMALL, the absent channels) stay zero for good
     for (int i = tid; i < 2 * IN_BUF / 16; i += THREADS) reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
 
@@ -538,6 +570,28 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         ld_in16 = reinterpret_cast<const unsigned char *>(in) + (size_t)img0n * cin * C::SS * 4;
         ld_last = B - 1 - img0n;
     }
+    if (MBWD && TRON_MBWD_PREFETCH) {
+        // The epilogue's operands (this group's region of zprev and res) start on their way into the L2 while the last chunk
+        // computes: one 4-byte LDS-DMA per 128-byte line, into the dump (no register, nothing waits for them).  A region is
+        // P * COUT runs of rows * S floats, one per (image, channel) plane.
+        constexpr int L = (C::ROWS_MAX * S * 4 + 127) / 128 + 1, NPF = (C::P * COUT * L + THREADS - 1) / THREADS;
+        const int runb = rows * S * 4;
+        const unsigned char *zb = reinterpret_cast<const unsigned char *>(zprev), *rb = res ? reinterpret_cast<const unsigned char *>(res) : zb;
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int idx = tid + j * THREADS;
+            int run = idx / L;
+            const int line = idx - run * L;
+            if (run >= C::P * COUT || run / COUT > last_img) run = 0;
+            int off = line * 128;
+            off = off < runb ? off : runb - 4;
+            const size_t byte = (wg_base + (size_t)run * C::SS + r0 * S) * 4 + off;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(zb + byte),
+                                             (__attribute__((address_space(3))) void *)dump, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rb + byte),
+                                             (__attribute__((address_space(3))) void *)dump, 4, 0, 0);
+        }
+    }
     TRON_CHUNK(PERSIST, nchunks - 1, 0);
 
 #undef TRON_CHUNK
@@ -584,6 +638,34 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         for (int t = 0; t < C::MT; ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc0[t][n] += r[t][n];
+    }
+    if (MBWD) {
+        const float *z_wg = zprev + wg_base;
+        float bsum[NT], bmax[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bsum[n] = bmax[n] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < C::MT; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const f32x4 z = live[t] ? *reinterpret_cast<const f32x4 *>(z_wg + (uint32_t)(o[t] + n * 16 * C::SS)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 v = live[t] ? mish_grad4(z, acc0[t][n]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc0[t][n] = v;
+                bsum[n] += (v[0] + v[1]) + (v[2] + v[3]);
+                bmax[n] = fmaxf(fmaxf(bmax[n], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {                                  // lanes li, li + 16, li + 32, li + 48 hold one channel
+            bsum[n] += __shfl_xor(bsum[n], 16);
+            bsum[n] += __shfl_xor(bsum[n], 32);
+            bmax[n] = fmaxf(bmax[n], __shfl_xor(bmax[n], 16));
+            bmax[n] = fmaxf(bmax[n], __shfl_xor(bmax[n], 32));
+            if (g_e == 0) {
+                float *slot = sacc + wave * 64 + n * 16 + li;
+                slot[0] += bsum[n];
+                slot[32] = fmaxf(slot[32], bmax[n]);
+            }
+        }
     }
     float *out_wg = out ? out + wg_base : nullptr;
     float *pre_wg = pre_out ? pre_out + wg_base : nullptr;
@@ -645,16 +727,22 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (the next group's weight chunk 0: LDS-DMA)
     __syncthreads();                                                    // the staged chunk is complete, the old buffers are free
     }
+    if (MBWD && lane < 16 * NT) {
+        const size_t slot = ((size_t)blockIdx.x * (THREADS / 64) + wave) * (16 * NT) + lane;
+        stats[slot] = sacc[wave * 64 + lane];
+        stats[(size_t)gridDim.x * (THREADS / 64) * (16 * NT) + slot] = sacc[wave * 64 + 32 + lane];
+    }
 }
 
-template <int S, int NT, bool SMALL, bool PERSIST>
+template <int S, int NT, bool SMALL, bool PERSIST, bool MBWD = false>
 int launch(const void *in, const f16 *ws, const float *bias, const float *res, float *out, float *pre_out, int64_t B,
-           int cin, float plane4, int apply_mish, int in_fmt, void *out_s16, const float *absmax, int n_absmax, hipStream_t st)
+           int cin, float plane4, int apply_mish, int in_fmt, void *out_s16, const float *absmax, int n_absmax, hipStream_t st,
+           const float *zprev = nullptr, float *stats = nullptr, int64_t *grid_out = nullptr, int64_t grid_max = 0)
 {
     using C = Cfg<S>;
-    constexpr size_t LDS_BYTES = 4 * (size_t)C::IN_HALF + 4 * (size_t)TAPS_PAD * 32 * NT * PITCH + 1024;
+    constexpr size_t LDS_BYTES = 4 * (size_t)C::IN_HALF + 4 * (size_t)TAPS_PAD * 32 * NT * PITCH + 1024 + (MBWD ? THREADS * 4 : 0);
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    auto kern = k_conv3x3_f16<S, NT, SMALL, PERSIST>;
+    auto kern = k_conv3x3_f16<S, NT, SMALL, PERSIST, MBWD>;
     static uint64_t prepared = 0;
     static int cus[64];
     int dev = 0;
@@ -671,10 +759,46 @@ int launch(const void *in, const f16 *ws, const float *bias, const float *res, f
     const int64_t groups = (B + C::P - 1) / C::P * C::NB;
     // PERSIST: one workgroup per CU (the kernel's LDS allows no more) walking groups blockIdx.x, + grid, ...
     const int64_t grid = PERSIST && groups > cus[dev & 63] ? cus[dev & 63] / C::NB * C::NB : groups;
+    if (grid_out) {
+        if (grid > grid_max) return TRON_ERR_UNSUPPORTED;               // (the caller sized its partial-sum scratch for grid_max workgroups)
+        *grid_out = grid;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, st, in, ws, bias, res, out, pre_out, (int)B,
-                       cin, plane4, apply_mish, in_fmt, reinterpret_cast<unsigned char *>(out_s16), absmax, n_absmax, (int)groups);
+                       cin, plane4, apply_mish, in_fmt, reinterpret_cast<unsigned char *>(out_s16), absmax, n_absmax, (int)groups,
+                       zprev, stats);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
+
+// stats[2][workgroups][8 waves][16 NT] of a MBWD launch -> bias_grad[c] (sums, fixed order) and absmax[c]; one workgroup per channel
+__global__ __launch_bounds__(256) void k_mbwd_finish(const float *__restrict__ stats, int groups, int nt, float *__restrict__ bias_grad,
+                                                     float *__restrict__ absmax)
+{
+    __shared__ float rs[256], rm[256];
+    const int c = blockIdx.x, per = 16 * nt, wn = c / per, col = c - wn * per;
+    const size_t half = (size_t)groups * (THREADS / 64) * per;
+    float s = 0.0f, m = 0.0f;
+    for (int i = threadIdx.x; i < groups * NWM; i += 256) {             // (group, wave row) pairs; wave = wn * NWM + row
+        const size_t slot = ((size_t)(i / NWM) * (THREADS / 64) + wn * NWM + (i % NWM)) * per + col;
+        s += stats[slot];
+        m = fmaxf(m, stats[half + slot]);
+    }
+    rs[threadIdx.x] = s;
+    rm[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            rs[threadIdx.x] += rs[threadIdx.x + d];
+            rm[threadIdx.x] = fmaxf(rm[threadIdx.x], rm[threadIdx.x + d]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        bias_grad[c] = rs[0];
+        absmax[c] = rm[0];
+    }
+}
+
+constexpr int64_t MBWD_GRID_MAX = 1024;         // workgroups a MBWD launch may have (persistent: one per CU)
 
 }  // namespace
 
@@ -739,4 +863,50 @@ int tron_conv3x3_f16x3(const void *in, int in_fmt, const float *weight, const fl
 #undef TRON_F16_CASE
 #undef TRON_F16_ARGS
     return TRON_ERR_UNSUPPORTED;
+}
+
+// ---- the learner's backward: input gradient + the activation gradient of the layer below in one launch ---------------
+extern "C" int64_t tron_conv3x3_dgrad_mish_workspace(int64_t batch, int32_t cin, int32_t cout, int32_t side)
+{
+    if (batch < 0 || (cin != 32 && cin != 64) || (cout != 32 && cout != 64) || (side != 12 && side != 26)) return 0;
+    const int64_t wbytes = (tron_conv3x3_f16x3_workspace(cout, cin) + 255) / 256 * 256;
+    return wbytes + 2 * MBWD_GRID_MAX * (THREADS / 64) * (cin / 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int tron_conv3x3_dgrad_mish(const float *grad_pre, const float *weight, const float *grad_absmax, int32_t n_absmax,
+                                       const float *extra_grad, const float *pre_below, float *grad_pre_below,
+                                       float *bias_grad_below, float *absmax_below, int64_t batch, int32_t cin, int32_t cout,
+                                       int32_t side, void *workspace, void *stream)
+{
+    if (!grad_pre || !weight || !pre_below || !grad_pre_below || !bias_grad_below || !absmax_below || !workspace || batch < 0 ||
+        (grad_absmax && n_absmax < 1))
+        return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(grad_pre) | reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(extra_grad) |
+         reinterpret_cast<uintptr_t>(pre_below) | reinterpret_cast<uintptr_t>(grad_pre_below) | reinterpret_cast<uintptr_t>(workspace)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    if ((cin != 32 && cin != 64) || (cout != 32 && cout != 64) || (side != 12 && side != 26) || batch > (1ll << 24))
+        return TRON_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (batch == 0) {
+        if (hipMemsetAsync(bias_grad_below, 0, cin * sizeof(float), st) != hipSuccess ||
+            hipMemsetAsync(absmax_below, 0, cin * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_LAUNCH; }
+        return TRON_OK;
+    }
+    // the kernel's view: a convolution from `cout` gradient channels to `cin` channels
+    f16 *ws = reinterpret_cast<f16 *>(workspace);
+    const int nchunks = cout / CIC;
+    const int total = nchunks * TAPS_PAD * cin * CIC;
+    float *stats = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(workspace) + (tron_conv3x3_f16x3_workspace(cout, cin) + 255) / 256 * 256);
+    hipLaunchKernelGGL(k_split_weights, dim3((total + 255) / 256), dim3(256), 0, st, weight, cin, cout, nchunks, 1, ws);
+    int rc = TRON_ERR_UNSUPPORTED;
+    int64_t groups = 0;
+#define TRON_MBWD_ARGS grad_pre, ws, nullptr, extra_grad, grad_pre_below, nullptr, batch, cout, 0.0f, 0, TRON_CONV_IN_F32, nullptr, grad_absmax, n_absmax, st, pre_below, stats, &groups, MBWD_GRID_MAX
+    if (side == 12)
+        rc = cin == 64 ? launch<12, 2, false, true, true>(TRON_MBWD_ARGS) : launch<12, 1, false, true, true>(TRON_MBWD_ARGS);
+    else
+        rc = cin == 64 ? launch<26, 2, false, true, true>(TRON_MBWD_ARGS) : launch<26, 1, false, true, true>(TRON_MBWD_ARGS);
+#undef TRON_MBWD_ARGS
+    if (rc != TRON_OK) return rc;
+    hipLaunchKernelGGL(k_mbwd_finish, dim3(cin), dim3(256), 0, st, stats, (int)groups, cin / 32, bias_grad_below, absmax_below);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }

@@ -136,7 +136,7 @@ __device__ unsigned char g_ws_dump[152 * 1024];                          // (as 
 __device__ uint4 g_ws_zero[64];                                          // 1 KB of zeros: what a DMA lane copies into halo rows, zones and plane padding
 
 #ifdef TRON_WS_STAMPS        // diagnostic build only (scripts/ws_stamps.py): per-wave cycle counts, read back by tron_conv_ws_stamps
-__device__ unsigned long long g_ws_stamps[256 * 8 * 8];
+__device__ unsigned long long g_ws_stamps[256 * 12 * 8];         // [workgroup][wave <= 12][8]
 #endif
 
 // One step = TPS pixel tiles of 16 pixels through all of K, with the PREVIOUS step's epilogue (bias, residual, mish,
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
     }
 #ifdef TRON_WS_STAMPS
     if (lane == 0 && blockIdx.x < 256) {
-        unsigned long long *d = g_ws_stamps + (blockIdx.x * 8 + wave) * 8;
+        unsigned long long *d = g_ws_stamps + (blockIdx.x * 12 + wave) * 8;
         d[0] = st_wait; d[1] = st_bar; d[2] = st_dma; d[3] = st_steps; d[4] = st_items;
         d[5] = __builtin_amdgcn_s_memtime() - st_t0; d[6] = __builtin_amdgcn_s_memrealtime() - st_r0; d[7] = st_res;
     }
@@ -659,15 +659,18 @@ extern "C" int tron_conv3x3_ws_fwd(const void *in_px16, const void *wfrag, const
 #ifndef TRON_WS_TPS
 #define TRON_WS_TPS (TRON_WS_WAVES == 4 ? 3 : 1)
 #endif
-#define TRON_WS_CASE(S_, R_, CI_, CO_, IPI_)                                                                          \
+#ifndef TRON_WS_WAVES32      // waves of the 32-input-channel layers: 72 weight registers, so three waves per SIMD fit, and 12 waves
+#define TRON_WS_WAVES32 12   // deal a 12x12 item's 9 (18) tiles evenly; 1-4 % faster than 8 (profiles/r03_ws_layer_bench_*.txt)
+#endif
+#define TRON_WS_CASE(S_, R_, CI_, CO_, IPI_, WAVES_)                                                                  \
     if (side == S_ && cin == CI_ && cout == CO_)                                                                      \
-        return launch_ws<Geo<S_, R_, CI_, CO_, IPI_, TRON_WS_WAVES, TRON_WS_TPS>>(in_px16, wfrag, bias, res_px16, out_px16, out_f32, pre_f32, batch, apply_mish, st);
-    TRON_WS_CASE(12, 12, 32, 32, 2)
-    TRON_WS_CASE(12, 12, 32, 64, 1)
-    TRON_WS_CASE(12, 12, 64, 64, 1)
-    TRON_WS_CASE(26, 13, 32, 32, 1)
-    TRON_WS_CASE(26, 13, 32, 64, 1)
-    TRON_WS_CASE(26, 7, 64, 64, 1)
+        return launch_ws<Geo<S_, R_, CI_, CO_, IPI_, WAVES_, TRON_WS_TPS>>(in_px16, wfrag, bias, res_px16, out_px16, out_f32, pre_f32, batch, apply_mish, st);
+    TRON_WS_CASE(12, 12, 32, 32, 2, TRON_WS_WAVES32)
+    TRON_WS_CASE(12, 12, 32, 64, 1, TRON_WS_WAVES32)
+    TRON_WS_CASE(12, 12, 64, 64, 1, TRON_WS_WAVES)
+    TRON_WS_CASE(26, 13, 32, 32, 1, TRON_WS_WAVES32)
+    TRON_WS_CASE(26, 13, 32, 64, 1, TRON_WS_WAVES32)
+    TRON_WS_CASE(26, 7, 64, 64, 1, TRON_WS_WAVES)
 #undef TRON_WS_CASE
     return TRON_ERR_UNSUPPORTED;
 }

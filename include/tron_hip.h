@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TRON_ABI_VERSION 5
+#define TRON_ABI_VERSION 6
 
 typedef enum {
     TRON_OK = 0,
@@ -359,6 +359,20 @@ int64_t tron_conv3x3_wgrad_workspace(int32_t cin, int32_t cout);
 int tron_conv3x3_dgrad(const float *grad_pre, const float *weight, const float *grad_absmax, int32_t n_absmax,
                        float *grad_in, int64_t batch, int32_t cin, int32_t cout, int32_t side, void *workspace,
                        void *stream);
+/* The same input gradient carried through the activation of the layer below in the same launch — what autograd does
+ * between two mish(conv(.)) layers of DQNNet.py:33-50 as three passes (convolution backward, the sum with the gradient
+ * arriving over a residual connection, mish backward + bias sum):
+ *   grad_pre_below = (dgrad(grad_pre, weight) + extra_grad) * mish'(pre_below)      f32[batch][cin][side][side]
+ *   bias_grad_below[c] = sum over b, y, x of grad_pre_below (fixed order: deterministic), absmax_below[c] = max |grad_pre_below|
+ * (the grad_absmax / n_absmax = cin the next tron_conv3x3_dgrad* / _wgrad call of the chain takes).  extra_grad (may be
+ * NULL) and pre_below are laid out like the output.  side 12 or 26, cin and cout 32 or 64; workspace:
+ * tron_conv3x3_dgrad_mish_workspace(batch, cin, cout, side) bytes (split weights + per-workgroup partial sums; 0 = shape
+ * not supported), 16-byte aligned like every tensor.                                                              */
+int tron_conv3x3_dgrad_mish(const float *grad_pre, const float *weight, const float *grad_absmax, int32_t n_absmax,
+                            const float *extra_grad, const float *pre_below, float *grad_pre_below, float *bias_grad_below,
+                            float *absmax_below, int64_t batch, int32_t cin, int32_t cout, int32_t side, void *workspace,
+                            void *stream);
+int64_t tron_conv3x3_dgrad_mish_workspace(int64_t batch, int32_t cin, int32_t cout, int32_t side);
 
 /* ---- the rest of the DQN net after the 3x3 trunk (Net/DQNNet.py:52-63) ------------------------------------------
  * q = actor2(mish(actor1(mish(fc2(mish(fc1(flatten(mish(conv7(pool(x)))))))))))  for gradient-free forwards

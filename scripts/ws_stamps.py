@@ -28,9 +28,9 @@ for _ in range(5):
 torch.cuda.synchronize()
 L = fused.nat.lib()
 L.tron_conv_ws_stamps.argtypes = [ctypes.c_void_p]
-buf = np.zeros(256 * 8 * 8, np.uint64)
+buf = np.zeros(256 * 12 * 8, np.uint64)
 assert L.tron_conv_ws_stamps(buf.ctypes.data) == 0
-st = buf.reshape(256, 8, 8).astype(np.float64)
+st = buf.reshape(256, 12, 8).astype(np.float64)       # [workgroup][wave (8 or 12 used)][stamp]
 st = st[:, st[0, :, 4] > 0, :]
 items = st[:, :, 4]
 print(f"{layer} B={B} S={S}: items per workgroup {items.mean():.1f}")
