@@ -36,10 +36,6 @@
 #define TRON_F16_ABLATE 0
 #endif
 
-#ifndef TRON_MBWD_PREFETCH   // 0: A/B switch for measurements (the fused backward epilogue's operands not prefetched into L2)
-#define TRON_MBWD_PREFETCH 1
-#endif
-
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -209,7 +205,10 @@ __device__ unsigned long long g_wave_stamps[256 * 8 * 4];
 // reaches the same tensor along a residual connection, zprev the layer below's pre-activation (laid out like out) — and
 // every wave keeps the sums and the largest magnitudes of what it wrote, per channel, in its own LDS slots and leaves them
 // in stats[2][workgroup][wave][16 NT] when it is done (k_mbwd_finish adds them up in a fixed order: the layer below's bias
-// gradient and the scale its consumers need).
+// gradient and the scale its consumers need).  The epilogue's loads and its mish' arithmetic are exposed (one workgroup per
+// CU, all waves in the same phase): +57 us on 168 at 4 096 x 12x12 x 64 channels, +250 on 824 at 26x26 — against 85 + 66 and
+// 473 + 366 us for the passes it replaces.  (Tried: touching the group's zprev / res lines by 4-byte LDS-DMA while the last
+// chunk computes, so that the epilogue's loads hit L2 — no change: the phase is bound by its arithmetic and stores.)
 template <int S, int NT, bool SMALL, bool PERSIST, bool MBWD = false>
 __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     const void *__restrict__ in, const f16 *__restrict__ ws, const float *__restrict__ bias,
@@ -569,28 +568,6 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
         ld_in_wg = reinterpret_cast<const float *>(in) + (size_t)img0n * cin * C::SS;
         ld_in16 = reinterpret_cast<const unsigned char *>(in) + (size_t)img0n * cin * C::SS * 4;
         ld_last = B - 1 - img0n;
-    }
-    if (MBWD && TRON_MBWD_PREFETCH) {
-        // The epilogue's operands (this group's region of zprev and res) start on their way into the L2 while the last chunk
-        // computes: one 4-byte LDS-DMA per 128-byte line, into the dump (no register, nothing waits for them).  A region is
-        // P * COUT runs of rows * S floats, one per (image, channel) plane.
-        constexpr int L = (C::ROWS_MAX * S * 4 + 127) / 128 + 1, NPF = (C::P * COUT * L + THREADS - 1) / THREADS;
-        const int runb = rows * S * 4;
-        const unsigned char *zb = reinterpret_cast<const unsigned char *>(zprev), *rb = res ? reinterpret_cast<const unsigned char *>(res) : zb;
-#pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-            const int idx = tid + j * THREADS;
-            int run = idx / L;
-            const int line = idx - run * L;
-            if (run >= C::P * COUT || run / COUT > last_img) run = 0;
-            int off = line * 128;
-            off = off < runb ? off : runb - 4;
-            const size_t byte = (wg_base + (size_t)run * C::SS + r0 * S) * 4 + off;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(zb + byte),
-                                             (__attribute__((address_space(3))) void *)dump, 4, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rb + byte),
-                                             (__attribute__((address_space(3))) void *)dump, 4, 0, 0);
-        }
     }
     TRON_CHUNK(PERSIST, nchunks - 1, 0);
 
