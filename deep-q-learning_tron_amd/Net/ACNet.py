@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from config import MAP_WIDTH
 from Net.DQNNet import conv7_side
-from Net.activations import mish as _mish
+from Net.activations import mish as _mish, Conv3x3 as _Conv3x3, pool_s2 as _pool_s2
 
 
 class Net(nn.Module):
@@ -55,12 +55,14 @@ class Net(nn.Module):
     # ---- the trunk every net shares (e.g. ACNet.py:97-116) -------------------------------
     def _build_trunk(self, in_channels, width):
         self.side = width + 2
-        self.conv1 = nn.Conv2d(in_channels, 32, 3, padding=1)
-        self.conv2 = nn.Conv2d(32, 32, 3, padding=1)
-        self.conv3 = nn.Conv2d(32, 32, 3, padding=1)
-        self.conv4 = nn.Conv2d(32, 64, 3, padding=1)
-        self.conv5 = nn.Conv2d(64, 64, 3, padding=1)
-        self.conv6 = nn.Conv2d(64, 64, 3, padding=1)
+        # Conv3x3: nn.Conv2d with its forward / input gradient / weight gradient on csrc/tron_conv_f16.hip, tron_conv_wgrad*.hip
+        # where they cover the shape (boards 10x10, 24x24, 32x32) — still the module K-FAC hooks (Net/kfac.py)
+        self.conv1 = _Conv3x3(in_channels, 32, 3, padding=1)
+        self.conv2 = _Conv3x3(32, 32, 3, padding=1)
+        self.conv3 = _Conv3x3(32, 32, 3, padding=1)
+        self.conv4 = _Conv3x3(32, 64, 3, padding=1)
+        self.conv5 = _Conv3x3(64, 64, 3, padding=1)
+        self.conv6 = _Conv3x3(64, 64, 3, padding=1)
         self.pool = nn.AvgPool2d(kernel_size=3, padding=1, stride=2)
         self.conv7 = nn.Conv2d(64, 64, 7, padding=3, stride=2)
         self.flat = 64 * conv7_side(self.side) ** 2
@@ -77,7 +79,7 @@ class Net(nn.Module):
         idx = x
         x = a(self.conv5(x))
         x = a(self.conv6(x) + idx)
-        x = self.pool(x)
+        x = _pool_s2(self.pool, x)            # (csrc/tron_head.hip's row kernels at 12 / 26 / 34, both directions; else self.pool)
         x = a(self.conv7(x))
         x = x.reshape(-1, self.flat)
         return self.dropout(a(self.fc1(x)))

@@ -131,6 +131,58 @@ class _Conv1CodesHIP(torch.autograd.Function):
         return None, gw, (gb if ctx.needs_input_grad[2] else None), None
 
 
+class _Conv3x3HIP(torch.autograd.Function):
+    """conv3x3(x, weight, padding=1) (+ bias) alone — no activation — on the hand-written kernels, for modules whose bias
+    and activation are separate layers: the ACKTR nets after KFACOptimizer split their biases (Net/kfac.py::SplitBias),
+    whose K-FAC hooks sit on the nn.Conv2d module around this node (kfac.py:156-189)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from Net import fused
+        out = fused.conv3x3_raw(x, weight, bias, None, act=False)
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from Net import fused
+        x, weight = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if not _aligned16(g):
+            g = g.clone(memory_format=torch.contiguous_format)
+        absmax = g.abs().amax().reshape(1)                    # the gradient's scale on its way into f16 (tron_conv3x3_dgrad)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if weight.shape[1] in (32, 64):
+                gx = fused.conv3x3_dgrad(g, weight.detach(), absmax)
+            else:
+                gx = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            if fused.wgrad_supported(weight, x.shape[-1]):
+                gw = fused.conv3x3_wgrad(x, g, absmax)
+            else:                                             # (34x34: the weight gradient stays on the library)
+                gw = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
+        if ctx.needs_input_grad[2]:
+            gb = g.sum((0, 2, 3))
+        return gx, gw, gb
+
+
+class Conv3x3(torch.nn.Conv2d):
+    """nn.Conv2d(cin, cout, 3, padding=1) whose forward runs on the hand-written kernels where they cover the shape (f32
+    CUDA tensors of side 12 / 26 / 34, 32 or 64 output channels) and on the library otherwise.  Same parameters, same
+    state_dict keys, still an nn.Conv2d for whoever looks for one (KFACOptimizer's hooks and factor shapes)."""
+
+    def forward(self, x):
+        from Net import fused
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] == x.shape[-2] and x.shape[0] > 0
+                and x.shape[1] == self.in_channels and fused.supported(self, x.shape[-1]) and _aligned16(x)
+                and (self.in_channels in (3, 4, 32, 64)) and not (self.in_channels in (3, 4) and self.out_channels != 32)):
+            return _Conv3x3HIP.apply(x.contiguous(), self.weight, self.bias)
+        return super().forward(x)
+
+
 class _TrunkHIP(torch.autograd.Function):
     """conv1 .. conv6 with their two residual connections (DQNNet.py:33-50) as ONE autograd node.  Forward is the six
     layer kernels `_ConvBiasMishHIP` runs.  Backward needs the node to see the whole chain: between two layers autograd

@@ -19,13 +19,18 @@ MATH = {"f32": nat.CONV_F32, "f16x3": nat.CONV_F16X3}
 # to the f32 kernel inside the library), "f32" = the exact f32 MFMA.  TRON_CONV_MATH overrides.
 import os as _os
 default_math = _os.environ.get("TRON_CONV_MATH", "f16x3")
-_SIDES = (12, 26)            # boards 10x10 and 24x24 (BASELINE configs 2 / 3); tron_conv3x3_fwd's instantiations
+_SIDES = (12, 26)            # boards 10x10 and 24x24 (BASELINE configs 2 / 3); tron_conv3x3_fwd's instantiations in both arithmetics
+_SIDES_F16X3 = (34,)         # 32x32 boards (config 5, the ACKTR nets): forward / input gradient of the split-f16 kernel only
+
+
+def side_supported(side):
+    return side in _SIDES or (default_math == "f16x3" and side in _SIDES_F16X3)
 
 
 def supported(conv, side):
     return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
-            and conv.out_channels in (32, 64) and side in _SIDES and conv.weight.is_cuda
+            and conv.out_channels in (32, 64) and side_supported(side) and conv.weight.is_cuda
             and conv.weight.dtype == torch.float32)
 
 

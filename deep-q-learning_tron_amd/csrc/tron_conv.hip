@@ -441,7 +441,7 @@ extern "C" int tron_conv3x3_fwd(const void *in, int32_t in_fmt, const float *wei
     const bool needs_f16 = in_fmt == TRON_CONV_IN_SPLIT16 || out_split != nullptr;
     const bool f16x3 = math == TRON_CONV_F16X3 || math == TRON_CONV_F16X3_PRESPLIT;
     if (math == TRON_CONV_F16X3_PRESPLIT && !workspace) return TRON_ERR_BAD_ARG;
-    if (needs_f16 && (!f16x3 || !workspace || (side != 12 && side != 26) || cout % 16 != 0 ||
+    if (needs_f16 && (!f16x3 || !workspace || (side != 12 && side != 26 && side != 34) || cout % 16 != 0 ||
                       (in_fmt == TRON_CONV_IN_SPLIT16 && cin % 16 != 0)))
         return TRON_ERR_UNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(out_split) & 15u) return TRON_ERR_BAD_ARG;

@@ -68,12 +68,13 @@ struct Cfg {
     static constexpr int SP = S + 8;
     static constexpr int SS = S * S;
     static constexpr int P = (S * S <= 144) ? (288 / (S * S)) : 1;     // images per workgroup
-    static constexpr int NB = (S * S <= 400) ? 1 : 2;                   // row bands per image
-    static constexpr int SPLIT = NB == 1 ? S : ((S / 2) & ~1);          // band 0 = rows [0, SPLIT), band 1 = [SPLIT, S)
-    static constexpr int ROWS_MAX = NB == 1 ? S : (S - SPLIT > SPLIT ? S - SPLIT : SPLIT);
+    static constexpr int NB = (S * S <= 400) ? 1 : (S <= 26 ? 2 : 4);   // row bands per image (34x34: 8 + 8 + 8 + 10 rows)
+    static constexpr int SPLIT = NB == 1 ? S : ((S / NB) & ~1);         // band b = rows [b SPLIT, (b + 1) SPLIT), the last one up to S
+    static constexpr int LAST = S - (NB - 1) * SPLIT;                   // rows of the last band
+    static constexpr int ROWS_MAX = LAST > SPLIT ? LAST : SPLIT;
     static constexpr int PLANE = (ROWS_MAX + 2) * SP;                   // padded plane of one image's band in LDS, pixels
     static constexpr int TILES_MAX = (P * ROWS_MAX * S + 15) / 16;      // 16-pixel M tiles of the larger band
-    static constexpr int TILES_MIN = (P * (NB == 1 ? S : (SPLIT < S - SPLIT ? SPLIT : S - SPLIT)) * S + 15) / 16;
+    static constexpr int TILES_MIN = (P * (LAST < SPLIT ? LAST : SPLIT) * S + 15) / 16;
     static constexpr int MT = (TILES_MAX + NWM - 1) / NWM;              // most tiles a wave gets
     static constexpr int MT_MIN = TILES_MIN / NWM;                      // fewest: staging rides on these tile-steps
     static constexpr int IN_HALF = P * PLANE * PITCH;                   // hi (or lo) image of one input chunk
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_conv3x3_f16(
     int grp = blockIdx.x;                                               // image group (x band): PERSIST walks grp += gridDim.x
     int img0 = (grp / C::NB) * C::P;
     const int band = grp % C::NB;                                       // neighbours in the grid share an image: halo rows hit L2
-    const int r0 = band ? C::SPLIT : 0, rows = C::NB == 1 ? S : (band ? S - C::SPLIT : C::SPLIT);
+    const int r0 = band * C::SPLIT, rows = band == C::NB - 1 ? C::LAST : C::SPLIT;
     const int rpx = rows * S;                                           // pixels of one image in this region
     const int npx = C::P * rpx;
     const int tiles = (npx + 15) >> 4;
@@ -820,7 +821,7 @@ int tron_conv3x3_f16x3(const void *in, int in_fmt, const float *weight, const fl
                        int n_absmax, int presplit, hipStream_t st)
 {
     const bool small = cin == 3 || cin == 4;
-    if ((side != 12 && side != 26) || (!small && cin % CIC != 0) || !workspace) return TRON_ERR_UNSUPPORTED;
+    if ((side != 12 && side != 26 && side != 34) || (!small && cin % CIC != 0) || !workspace) return TRON_ERR_UNSUPPORTED;
     f16 *ws = reinterpret_cast<f16 *>(workspace);
     const int nchunks = (cin + CIC - 1) / CIC;
     const int total = nchunks * TAPS_PAD * cout * CIC;
@@ -837,6 +838,7 @@ int tron_conv3x3_f16x3(const void *in, int in_fmt, const float *weight, const fl
     }
     TRON_F16_CASE(12, true)
     TRON_F16_CASE(26, true)
+    TRON_F16_CASE(34, true)              // 32x32 boards (BASELINE config 5: the ACKTR nets' trunk, Net/ACNet.py)
 #undef TRON_F16_CASE
 #undef TRON_F16_ARGS
     return TRON_ERR_UNSUPPORTED;

@@ -86,7 +86,7 @@ def test_conv1_from_codes_and_from_planes(fused, S, B, cin, math, monkeypatch):
 def test_unsupported_shapes_are_reported(fused):
     from tron import _native as nat
     conv = torch.nn.Conv2d(32, 32, 3, padding=1).cuda()
-    assert fused.supported(conv, 12) and fused.supported(conv, 26) and not fused.supported(conv, 13)
+    assert fused.supported(conv, 12) and fused.supported(conv, 26) and fused.supported(conv, 34) and not fused.supported(conv, 13)
     assert not fused.supported(torch.nn.Conv2d(32, 48, 3, padding=1).cuda(), 12)
     with pytest.raises(nat.TronNativeError):
         fused.conv3x3(torch.randn(2, 32, 14, 14, device="cuda"), conv)
@@ -488,3 +488,66 @@ def test_conv3x3_wgrad_26_matches_float64(fused, cin, cout, B, magnitude):
     wd = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
     F.conv2d(x.double(), wd, padding=1).backward(gp.double())
     assert torch.equal(fused.conv3x3_wgrad(x, gp).double(), wd.grad)              # small integers: exact
+
+
+@pytest.mark.parametrize("S,B", [(34, 1), (34, 6), (34, 67), (34, 300)])   # 300 x 4 bands: several groups per persistent workgroup
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64), (64, 32), (3, 32), (4, 32)])
+def test_conv3x3_side_34_matches_float64(fused, S, B, cin, cout):
+    """32x32 boards (BASELINE config 5, the ACKTR nets' trunk): the split-f16 kernel with four row bands per image —
+    forward with bias / residual / activation, and the input gradient."""
+    if cin <= 4 and B > 67:
+        pytest.skip("conv1: one size is enough")
+    torch.manual_seed(S + B + cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
+    assert fused.supported(conv, 34)
+    x = torch.randn(B, cin, S, S, device="cuda")
+    res = torch.randn(B, cout, S, S, device="cuda")
+    for r, act in ((res, True), (None, False)):
+        got, pre = fused.conv3x3(x, conv, residual=r, act=act, want_pre=True)
+        ref_pre, ref = _ref(x, conv, r, act)
+        assert (pre.double() - ref_pre).abs().max().item() < TOL
+        assert (got.double() - ref).abs().max().item() < TOL
+    with torch.no_grad():
+        conv.weight.copy_(torch.arange(conv.weight.numel(), device="cuda").reshape(conv.weight.shape).float() % 17 - 8)
+    x = torch.zeros(B, cin, S, S, device="cuda")
+    for row in (0, 7, 8, 15, 16, 23, 24, 33):                              # both sides of every band edge
+        x[:, 1, row, (row * 5) % S] = 1.0 + row
+    x[:, cin - 1, S - 1, 0] = 2.0
+    assert torch.equal(fused.conv3x3(x, conv, act=False), F.conv2d(x, conv.weight, conv.bias, padding=1))   # small integers: exact
+    if cin >= 32:
+        for magnitude in (1.0, 1e-7):
+            gp = torch.randn(B, cout, S, S, device="cuda") * magnitude
+            xd = torch.zeros(B, cin, S, S, dtype=torch.float64, device="cuda", requires_grad=True)
+            F.conv2d(xd, conv.weight.double(), padding=1).backward(gp.double())
+            got = fused.conv3x3_dgrad(gp, conv.weight.detach(), gp.abs().amax().reshape(1))
+            assert (got.double() - xd.grad).abs().max().item() / xd.grad.abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("S,B,cin,cout", [(12, 9, 3, 32), (12, 40, 32, 64), (26, 5, 64, 64), (34, 3, 4, 32), (34, 4, 32, 32), (34, 5, 64, 64),
+                                          (14, 3, 32, 32), (12, 3, 32, 48)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_conv3x3_module_matches_float64_conv2d(fused, S, B, cin, cout, bias):
+    """Net/activations.py::Conv3x3 — the nn.Conv2d of the ACKTR nets (ACNet.py:97-116) with forward, input gradient and
+    weight gradient on the hand-written kernels (the weight gradient on the library at 34x34); shapes they do not cover
+    (side 14, 48 channels) run the library convolution."""
+    from Net.activations import Conv3x3
+    torch.manual_seed(S + B + cin + cout)
+    m = Conv3x3(cin, cout, 3, padding=1, bias=bias).cuda()
+    ref = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=bias).cuda().double()
+    ref.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    x = torch.randn(B, cin, S, S, device="cuda", requires_grad=True)
+    xd = x.detach().double().requires_grad_(True)
+    g = torch.randn(B, cout, S, S, device="cuda") * 1e-3
+    y, yd = m(x), ref(xd)
+    assert (y.double() - yd).abs().max().item() < TOL
+    y.backward(g)
+    yd.backward(g.double())
+    for got, want in [(x.grad, xd.grad), (m.weight.grad, ref.weight.grad)] + ([(m.bias.grad, ref.bias.grad)] if bias else []):
+        assert (got.double() - want).abs().max().item() / want.abs().max().item() < 1e-5
+    # K-FAC's hooks sit on the module: they see the input and the output gradient as with the library convolution
+    seen = {}
+    m.register_forward_pre_hook(lambda mod, inp: seen.__setitem__("a", inp[0]))
+    m.register_full_backward_hook(lambda mod, gi, go: seen.__setitem__("g", go[0]))
+    x2 = x.detach().clone().requires_grad_(True)
+    m(x2).backward(g)
+    assert torch.equal(seen["a"], x2) and torch.equal(seen["g"], g)
