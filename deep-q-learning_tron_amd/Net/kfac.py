@@ -86,6 +86,50 @@ def extract_patches(a, kernel_size, padding, stride):
     return cols.transpose(1, 2).reshape(-1, cols.size(1))
 
 
+# The input factors on the hand-written Gram kernels (csrc/tron_kfac.hip: split-f16 matrix cores, upper triangle only) instead
+# of extract_patches + an f32 library GEMM; TRON_KFAC_GRAM=0 keeps the library path (A/B measurements).
+import os as _os
+use_gram = _os.environ.get("TRON_KFAC_GRAM", "1") != "0"
+
+
+def _gram_hip(a, module, scale):
+    """scale * P^T P for a conv layer's input a [B, C, H, W] (P = its patch matrix) or scale * a^T a for a Linear layer's
+    [rows, d], on csrc/tron_kfac.hip; None where that does not apply (CPU tensors, tiny factors)."""
+    if not (use_gram and a.is_cuda and a.dtype == torch.float32 and a.numel() > 0):
+        return None
+    from tron import _native as nat
+    L = nat.lib()
+    a = a.contiguous()
+    if a.data_ptr() % 16:
+        a = a.clone()
+    if isinstance(module, nn.Conv2d):
+        if a.dim() != 4 or module.padding[0] != module.padding[1] or module.stride[0] != module.stride[1] or module.dilation != (1, 1):
+            return None
+        B, C, H, W = a.shape
+        kh, kw = module.kernel_size
+        d = C * kh * kw
+        nbytes = int(L.tron_kfac_patch_gram_workspace(B, C, H, W, kh, kw, module.padding[0], module.stride[0]))
+        if nbytes <= 0:
+            return None
+        gram = torch.empty(d, d, dtype=torch.float32, device=a.device)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+        with torch.cuda.device(a.device):
+            nat.check(L.tron_kfac_patch_gram(nat.ptr(a), B, C, H, W, kh, kw, module.padding[0], module.stride[0], float(scale),
+                                             nat.ptr(gram), nat.ptr(ws), nat.stream_ptr()), "tron_kfac_patch_gram")
+        return gram
+    if a.dim() != 2 or a.shape[1] < 32 or a.shape[0] < 512:
+        return None
+    rows, d = a.shape
+    nbytes = int(L.tron_kfac_gram_workspace(rows, d))
+    if nbytes <= 0:
+        return None
+    gram = torch.empty(d, d, dtype=torch.float32, device=a.device)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device):
+        nat.check(L.tron_kfac_gram(nat.ptr(a), rows, d, float(scale), nat.ptr(gram), nat.ptr(ws), nat.stream_ptr()), "tron_kfac_gram")
+    return gram
+
+
 def cov_inputs(a, module, batch=None):
     """A-factor sample of one batch (kfac.py:41-58).  `batch` = size of the WHOLE batch when `a` is
     only a micro-batch of it (the result is then this micro-batch's additive share)."""
@@ -95,6 +139,9 @@ def cov_inputs(a, module, batch=None):
         oh = (a.size(2) + 2 * module.padding[0] - module.kernel_size[0]) // module.stride[0] + 1
         ow = (a.size(3) + 2 * module.padding[1] - module.kernel_size[1]) // module.stride[1] + 1
         d = a.size(1) * module.kernel_size[0] * module.kernel_size[1]
+        got = _gram_hip(a, module, 1.0 / (batch * float(oh * ow) ** 2))
+        if got is not None:
+            return got
         if a.is_cuda:
             # rows/(oh*ow) then rows^T (rows/batch) of the reference is P^T P / (batch (oh ow)^2): the patch
             # matrix goes into the GEMM unscaled, in chunks of <= 1 GB so 16 384 envs x 5 steps stay bounded
@@ -116,7 +163,8 @@ def cov_inputs(a, module, batch=None):
         return acc
     if isinstance(module, AddBias):
         return torch.full((1, 1), share, device=a.device, dtype=a.dtype)   # ones(B,1)^T ones(B,1) / B
-    return a.t() @ (a / batch)
+    got = _gram_hip(a, module, 1.0 / batch)
+    return got if got is not None else a.t() @ (a / batch)
 
 
 def cov_grads(g, module, batch=None):

@@ -63,3 +63,335 @@ extern "C" int tron_extract_patches(const float *x, int64_t batch, int32_t chann
                        reinterpret_cast<hipStream_t>(stream), x, channels, height, width, kh, kw, pad, stride, OH, OW, out);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
+
+// ---- the input factor itself: gram = P^T P (kfac.py:41-58 `compute_cov_a`: a.t() @ (a / batch_size)) -----------------------
+// The factor of a convolution is the Gram matrix of its patch matrix P [batch * OH * OW][d = C kh kw] — at 16 384 envs x 32x32
+// with five rollout steps that is 95 M rows per layer and update, and as `extract_patches` + an f32 library GEMM it was 60 % of
+// an ACKTR iteration (profiles/r03_acktr_config5_kernel_rows.txt: 112 TFLOP/s).  Here the product runs on the f16 matrix cores
+// with both operands split in two halves (v / 64 = hi + lo 2^-11: three MFMAs per 32-deep slab, f32 accumulation; the error
+// analysis is csrc/tron_conv_f16.hip's) and only the tiles on and above the diagonal are computed:
+//   k_patches_t      x -> P^T as split f16 [d padded to 64][rows padded to 64] (K = rows contiguous: what both MFMA operands
+//                    want), a thread = 8 consecutive output positions of one patch column, 16-byte stores
+//   k_transpose_split  the same for a Linear layer's input a [rows][d]: a^T split, through an LDS tile
+//   k_gram_f16x3     partial[s] += X X^T over K range s of the chunk: 128 x 64 tiles, 8 waves, K chunks of 64 through LDS
+//                    (csrc/tron_head.hip's GEMM loop); blockIdx = (tile, K split) so that small d still fills the chip
+//   k_gram_finish    gram[i][j] = scale * sum_s partial[s][min(i,j)][max(i,j)]          (fixed order: deterministic)
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float ACT_SCALE = 1.0f / 64.0f, LO_SCALE = 2048.0f, LO_UNSCALE = 1.0f / 2048.0f;
+constexpr float GRAM_UNSCALE = 4096.0f;            // both operands carry 2^-6
+
+__device__ __forceinline__ void split(float v, f16 &hi, f16 &lo)
+{
+    hi = (f16)v;
+    lo = (f16)((v - (float)hi) * LO_SCALE);
+}
+
+__global__ __launch_bounds__(256) void k_patches_t(const float *__restrict__ x, int n_img, int C, int H, int W, int kh, int kw,
+                                                   int pad, int stride, int OH, int OW, int d, int dpad, int64_t rows,
+                                                   int64_t rows_pad, f16 *__restrict__ xh, f16 *__restrict__ xl)
+{
+    const int64_t groups = rows_pad / 8, total = (int64_t)dpad * groups;
+    for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(item / groups);
+        const int64_t r0 = (item - (int64_t)j * groups) * 8;
+        f16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = l[e] = (f16)0.0f;
+        if (j < d && r0 < rows) {
+            const int c = j / (kh * kw), t = j - c * (kh * kw), ky = t / kw, kx = t - ky * kw;
+            int64_t b = r0 / (OH * OW);
+            int rem = (int)(r0 - b * (OH * OW)), oy = rem / OW, ox = rem - oy * OW;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (r0 + e < rows) {
+                    const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                    float v = 0.0f;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)b * C + c) * H + iy) * W + ix];
+                    f16 hh, ll;
+                    split(v * ACT_SCALE, hh, ll);
+                    h[e] = hh;
+                    l[e] = ll;
+                }
+                if (++ox == OW) { ox = 0; if (++oy == OH) { oy = 0; ++b; } }
+            }
+        }
+        *reinterpret_cast<f16x8 *>(xh + (size_t)j * rows_pad + r0) = h;
+        *reinterpret_cast<f16x8 *>(xl + (size_t)j * rows_pad + r0) = l;
+    }
+}
+
+// a f32 [rows][d] -> a^T split [dpad][rows_pad]; a workgroup = a 64 x 64 tile through LDS (reads along d, writes along rows)
+__global__ __launch_bounds__(256) void k_transpose_split(const float *__restrict__ a, int64_t rows, int d, int dpad, int64_t rows_pad,
+                                                         f16 *__restrict__ xh, f16 *__restrict__ xl)
+{
+    __shared__ float tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int j0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int rr = i >> 6, jj = i & 63;
+        tile[rr][jj] = (r0 + rr < rows && j0 + jj < d) ? a[(size_t)(r0 + rr) * d + j0 + jj] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {                   // (column jj, 8 consecutive rows)
+        const int jj = i >> 3, g = i & 7;
+        f16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            f16 hh, ll;
+            split(tile[g * 8 + e][jj] * ACT_SCALE, hh, ll);
+            h[e] = hh;
+            l[e] = ll;
+        }
+        *reinterpret_cast<f16x8 *>(xh + (size_t)(j0 + jj) * rows_pad + r0 + g * 8) = h;
+        *reinterpret_cast<f16x8 *>(xl + (size_t)(j0 + jj) * rows_pad + r0 + g * 8) = l;
+    }
+}
+
+constexpr int GM = 128, GN = 64, GK = 64;
+constexpr int GPITCH = GK * 2 + 32;                // LDS row pitch in bytes: conflict-free ds_read_b128 (tron_head.hip)
+constexpr int G_THREADS = 512;
+constexpr int A_HALF = GM * GPITCH, W_HALF = GN * GPITCH;
+constexpr int G_LDS = 2 * A_HALF + 2 * W_HALF;     // 61 440 bytes: two workgroups per CU
+
+__global__ __launch_bounds__(G_THREADS, 4) void k_gram_f16x3(const f16 *__restrict__ Xh, const f16 *__restrict__ Xl, int d, int dpad,
+                                                             int64_t pitch, int nk, int ksplit, float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *a_h = lds, *a_l = lds + A_HALF, *w_h = lds + 2 * A_HALF, *w_l = w_h + W_HALF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 3, wn = wave >> 2, li = lane & 15, g = lane >> 4;
+    const int nblocks = dpad / GN, ntiles = ((d + GM - 1) / GM) * nblocks;
+    const int tile = blockIdx.x % ntiles, s = blockIdx.x / ntiles;
+    const int m0 = (tile / nblocks) * GM, n0 = (tile % nblocks) * GN;
+    if (n0 + GN <= m0) return;                                          // strictly below the diagonal: k_gram_finish mirrors
+    const int k_lo = (int)((int64_t)nk * s / ksplit), k_hi = (int)((int64_t)nk * (s + 1) / ksplit);
+    if (k_lo >= k_hi) return;
+
+    f32x4 ra[4], rw[2];
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = tid + j * G_THREADS, half = q >> 10, r = q & 1023, row = r >> 3, pc = r & 7;
+            int m = m0 + row;
+            m = m < dpad ? m : dpad - 1;
+            ra[j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(half ? Xl : Xh) +
+                                                     ((size_t)m * pitch + (size_t)kc * GK) * 2 + pc * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = tid + j * G_THREADS, half = q >> 9, r = q & 511, row = r >> 3, pc = r & 7;
+            rw[j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(half ? Xl : Xh) +
+                                                     ((size_t)(n0 + row) * pitch + (size_t)kc * GK) * 2 + pc * 16);
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = tid + j * G_THREADS, half = q >> 10, r = q & 1023, row = r >> 3, pc = r & 7;
+            *reinterpret_cast<f32x4 *>(lds + half * A_HALF + row * GPITCH + pc * 16) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = tid + j * G_THREADS, half = q >> 9, r = q & 511, row = r >> 3, pc = r & 7;
+            *reinterpret_cast<f32x4 *>(lds + 2 * A_HALF + half * W_HALF + row * GPITCH + pc * 16) = rw[j];
+        }
+    };
+
+    f32x4 acc0[2][2], acc1[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            acc0[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc1[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    const int a_off = (wm * 32 + li) * GPITCH + g * 16, b_off = (wn * 32 + li) * GPITCH + g * 16;
+    load_chunk(k_lo);
+    store_chunk();
+    __syncthreads();
+    for (int kc = k_lo; kc < k_hi; ++kc) {
+        if (kc + 1 < k_hi) load_chunk(kc + 1);                          // in flight under the MFMAs
+#pragma unroll
+        for (int sl = 0; sl < GK / 32; ++sl) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const f16x8 *>(a_h + a_off + t * 16 * GPITCH + sl * 64);
+                al[t] = *reinterpret_cast<const f16x8 *>(a_l + a_off + t * 16 * GPITCH + sl * 64);
+                bh[t] = *reinterpret_cast<const f16x8 *>(w_h + b_off + t * 16 * GPITCH + sl * 64);
+                bl[t] = *reinterpret_cast<const f16x8 *>(w_l + b_off + t * 16 * GPITCH + sl * 64);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc1[t][n], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc0[t][n], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc1[t][n], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kc + 1 < k_hi) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+    // D row = 4 * (lane >> 4) + r, column = lane & 15; this split's partial sums are added to what earlier chunks left
+    float *out = partial + (size_t)s * d * dpad;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = n0 + wn * 32 + n * 16 + li;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 v = (acc0[t][n] + acc1[t][n] * LO_UNSCALE) * GRAM_UNSCALE;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + t * 16 + 4 * g + r;
+                if (m < d) out[(size_t)m * dpad + col] += v[r];
+            }
+        }
+    }
+}
+
+__global__ void k_gram_finish(const float *__restrict__ partial, int ksplit, int d, int dpad, float scale, float *__restrict__ gram)
+{
+    const int64_t total = (int64_t)d * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / d), c = (int)(i - (int64_t)r * d);
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+        float sum = 0.0f;
+        for (int s = 0; s < ksplit; ++s) sum += partial[((size_t)s * d + lo) * dpad + hi];
+        gram[i] = sum * scale;
+    }
+}
+
+constexpr int64_t GRAM_CHUNK_BYTES = 512ll << 20;   // the split transposed operand of one pass
+
+struct GramPlan {
+    int dpad, ksplit;
+    int64_t rows_chunk, x_bytes, partial_bytes, total;   // rows per pass (multiple of 64), bytes of one half of X
+};
+inline GramPlan gram_plan(int64_t rows_total, int64_t rows_unit, int d)
+{
+    GramPlan p;
+    p.dpad = (d + 63) / 64 * 64;
+    int64_t rows = GRAM_CHUNK_BYTES / (4 * (int64_t)p.dpad);            // hi + lo, 2 bytes each
+    rows = rows / rows_unit * rows_unit;                                // whole images per pass
+    if (rows < rows_unit) rows = rows_unit;
+    if (rows > rows_total) rows = (rows_total + rows_unit - 1) / rows_unit * rows_unit;
+    p.rows_chunk = (rows + 63) / 64 * 64;
+    const int nblocks = p.dpad / GN, mt = (d + GM - 1) / GM;
+    int upper = 0;
+    for (int bm = 0; bm < mt; ++bm)
+        for (int bn = 0; bn < nblocks; ++bn) upper += (bn * GN + GN > bm * GM);
+    int ks = 2048 / (upper > 0 ? upper : 1);                            // ~8 workgroups per CU in flight over the launch
+    const int64_t nk = p.rows_chunk / GK;
+    if (ks > nk / 16) ks = (int)(nk / 16);                              // a split walks at least 16 K chunks
+    if (ks < 1) ks = 1;
+    if (ks > 256) ks = 256;
+    p.ksplit = ks;
+    p.x_bytes = (int64_t)p.dpad * p.rows_chunk * 2;
+    p.partial_bytes = (int64_t)ks * d * p.dpad * 4;
+    p.total = 2 * p.x_bytes + p.partial_bytes + 512;
+    return p;
+}
+
+int gram_pass(const f16 *xh, const f16 *xl, const GramPlan &p, int d, int64_t rows_pad, float *partial, hipStream_t st)
+{
+    static uint64_t prepared = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
+    if (!(prepared & (1ull << (dev & 63)))) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gram_f16x3), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) != hipSuccess)
+            (void)hipGetLastError();
+        prepared |= 1ull << (dev & 63);
+    }
+    const int ntiles = ((d + GM - 1) / GM) * (p.dpad / GN);
+    hipLaunchKernelGGL(k_gram_f16x3, dim3((unsigned)(ntiles * p.ksplit)), dim3(G_THREADS), G_LDS, st, xh, xl, d, p.dpad, rows_pad,
+                       (int)(rows_pad / GK), p.ksplit, partial);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int64_t tron_kfac_patch_gram_workspace(int64_t batch, int32_t channels, int32_t height, int32_t width, int32_t kh,
+                                                  int32_t kw, int32_t pad, int32_t stride)
+{
+    if (batch < 1 || channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad < 0 || stride < 1) return 0;
+    const int OH = (height + 2 * pad - kh) / stride + 1, OW = (width + 2 * pad - kw) / stride + 1;
+    if (OH < 1 || OW < 1 || (int64_t)channels * kh * kw > 8192) return 0;
+    return gram_plan(batch * OH * OW, (int64_t)OH * OW, channels * kh * kw).total;
+}
+
+extern "C" int tron_kfac_patch_gram(const float *x, int64_t batch, int32_t channels, int32_t height, int32_t width, int32_t kh,
+                                    int32_t kw, int32_t pad, int32_t stride, float scale, float *gram, void *workspace, void *stream)
+{
+    if (!x || !gram || !workspace || batch < 0 || channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad < 0 || stride < 1)
+        return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(gram)) & 15u) return TRON_ERR_BAD_ARG;
+    const int OH = (height + 2 * pad - kh) / stride + 1, OW = (width + 2 * pad - kw) / stride + 1;
+    if (OH < 1 || OW < 1) return TRON_ERR_BAD_ARG;
+    const int d = channels * kh * kw;
+    if (d > 8192) return TRON_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (batch == 0) return hipMemsetAsync(gram, 0, (size_t)d * d * sizeof(float), st) == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+    const int64_t per = (int64_t)OH * OW;
+    const GramPlan p = gram_plan(batch * per, per, d);
+    unsigned char *wsb = reinterpret_cast<unsigned char *>(workspace);
+    f16 *xh = reinterpret_cast<f16 *>(wsb), *xl = reinterpret_cast<f16 *>(wsb + p.x_bytes);
+    float *partial = reinterpret_cast<float *>(wsb + 2 * p.x_bytes);
+    if (hipMemsetAsync(partial, 0, (size_t)p.partial_bytes, st) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_LAUNCH; }
+    const int64_t imgs_chunk = p.rows_chunk / per > 0 ? p.rows_chunk / per : 1;
+    for (int64_t i = 0; i < batch; i += imgs_chunk) {
+        const int64_t n = batch - i < imgs_chunk ? batch - i : imgs_chunk;
+        const int64_t rows = n * per, rows_pad = (rows + 63) / 64 * 64;
+        const int64_t items = (int64_t)p.dpad * (rows_pad / 8);
+        const unsigned blocks = (unsigned)(items / 256 + 1 < 65536 * 8 ? items / 256 + 1 : 65536 * 8);
+        hipLaunchKernelGGL(k_patches_t, dim3(blocks), dim3(256), 0, st, x + (size_t)i * channels * height * width, (int)n, channels,
+                           height, width, kh, kw, pad, stride, OH, OW, d, p.dpad, rows, rows_pad, xh, xl);
+        const int rc = gram_pass(xh, xl, p, d, rows_pad, partial, st);
+        if (rc != TRON_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_gram_finish, dim3((unsigned)(((int64_t)d * d + 255) / 256 < 4096 ? ((int64_t)d * d + 255) / 256 : 4096)), dim3(256),
+                       0, st, partial, p.ksplit, d, p.dpad, scale, gram);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int64_t tron_kfac_gram_workspace(int64_t rows, int32_t d)
+{
+    if (rows < 1 || d < 1 || d > 8192) return 0;
+    return gram_plan(rows, 64, d).total;
+}
+
+extern "C" int tron_kfac_gram(const float *a, int64_t rows, int32_t d, float scale, float *gram, void *workspace, void *stream)
+{
+    if (!a || !gram || !workspace || rows < 0 || d < 1) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(gram)) & 15u) return TRON_ERR_BAD_ARG;
+    if (d > 8192) return TRON_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (rows == 0) return hipMemsetAsync(gram, 0, (size_t)d * d * sizeof(float), st) == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+    const GramPlan p = gram_plan(rows, 64, d);
+    unsigned char *wsb = reinterpret_cast<unsigned char *>(workspace);
+    f16 *xh = reinterpret_cast<f16 *>(wsb), *xl = reinterpret_cast<f16 *>(wsb + p.x_bytes);
+    float *partial = reinterpret_cast<float *>(wsb + 2 * p.x_bytes);
+    if (hipMemsetAsync(partial, 0, (size_t)p.partial_bytes, st) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_LAUNCH; }
+    for (int64_t i = 0; i < rows; i += p.rows_chunk) {
+        const int64_t n = rows - i < p.rows_chunk ? rows - i : p.rows_chunk, rows_pad = (n + 63) / 64 * 64;
+        hipLaunchKernelGGL(k_transpose_split, dim3((unsigned)(rows_pad / 64), (unsigned)(p.dpad / 64)), dim3(256), 0, st,
+                           a + (size_t)i * d, n, d, p.dpad, rows_pad, xh, xl);
+        const int rc = gram_pass(xh, xl, p, d, rows_pad, partial, st);
+        if (rc != TRON_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_gram_finish, dim3((unsigned)(((int64_t)d * d + 255) / 256 < 4096 ? ((int64_t)d * d + 255) / 256 : 4096)), dim3(256),
+                       0, st, partial, p.ksplit, d, p.dpad, scale, gram);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}

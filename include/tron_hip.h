@@ -250,6 +250,18 @@ int tron_minimax_codes(const int8_t *codes, int64_t n, int32_t side, int32_t dep
  * channels*kh*(width+2*pad)*4 bytes must fit 64 KB of LDS (else TRON_ERR_UNSUPPORTED).           */
 int tron_extract_patches(const float *x, int64_t batch, int32_t channels, int32_t height, int32_t width,
                          int32_t kh, int32_t kw, int32_t pad, int32_t stride, float *out, void *stream);
+/* K-FAC's input factor of one layer and batch (kfac.py:41-58 `compute_cov_a`): gram f32[d][d] = scale * P^T P, overwritten,
+ * P = the patch matrix above ([batch*OH*OW][d = channels*kh*kw]) — never materialised as f32: its transpose is written
+ * as split f16 (v / 64 = hi + lo 2^-11) in passes of <= 512 MB and multiplied on the f16 matrix cores (three MFMAs per
+ * slab, f32 accumulation, relative error ~1e-6), tiles on and above the diagonal only, K split over workgroups, sums in a
+ * fixed order.  tron_kfac_gram: the same for a Linear layer's input a f32[rows][d] (gram = scale * a^T a).  d <= 8192;
+ * workspace: tron_kfac_*_workspace(...) bytes (0 = not supported), 16-byte aligned.                              */
+int tron_kfac_patch_gram(const float *x, int64_t batch, int32_t channels, int32_t height, int32_t width, int32_t kh,
+                         int32_t kw, int32_t pad, int32_t stride, float scale, float *gram, void *workspace, void *stream);
+int64_t tron_kfac_patch_gram_workspace(int64_t batch, int32_t channels, int32_t height, int32_t width, int32_t kh,
+                                       int32_t kw, int32_t pad, int32_t stride);
+int tron_kfac_gram(const float *a, int64_t rows, int32_t d, float scale, float *gram, void *workspace, void *stream);
+int64_t tron_kfac_gram_workspace(int64_t rows, int32_t d);
 
 /* ---- the nets' activation (Net/ACNet.py:56-57: x * tanh(softplus(x))) as one pass each way --------- */
 /* y[i] = mish(x[i]); f32, 16-byte aligned buffers, n elements.                                        */

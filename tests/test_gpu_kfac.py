@@ -71,6 +71,92 @@ def test_cov_inputs_gpu_matches_cpu(C, side, k, pad, stride):
     assert torch.allclose(parts.cpu(), want, rtol=1e-4, atol=1e-6)
 
 
+GRAM_SHAPES = [  # B, C, H, W, k, pad, stride
+    (5, 3, 12, 12, 3, 1, 1),      # conv1 at 10x10 (d = 27: one ragged tile)
+    (9, 4, 34, 34, 3, 1, 1),      # conv1 of MapNet at 32x32
+    (40, 32, 12, 12, 3, 1, 1),    # d = 288
+    (3, 32, 26, 26, 3, 1, 1),
+    (6, 64, 34, 34, 3, 1, 1),     # d = 576, 6 936 rows
+    (7, 64, 17, 17, 7, 3, 2),     # conv7 after the pool at 32x32: d = 3 136
+    (64, 64, 6, 6, 7, 3, 2),      # conv7 at 10x10: 9 rows per image
+    (7, 5, 9, 11, 3, 0, 1),       # no padding, odd sizes, non-square
+    (1, 1, 3, 3, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("B,C,H,W,k,pad,stride", GRAM_SHAPES)
+def test_patch_gram_matches_float64(B, C, H, W, k, pad, stride):
+    """tron_kfac_patch_gram == P^T P of F.unfold's patch matrix in float64 (relative to the largest entry), symmetric
+    bit for bit (the lower triangle is the mirrored upper one), the same bits when run again."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from Net import kfac
+    torch.manual_seed(B * 100 + C)
+    x = torch.randn(B, C, H, W, device="cuda") * 2.0
+    conv = nn.Conv2d(C, 8, k, padding=pad, stride=stride)
+    got = kfac._gram_hip(x, conv, 0.5)
+    cols = F.unfold(x.double(), (k, k), padding=pad, stride=stride)
+    P = cols.transpose(1, 2).reshape(-1, cols.size(1))
+    want = 0.5 * (P.t() @ P)
+    assert got.shape == want.shape
+    assert (got.double() - want).abs().max().item() / want.abs().max().item() < 2e-6
+    assert torch.equal(got, got.t())
+    assert torch.equal(got, kfac._gram_hip(x, conv, 0.5))
+
+
+@pytest.mark.parametrize("rows,d", [(512, 32), (1000, 129), (4096, 256), (8192, 576), (3000, 5184), (700, 257)])
+def test_linear_gram_matches_float64(rows, d):
+    """tron_kfac_gram (a Linear layer's input factor, kfac.py:57-58) == a^T a in float64."""
+    import torch.nn as nn
+    from Net import kfac
+    torch.manual_seed(rows + d)
+    a = torch.randn(rows, d, device="cuda") * 3.0
+    got = kfac._gram_hip(a, nn.Linear(d, 4), 1.0 / rows)
+    want = a.double().t() @ a.double() / rows
+    assert (got.double() - want).abs().max().item() / want.abs().max().item() < 2e-6
+    assert torch.equal(got, got.t())
+
+
+def test_gram_over_several_passes_and_bad_arguments():
+    """A patch matrix larger than one 512 MB pass (here 64-channel 34x34 inputs: 1.3 GB split) goes through the kernel in
+    passes whose partial sums add up: the factor of a batch == the sum of the factors of its halves, each a single pass."""
+    import torch.nn as nn
+    from Net import kfac
+    from tron import _native as nat
+    torch.manual_seed(11)
+    conv = nn.Conv2d(64, 64, 3, padding=1)
+    x = torch.randn(500, 64, 34, 34, device="cuda")
+    whole = kfac._gram_hip(x, conv, 1.0)
+    halves = kfac._gram_hip(x[:200], conv, 1.0) + kfac._gram_hip(x[200:], conv, 1.0)
+    assert (whole - halves).abs().max().item() / whole.abs().max().item() < 1e-6
+    L = nat.lib()
+    assert L.tron_kfac_gram_workspace(100, 9000) == 0 and L.tron_kfac_patch_gram_workspace(0, 3, 12, 12, 3, 3, 1, 1) == 0
+    g = torch.empty(27, 27, device="cuda")
+    ws = torch.empty(int(L.tron_kfac_patch_gram_workspace(4, 3, 12, 12, 3, 3, 1, 1)), dtype=torch.uint8, device="cuda")
+    xs = torch.randn(4, 3, 12, 12, device="cuda")
+    assert L.tron_kfac_patch_gram(None, 4, 3, 12, 12, 3, 3, 1, 1, 1.0, nat.ptr(g), nat.ptr(ws), None) == nat.ERR_BAD_ARG
+    assert L.tron_kfac_patch_gram(nat.ptr(xs), 4, 3, 12, 12, 3, 3, 1, 0, 1.0, nat.ptr(g), nat.ptr(ws), None) == nat.ERR_BAD_ARG
+    assert L.tron_kfac_patch_gram(nat.ptr(xs), 0, 3, 12, 12, 3, 3, 1, 1, 1.0, nat.ptr(g), nat.ptr(ws), None) == 0
+    torch.cuda.synchronize()
+    assert torch.count_nonzero(g) == 0                                   # the sum over nothing
+
+
+def test_cov_inputs_uses_the_gram_kernels_and_matches_the_library_path(monkeypatch):
+    """Net/kfac.py::cov_inputs with and without csrc/tron_kfac.hip's Gram kernels, whole batch and micro-batches."""
+    import torch.nn as nn
+    from Net import kfac
+    torch.manual_seed(2)
+    conv = nn.Conv2d(32, 8, 3, padding=1)
+    lin = nn.Linear(300, 7)
+    a, b = torch.randn(600, 32, 12, 12, device="cuda"), torch.randn(2048, 300, device="cuda")
+    got_a, got_b = kfac.cov_inputs(a, conv), kfac.cov_inputs(b, lin)
+    parts = sum(kfac.cov_inputs(a[i:i + 200], conv, 600) for i in range(0, 600, 200))
+    monkeypatch.setattr(kfac, "use_gram", False)
+    want_a, want_b = kfac.cov_inputs(a, conv), kfac.cov_inputs(b, lin)
+    for got, want in ((got_a, want_a), (got_b, want_b), (parts, want_a)):
+        assert (got - want).abs().max().item() / want.abs().max().item() < 1e-5
+
+
 def test_mish_kernels_match_the_composed_form():
     """csrc/tron_nn.hip: mish forward / backward against x * tanh(softplus(x)) and its autograd gradient
     evaluated in float64, over the whole input range (incl. the > 20 cut-over and deep negatives)."""
