@@ -150,7 +150,8 @@ class _Conv3x3HIP(torch.autograd.Function):
         g = grad_out.contiguous()
         if not _aligned16(g):
             g = g.clone(memory_format=torch.contiguous_format)
-        absmax = g.abs().amax().reshape(1)                    # the gradient's scale on its way into f16 (tron_conv3x3_dgrad)
+        lo, hi = torch.aminmax(g)                             # one pass: the gradient's scale on its way into f16 (tron_conv3x3_dgrad)
+        absmax = torch.maximum(hi, -lo).reshape(1)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if weight.shape[1] in (32, 64):

@@ -92,9 +92,11 @@ import os as _os
 use_gram = _os.environ.get("TRON_KFAC_GRAM", "1") != "0"
 
 
-def _gram_hip(a, module, scale):
-    """scale * P^T P for a conv layer's input a [B, C, H, W] (P = its patch matrix) or scale * a^T a for a Linear layer's
-    [rows, d], on csrc/tron_kfac.hip; None where that does not apply (CPU tensors, tiny factors)."""
+def _gram_hip(a, module, scale, geometry=None, in_scale=None):
+    """scale * P^T P for a conv layer's input a [B, C, H, W] (P = its patch matrix; geometry = (kh, kw, pad, stride),
+    default the module's) or scale * a^T a for a Linear layer's [rows, d], on csrc/tron_kfac.hip; None where that does not
+    apply (CPU tensors, tiny factors).  in_scale: a device scalar (a power of two) the input is multiplied by on its way
+    into f16 — gradient tensors."""
     if not (use_gram and a.is_cuda and a.dtype == torch.float32 and a.numel() > 0):
         return None
     from tron import _native as nat
@@ -102,19 +104,21 @@ def _gram_hip(a, module, scale):
     a = a.contiguous()
     if a.data_ptr() % 16:
         a = a.clone()
-    if isinstance(module, nn.Conv2d):
-        if a.dim() != 4 or module.padding[0] != module.padding[1] or module.stride[0] != module.stride[1] or module.dilation != (1, 1):
-            return None
+    if a.dim() == 4:
+        if geometry is None:
+            if module.padding[0] != module.padding[1] or module.stride[0] != module.stride[1] or module.dilation != (1, 1):
+                return None
+            geometry = (module.kernel_size[0], module.kernel_size[1], module.padding[0], module.stride[0])
         B, C, H, W = a.shape
-        kh, kw = module.kernel_size
+        kh, kw, pad, stride = geometry
         d = C * kh * kw
-        nbytes = int(L.tron_kfac_patch_gram_workspace(B, C, H, W, kh, kw, module.padding[0], module.stride[0]))
+        nbytes = int(L.tron_kfac_patch_gram_workspace(B, C, H, W, kh, kw, pad, stride))
         if nbytes <= 0:
             return None
         gram = torch.empty(d, d, dtype=torch.float32, device=a.device)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
         with torch.cuda.device(a.device):
-            nat.check(L.tron_kfac_patch_gram(nat.ptr(a), B, C, H, W, kh, kw, module.padding[0], module.stride[0], float(scale),
+            nat.check(L.tron_kfac_patch_gram(nat.ptr(a), B, C, H, W, kh, kw, pad, stride, float(scale), nat.ptr(in_scale),
                                              nat.ptr(gram), nat.ptr(ws), nat.stream_ptr()), "tron_kfac_patch_gram")
         return gram
     if a.dim() != 2 or a.shape[1] < 32 or a.shape[0] < 512:
@@ -126,8 +130,19 @@ def _gram_hip(a, module, scale):
     gram = torch.empty(d, d, dtype=torch.float32, device=a.device)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
     with torch.cuda.device(a.device):
-        nat.check(L.tron_kfac_gram(nat.ptr(a), rows, d, float(scale), nat.ptr(gram), nat.ptr(ws), nat.stream_ptr()), "tron_kfac_gram")
+        nat.check(L.tron_kfac_gram(nat.ptr(a), rows, d, float(scale), nat.ptr(in_scale), nat.ptr(gram), nat.ptr(ws), nat.stream_ptr()),
+                  "tron_kfac_gram")
     return gram
+
+
+def _pow2_scale(g):
+    """A device scalar 2^k that brings max |g| to [2^9, 2^10) (f16's comfortable range after the kernels' 2^-6), without
+    reading anything back; 1 for an all-zero tensor."""
+    lo, hi = torch.aminmax(g)
+    m = torch.maximum(hi, -lo).to(torch.float32)
+    e = torch.frexp(m)[1]                                   # m = f 2^e, f in [0.5, 1)
+    s = torch.ldexp(torch.ones((), dtype=torch.float32, device=g.device), (16 - e).clamp(-60, 60))     # (its square must stay finite)
+    return torch.where(m > 0, s, torch.ones_like(s)).reshape(1).contiguous()
 
 
 def cov_inputs(a, module, batch=None):
@@ -174,9 +189,19 @@ def cov_grads(g, module, batch=None):
     batch = g.size(0) if batch is None else batch
     if isinstance(module, nn.Conv2d):
         oh, ow = g.size(2), g.size(3)
+        if g.is_cuda and g.dtype == torch.float32 and use_gram and g.size(1) >= 16:
+            # g_ = g (oh ow) batch as rows (sample, position); g_^T g_ / (rows scale): the NCHW tensor is its own 1x1 patch matrix
+            rows = g.size(0) * oh * ow
+            got = _gram_hip(g, module, (float(oh * ow) * batch) ** 2 / (rows * scale), geometry=(1, 1, 0, 1), in_scale=_pow2_scale(g))
+            if got is not None:
+                return got
         g = g.permute(0, 2, 3, 1).reshape(-1, g.size(1)) * (oh * ow)
     elif isinstance(module, AddBias):
         g = g.reshape(g.size(0), g.size(1), -1).sum(-1)
+    if g.is_cuda and g.dtype == torch.float32 and g.dim() == 2:
+        got = _gram_hip(g, module, float(batch) ** 2 / (g.size(0) * scale), in_scale=_pow2_scale(g))
+        if got is not None:
+            return got
     g_ = g * batch
     return g_.t() @ (g_ / (g.size(0) * scale))
 

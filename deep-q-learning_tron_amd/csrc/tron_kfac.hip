@@ -93,8 +93,10 @@ __device__ __forceinline__ void split(float v, f16 &hi, f16 &lo)
 
 __global__ __launch_bounds__(256) void k_patches_t(const float *__restrict__ x, int n_img, int C, int H, int W, int kh, int kw,
                                                    int pad, int stride, int OH, int OW, int d, int dpad, int64_t rows,
-                                                   int64_t rows_pad, f16 *__restrict__ xh, f16 *__restrict__ xl)
+                                                   int64_t rows_pad, const float *__restrict__ in_scale, f16 *__restrict__ xh,
+                                                   f16 *__restrict__ xl)
 {
+    const float sc = ACT_SCALE * (in_scale ? *in_scale : 1.0f);
     const int64_t groups = rows_pad / 8, total = (int64_t)dpad * groups;
     for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(item / groups);
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void k_patches_t(const float *__restrict__ x, 
                     float v = 0.0f;
                     if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)b * C + c) * H + iy) * W + ix];
                     f16 hh, ll;
-                    split(v * ACT_SCALE, hh, ll);
+                    split(v * sc, hh, ll);
                     h[e] = hh;
                     l[e] = ll;
                 }
@@ -127,9 +129,10 @@ __global__ __launch_bounds__(256) void k_patches_t(const float *__restrict__ x, 
 
 // a f32 [rows][d] -> a^T split [dpad][rows_pad]; a workgroup = a 64 x 64 tile through LDS (reads along d, writes along rows)
 __global__ __launch_bounds__(256) void k_transpose_split(const float *__restrict__ a, int64_t rows, int d, int dpad, int64_t rows_pad,
-                                                         f16 *__restrict__ xh, f16 *__restrict__ xl)
+                                                         const float *__restrict__ in_scale, f16 *__restrict__ xh, f16 *__restrict__ xl)
 {
     __shared__ float tile[64][65];
+    const float sc = ACT_SCALE * (in_scale ? *in_scale : 1.0f);
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int j0 = blockIdx.y * 64;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void k_transpose_split(const float *__restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             f16 hh, ll;
-            split(tile[g * 8 + e][jj] * ACT_SCALE, hh, ll);
+            split(tile[g * 8 + e][jj] * sc, hh, ll);
             h[e] = hh;
             l[e] = ll;
         }
@@ -262,8 +265,10 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gram_f16x3(const f16 *__restri
     }
 }
 
-__global__ void k_gram_finish(const float *__restrict__ partial, int ksplit, int d, int dpad, float scale, float *__restrict__ gram)
+__global__ void k_gram_finish(const float *__restrict__ partial, int ksplit, int d, int dpad, float scale,
+                              const float *__restrict__ in_scale, float *__restrict__ gram)
 {
+    if (in_scale) scale /= (*in_scale) * (*in_scale);                   // (a power of two: exact)
     const int64_t total = (int64_t)d * d;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / d), c = (int)(i - (int64_t)r * d);
@@ -333,7 +338,8 @@ extern "C" int64_t tron_kfac_patch_gram_workspace(int64_t batch, int32_t channel
 }
 
 extern "C" int tron_kfac_patch_gram(const float *x, int64_t batch, int32_t channels, int32_t height, int32_t width, int32_t kh,
-                                    int32_t kw, int32_t pad, int32_t stride, float scale, float *gram, void *workspace, void *stream)
+                                    int32_t kw, int32_t pad, int32_t stride, float scale, const float *in_scale, float *gram,
+                                    void *workspace, void *stream)
 {
     if (!x || !gram || !workspace || batch < 0 || channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad < 0 || stride < 1)
         return TRON_ERR_BAD_ARG;
@@ -357,12 +363,12 @@ extern "C" int tron_kfac_patch_gram(const float *x, int64_t batch, int32_t chann
         const int64_t items = (int64_t)p.dpad * (rows_pad / 8);
         const unsigned blocks = (unsigned)(items / 256 + 1 < 65536 * 8 ? items / 256 + 1 : 65536 * 8);
         hipLaunchKernelGGL(k_patches_t, dim3(blocks), dim3(256), 0, st, x + (size_t)i * channels * height * width, (int)n, channels,
-                           height, width, kh, kw, pad, stride, OH, OW, d, p.dpad, rows, rows_pad, xh, xl);
+                           height, width, kh, kw, pad, stride, OH, OW, d, p.dpad, rows, rows_pad, in_scale, xh, xl);
         const int rc = gram_pass(xh, xl, p, d, rows_pad, partial, st);
         if (rc != TRON_OK) return rc;
     }
     hipLaunchKernelGGL(k_gram_finish, dim3((unsigned)(((int64_t)d * d + 255) / 256 < 4096 ? ((int64_t)d * d + 255) / 256 : 4096)), dim3(256),
-                       0, st, partial, p.ksplit, d, p.dpad, scale, gram);
+                       0, st, partial, p.ksplit, d, p.dpad, scale, in_scale, gram);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
@@ -372,7 +378,8 @@ extern "C" int64_t tron_kfac_gram_workspace(int64_t rows, int32_t d)
     return gram_plan(rows, 64, d).total;
 }
 
-extern "C" int tron_kfac_gram(const float *a, int64_t rows, int32_t d, float scale, float *gram, void *workspace, void *stream)
+extern "C" int tron_kfac_gram(const float *a, int64_t rows, int32_t d, float scale, const float *in_scale, float *gram,
+                              void *workspace, void *stream)
 {
     if (!a || !gram || !workspace || rows < 0 || d < 1) return TRON_ERR_BAD_ARG;
     if ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(gram)) & 15u) return TRON_ERR_BAD_ARG;
@@ -387,11 +394,11 @@ extern "C" int tron_kfac_gram(const float *a, int64_t rows, int32_t d, float sca
     for (int64_t i = 0; i < rows; i += p.rows_chunk) {
         const int64_t n = rows - i < p.rows_chunk ? rows - i : p.rows_chunk, rows_pad = (n + 63) / 64 * 64;
         hipLaunchKernelGGL(k_transpose_split, dim3((unsigned)(rows_pad / 64), (unsigned)(p.dpad / 64)), dim3(256), 0, st,
-                           a + (size_t)i * d, n, d, p.dpad, rows_pad, xh, xl);
+                           a + (size_t)i * d, n, d, p.dpad, rows_pad, in_scale, xh, xl);
         const int rc = gram_pass(xh, xl, p, d, rows_pad, partial, st);
         if (rc != TRON_OK) return rc;
     }
     hipLaunchKernelGGL(k_gram_finish, dim3((unsigned)(((int64_t)d * d + 255) / 256 < 4096 ? ((int64_t)d * d + 255) / 256 : 4096)), dim3(256),
-                       0, st, partial, p.ksplit, d, p.dpad, scale, gram);
+                       0, st, partial, p.ksplit, d, p.dpad, scale, in_scale, gram);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }

@@ -51,9 +51,9 @@ SIGNATURES = {
     "tron_minimax_actions": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "tron_minimax_codes": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "tron_extract_patches": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "tron_kfac_patch_gram": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "tron_kfac_patch_gram": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "tron_kfac_patch_gram_workspace": (C.c_int64, [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
-    "tron_kfac_gram": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp]),
+    "tron_kfac_gram": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "tron_kfac_gram_workspace": (C.c_int64, [_i64, _i32]),
     "tron_mish_fwd": (C.c_int, [_vp, _vp, _i64, _vp]),
     "tron_mish_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

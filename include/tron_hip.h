@@ -255,12 +255,18 @@ int tron_extract_patches(const float *x, int64_t batch, int32_t channels, int32_
  * as split f16 (v / 64 = hi + lo 2^-11) in passes of <= 512 MB and multiplied on the f16 matrix cores (three MFMAs per
  * slab, f32 accumulation, relative error ~1e-6), tiles on and above the diagonal only, K split over workgroups, sums in a
  * fixed order.  tron_kfac_gram: the same for a Linear layer's input a f32[rows][d] (gram = scale * a^T a).  d <= 8192;
- * workspace: tron_kfac_*_workspace(...) bytes (0 = not supported), 16-byte aligned.                              */
+ * workspace: tron_kfac_*_workspace(...) bytes (0 = not supported), 16-byte aligned.
+ * The output-gradient factors (kfac.py:61-76 `compute_cov_g`) are the same products of gradient tensors — a convolution's
+ * g f32[batch][cout][OH][OW] is the 1x1 "patch matrix" [batch*OH*OW][cout] — whose entries sit far below f16's range:
+ * in_scale (may be NULL) points at ONE f32 on the device, a power of two the input is multiplied by on its way into f16
+ * and the result divided by squared (the caller derives it from max |g| without reading it back).                */
 int tron_kfac_patch_gram(const float *x, int64_t batch, int32_t channels, int32_t height, int32_t width, int32_t kh,
-                         int32_t kw, int32_t pad, int32_t stride, float scale, float *gram, void *workspace, void *stream);
+                         int32_t kw, int32_t pad, int32_t stride, float scale, const float *in_scale, float *gram,
+                         void *workspace, void *stream);
 int64_t tron_kfac_patch_gram_workspace(int64_t batch, int32_t channels, int32_t height, int32_t width, int32_t kh,
                                        int32_t kw, int32_t pad, int32_t stride);
-int tron_kfac_gram(const float *a, int64_t rows, int32_t d, float scale, float *gram, void *workspace, void *stream);
+int tron_kfac_gram(const float *a, int64_t rows, int32_t d, float scale, const float *in_scale, float *gram, void *workspace,
+                   void *stream);
 int64_t tron_kfac_gram_workspace(int64_t rows, int32_t d);
 
 /* ---- the nets' activation (Net/ACNet.py:56-57: x * tanh(softplus(x))) as one pass each way --------- */

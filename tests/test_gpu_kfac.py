@@ -134,9 +134,9 @@ def test_gram_over_several_passes_and_bad_arguments():
     g = torch.empty(27, 27, device="cuda")
     ws = torch.empty(int(L.tron_kfac_patch_gram_workspace(4, 3, 12, 12, 3, 3, 1, 1)), dtype=torch.uint8, device="cuda")
     xs = torch.randn(4, 3, 12, 12, device="cuda")
-    assert L.tron_kfac_patch_gram(None, 4, 3, 12, 12, 3, 3, 1, 1, 1.0, nat.ptr(g), nat.ptr(ws), None) == nat.ERR_BAD_ARG
-    assert L.tron_kfac_patch_gram(nat.ptr(xs), 4, 3, 12, 12, 3, 3, 1, 0, 1.0, nat.ptr(g), nat.ptr(ws), None) == nat.ERR_BAD_ARG
-    assert L.tron_kfac_patch_gram(nat.ptr(xs), 0, 3, 12, 12, 3, 3, 1, 1, 1.0, nat.ptr(g), nat.ptr(ws), None) == 0
+    assert L.tron_kfac_patch_gram(None, 4, 3, 12, 12, 3, 3, 1, 1, 1.0, None, nat.ptr(g), nat.ptr(ws), None) == nat.ERR_BAD_ARG
+    assert L.tron_kfac_patch_gram(nat.ptr(xs), 4, 3, 12, 12, 3, 3, 1, 0, 1.0, None, nat.ptr(g), nat.ptr(ws), None) == nat.ERR_BAD_ARG
+    assert L.tron_kfac_patch_gram(nat.ptr(xs), 0, 3, 12, 12, 3, 3, 1, 1, 1.0, None, nat.ptr(g), nat.ptr(ws), None) == 0
     torch.cuda.synchronize()
     assert torch.count_nonzero(g) == 0                                   # the sum over nothing
 
@@ -155,6 +155,30 @@ def test_cov_inputs_uses_the_gram_kernels_and_matches_the_library_path(monkeypat
     want_a, want_b = kfac.cov_inputs(a, conv), kfac.cov_inputs(b, lin)
     for got, want in ((got_a, want_a), (got_b, want_b), (parts, want_a)):
         assert (got - want).abs().max().item() / want.abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("magnitude", [1.0, 1e-6, 1e-12])
+def test_cov_grads_on_the_gram_kernels_matches_float64(magnitude):
+    """kfac.py:61-76 `compute_cov_g` for a convolution's and a Linear layer's output gradients — tensors whose entries sit
+    far below f16's range: the kernels scale them by a power of two found on the device (no read-back)."""
+    import torch.nn as nn
+    from Net import kfac
+    torch.manual_seed(4)
+    conv, lin = nn.Conv2d(8, 64, 3, padding=1), nn.Linear(10, 128)
+    g = torch.randn(300, 64, 12, 12, device="cuda") * magnitude
+    h = torch.randn(4096, 128, device="cuda") * magnitude
+    for grad, module, whole in ((g, conv, None), (g[:100], conv, 300), (h, lin, None), (h[:1024], lin, 4096)):
+        got = kfac.cov_grads(grad, module, whole)
+        gd = grad.double()
+        batch = grad.size(0) if whole is None else whole
+        scale = 1.0 if whole is None else whole / grad.size(0)
+        if gd.dim() == 4:
+            gd = gd.permute(0, 2, 3, 1).reshape(-1, gd.size(1)) * (gd.size(2) * gd.size(3))
+        g_ = gd * batch
+        want = g_.t() @ (g_ / (gd.size(0) * scale))
+        assert (got.double() - want).abs().max().item() / want.abs().max().item() < 2e-6
+    z = kfac.cov_grads(torch.zeros(600, 64, 12, 12, device="cuda"), conv)
+    assert torch.count_nonzero(z) == 0 and torch.isfinite(z).all()
 
 
 def test_mish_kernels_match_the_composed_form():
