@@ -26,6 +26,9 @@ for W in 10 24; do
   rocprofv3 --kernel-trace --output-format csv -d "$O/learn$W" -- python3 scripts/learn_prof.py $W 4096 8 > "$O/learn$W.log" 2>&1 || echo "learn$W failed"
   python3 scripts/kstats.py "$O/learn$W" --batch 4096 --skip-first 3 > "$O/r03_learn_${W}x${W}_kernel_rows.txt" 2>&1
 done
+# ACKTR at BASELINE config 5 (16 384 envs x 32x32): one iteration's kernels
+rocprofv3 --kernel-trace --output-format csv -d "$O/acktr" -- python3 bench.py --acktr --acktr-iterations 1 > "$O/acktr.log" 2>&1 || echo "acktr failed"
+python3 scripts/kstats.py "$O/acktr" > "$O/r03_acktr_config5_kernel_rows.txt" 2>&1
 python3 scripts/ws_layer_bench.py 8192 12 > "$O/r03_ws_layer_bench_12.txt" 2>&1
 python3 scripts/ws_layer_bench.py 2048 26 > "$O/r03_ws_layer_bench_26.txt" 2>&1
 find "$O" -name "*.csv" -size +20M -delete
