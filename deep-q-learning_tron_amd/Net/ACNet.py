@@ -18,7 +18,8 @@ import torch.nn.functional as F
 
 from config import MAP_WIDTH
 from Net.DQNNet import conv7_side
-from Net.activations import mish as _mish, Conv3x3 as _Conv3x3, pool_s2 as _pool_s2
+from Net.activations import mish as _mish, Conv3x3 as _Conv3x3, pool_s2 as _pool_s2, conv_bias_mish as _conv_bias_mish
+from Net.kfac import SplitBias as _SplitBias
 
 
 class Net(nn.Module):
@@ -68,19 +69,32 @@ class Net(nn.Module):
         self.flat = 64 * conv7_side(self.side) ** 2
         self.fc1 = nn.Linear(self.flat, 256)
 
+    def _conv_act(self, conv, x, residual=None):
+        """activation(conv(x) + residual).  With the nets' own mish: a plain conv layer goes through `conv_bias_mish`
+        (convolution, bias, residual and activation in one kernel where the HIP kernels cover the shape); after
+        KFACOptimizer split the bias off (Net/kfac.py::SplitBias) the hooked convolution module runs first and bias +
+        residual + activation are one pass behind it."""
+        if self.activation is Net.mish or self.activation is self.mish:
+            if isinstance(conv, _SplitBias):
+                return conv(x, residual=residual, act=True)
+            if isinstance(conv, nn.Conv2d) and conv.bias is not None:
+                return _conv_bias_mish(conv, x, residual)
+        y = conv(x)
+        return self.activation(y if residual is None else y + residual)
+
     def _trunk(self, x):
         """conv1..conv7 + fc1 with dropout; returns the [B, 256] feature."""
         a = self.activation
-        x = a(self.conv1(x))
+        x = self._conv_act(self.conv1, x)
         idx = x
-        x = a(self.conv2(x))
-        x = a(self.conv3(x) + idx)
-        x = a(self.conv4(x))
+        x = self._conv_act(self.conv2, x)
+        x = self._conv_act(self.conv3, x, idx)
+        x = self._conv_act(self.conv4, x)
         idx = x
-        x = a(self.conv5(x))
-        x = a(self.conv6(x) + idx)
+        x = self._conv_act(self.conv5, x)
+        x = self._conv_act(self.conv6, x, idx)
         x = _pool_s2(self.pool, x)            # (csrc/tron_head.hip's row kernels at 12 / 26 / 34, both directions; else self.pool)
-        x = a(self.conv7(x))
+        x = self._conv_act(self.conv7, x)
         x = x.reshape(-1, self.flat)
         return self.dropout(a(self.fc1(x)))
 

@@ -298,20 +298,25 @@ def conv1_codes_mish(conv, codes, plane4=0.0):
 
 
 class _BiasMish(torch.autograd.Function):
-    """mish(y + bias[c] (+ residual)) for a bias-free convolution output y [N, C, H, W]."""
+    """mish(y + bias[c] (+ residual)) for a bias-free convolution output y [N, C, H, W].  grad_pre_hook (may be None) is
+    called in backward with the gradient at the pre-activation — where K-FAC's statistics hook of a split-off bias layer
+    (Net/kfac.py::AddBias, kfac.py:156-189) would have seen it had bias, residual and activation been separate modules."""
 
     @staticmethod
-    def forward(ctx, y, bias, residual):
+    def forward(ctx, y, bias, residual, grad_pre_hook=None):
         from tron import _native as nat
         pre = y.contiguous()                      # overwritten with y + bias (+ residual): saved for backward
         res = None if residual is None else residual.contiguous()
         out = torch.empty_like(pre)
         N, C, H, W = pre.shape
+        b = bias.reshape(-1).contiguous()
         with torch.cuda.device(pre.device):
-            nat.check(nat.lib().tron_bias_mish_fwd(nat.ptr(pre), nat.ptr(bias), nat.ptr(res), nat.ptr(out), N, C, H * W,
+            nat.check(nat.lib().tron_bias_mish_fwd(nat.ptr(pre), nat.ptr(b), nat.ptr(res), nat.ptr(out), N, C, H * W,
                                                    nat.stream_ptr()), "tron_bias_mish_fwd")
         ctx.save_for_backward(pre)
         ctx.has_res = residual is not None
+        ctx.bias_shape = tuple(bias.shape)
+        ctx.grad_pre_hook = grad_pre_hook
         return out
 
     @staticmethod
@@ -322,7 +327,20 @@ class _BiasMish(torch.autograd.Function):
         if not _aligned16(g):
             g = g.clone(memory_format=torch.contiguous_format)
         gp, gb = bias_mish_bwd(pre, g)
-        return gp, gb, (gp if ctx.has_res else None)
+        if ctx.grad_pre_hook is not None:
+            ctx.grad_pre_hook(gp)
+        return gp, gb.reshape(ctx.bias_shape), (gp if ctx.has_res else None), None
+
+
+def bias_mish_supported(y, residual=None):
+    """tron_bias_mish_fwd / _bwd's shapes: f32 CUDA [N, C, H, W] with H W a multiple of 4, 16-byte aligned."""
+    return (y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and (y.shape[2] * y.shape[3]) % 4 == 0 and 0 < y.numel() < 2 ** 32
+            and _aligned16(y, residual) and (residual is None or (residual.shape == y.shape and residual.dtype == torch.float32)))
+
+
+def bias_mish(y, bias, residual=None, grad_pre_hook=None):
+    """mish(y + bias (+ residual)) as one pass each way (bias [C] or [C, 1]); the caller checked bias_mish_supported."""
+    return _BiasMish.apply(y, bias, residual, grad_pre_hook)
 
 
 class _PoolConv7(torch.autograd.Function):
@@ -445,7 +463,7 @@ def conv_bias_mish(conv, x, residual=None):
             return _ConvBiasMishHIP.apply(x, conv.weight, conv.bias, residual)
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if (y.shape[2] * y.shape[3]) % 4 == 0 and y.numel() < 2 ** 32 and _aligned16(y, residual):
-            return _BiasMish.apply(y, conv.bias, residual)
+            return _BiasMish.apply(y, conv.bias, residual, None)
         y = y + conv.bias.view(1, -1, 1, 1)
         return mish(y if residual is None else y + residual)
     y = conv(x)

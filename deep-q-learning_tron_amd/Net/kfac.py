@@ -36,10 +36,22 @@ class AddBias(nn.Module):
     def __init__(self, bias):
         super(AddBias, self).__init__()
         self._bias = nn.Parameter(bias.unsqueeze(1))
+        self._kfac = None          # the KFACOptimizer whose hooks sit on this module (set by it; not part of the state)
 
     def forward(self, x):
         b = self._bias.t()
         return x + (b.view(1, -1) if x.dim() == 2 else b.view(1, -1, 1, 1))
+
+    def fused_mish(self, x, residual=None):
+        """mish(x + bias (+ residual)) in one pass each way (csrc/tron_nn.hip) instead of three modules' worth of
+        elementwise kernels, with K-FAC's two statistics hooks of this module fed by hand: they would have seen x on the
+        way in and the gradient at x + bias (+ residual) on the way back."""
+        from Net.activations import bias_mish
+        opt = self._kfac
+        if opt is not None:
+            opt._save_input(self, (x,))
+        hook = None if opt is None else (lambda gp, m=self, o=opt: o._save_grad_output(m, None, (gp,)))
+        return bias_mish(x, self._bias, residual, hook)
 
 
 class SplitBias(nn.Module):
@@ -51,8 +63,18 @@ class SplitBias(nn.Module):
         self.add_bias = AddBias(module.bias.data)
         self.module.bias = None
 
-    def forward(self, input):
-        return self.add_bias(self.module(input))
+    def forward(self, input, residual=None, act=False):
+        """add_bias(module(input)); with act=True: mish(add_bias(module(input)) + residual) — what every conv layer of the
+        nets' trunk is followed by (ACNet.py:97-116) — fused behind the (still hooked) module where the kernels cover it."""
+        y = self.module(input)
+        if act:
+            from Net.activations import bias_mish_supported, mish
+            if bias_mish_supported(y, residual):
+                return self.add_bias.fused_mish(y, residual)
+            y = self.add_bias(y)
+            return mish(y if residual is None else y + residual)
+        y = self.add_bias(y)
+        return y if residual is None else y + residual
 
 
 def split_biases(model):
@@ -219,6 +241,8 @@ class KFACOptimizer(optim.Optimizer):
             assert len(list(m.parameters(recurse=False))) == 1, "one parameter per factored module"
             m.register_forward_pre_hook(self._save_input)
             m.register_full_backward_hook(self._save_grad_output)
+            if isinstance(m, AddBias):
+                m._kfac = self                    # (AddBias.fused_mish calls the two hooks itself)
         self.steps = 0
         self.acc_stats = False
         self._whole_batch = None          # set by accumulate(): hooks then add micro-batch shares

@@ -181,6 +181,42 @@ def test_cov_grads_on_the_gram_kernels_matches_float64(magnitude):
     assert torch.count_nonzero(z) == 0 and torch.isfinite(z).all()
 
 
+@pytest.mark.parametrize("width,model", [(10, "MapNet"), (24, "Mulnet"), (32, "TestNet")])
+def test_fused_bias_residual_mish_keeps_kfac_statistics(width, model, monkeypatch):
+    """After KFACOptimizer split the biases, a trunk layer is the hooked conv module followed by ONE bias + residual +
+    activation pass (Net/kfac.py::SplitBias / AddBias.fused_mish) that feeds AddBias's two statistics hooks by hand: outputs,
+    parameter gradients and every Kronecker factor equal those of the module-by-module graph (kfac.py:156-189)."""
+    import copy
+    import torch.nn.functional as F
+    from Net import ACNet, activations, kfac
+    torch.manual_seed(width)
+    S, B = width + 2, 24
+    net = getattr(ACNet, model)(width).cuda()
+    net.dropout.p = 0.0
+    ref = copy.deepcopy(net)
+    opts = [kfac.KFACOptimizer(m) for m in (net, ref)]
+    x = torch.randn(B, 4 if model == "MapNet" else 3, S, S, device="cuda")
+    extra = () if model == "MapNet" else ((torch.rand(B, 2, device="cuda"),) if model == "Mulnet" else (torch.rand(B, device="cuda"),))
+    acts = torch.randint(0, 4, (B, 1), device="cuda")
+    outs = []
+    for m, opt, fused in ((net, opts[0], True), (ref, opts[1], False)):
+        if not fused:
+            monkeypatch.setattr(activations, "bias_mish_supported", lambda y, residual=None: False)
+        v, logp, ent = m.evaluate_actions(x, acts, *extra)
+        opt.acc_stats = True
+        (-(logp.mean()) - v.pow(2).mean()).backward(retain_graph=True)
+        opt.acc_stats = False
+        (v.pow(2).mean() - logp.mean() - 0.01 * ent).backward()
+        outs.append((v.detach(), logp.detach()))
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-5 and (outs[0][1] - outs[1][1]).abs().max().item() < 1e-5
+    for (name, p), (_, r) in zip(net.named_parameters(), ref.named_parameters()):
+        assert (p.grad - r.grad).abs().max().item() / (r.grad.abs().max().item() + 1e-30) < 1e-4, name
+    for ma, mb in zip(opts[0].modules, opts[1].modules):
+        for store in ("m_aa", "m_gg"):
+            a, b = getattr(opts[0], store)[ma], getattr(opts[1], store)[mb]
+            assert (a - b).abs().max().item() / (b.abs().max().item() + 1e-30) < 1e-4, (type(ma).__name__, store)
+
+
 def test_mish_kernels_match_the_composed_form():
     """csrc/tron_nn.hip: mish forward / backward against x * tanh(softplus(x)) and its autograd gradient
     evaluated in float64, over the whole input range (incl. the > 20 cut-over and deep negatives)."""
