@@ -76,6 +76,10 @@ extern "C" int tron_extract_patches(const float *x, int64_t batch, int32_t chann
 //   k_gram_f16x3     partial[s] += X X^T over K range s of the chunk: 128 x 64 tiles, 8 waves, K chunks of 64 through LDS
 //                    (csrc/tron_head.hip's GEMM loop); blockIdx = (tile, K split) so that small d still fills the chip
 //   k_gram_finish    gram[i][j] = scale * sum_s partial[s][min(i,j)][max(i,j)]          (fixed order: deterministic)
+#ifndef TRON_GRAM_V2         // 0: the register-staged 128 x 64 kernel (A/B measurements)
+#define TRON_GRAM_V2 1
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -96,30 +100,36 @@ __global__ __launch_bounds__(256) void k_patches_t(const float *__restrict__ x, 
                                                    int64_t rows_pad, const float *__restrict__ in_scale, f16 *__restrict__ xh,
                                                    f16 *__restrict__ xl)
 {
+    // blockIdx.y = patch column j, blockIdx.x strides over groups of 8 rows: 32-bit index arithmetic only (rows_pad < 2^31)
     const float sc = ACT_SCALE * (in_scale ? *in_scale : 1.0f);
-    const int64_t groups = rows_pad / 8, total = (int64_t)dpad * groups;
-    for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)(item / groups);
-        const int64_t r0 = (item - (int64_t)j * groups) * 8;
+    const int groups = (int)(rows_pad / 8);
+    const int j = blockIdx.y;
+    const int c = j / (kh * kw), t = j - c * (kh * kw), ky = t / kw, kx = t - ky * kw;
+    for (int grp = blockIdx.x * blockDim.x + threadIdx.x; grp < groups; grp += gridDim.x * blockDim.x) {
+        const int r0 = grp * 8;
         f16x8 h, l;
 #pragma unroll
         for (int e = 0; e < 8; ++e) h[e] = l[e] = (f16)0.0f;
         if (j < d && r0 < rows) {
-            const int c = j / (kh * kw), t = j - c * (kh * kw), ky = t / kw, kx = t - ky * kw;
-            int64_t b = r0 / (OH * OW);
-            int rem = (int)(r0 - b * (OH * OW)), oy = rem / OW, ox = rem - oy * OW;
+            const int b = r0 / (OH * OW);
+            int rem = r0 - b * (OH * OW), oy = rem / OW, ox = rem - oy * OW;
+            // 32-bit offsets into this pass's images (a pass is at most 512 MB of patches: < 2^31 input floats)
+            int plane = (b * C + c) * H * W, iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if (r0 + e < rows) {
-                    const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
-                    float v = 0.0f;
-                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)b * C + c) * H + iy) * W + ix];
-                    f16 hh, ll;
-                    split(v * sc, hh, ll);
-                    h[e] = hh;
-                    l[e] = ll;
+                float v = 0.0f;
+                if (r0 + e < rows && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[plane + iy * W + ix];
+                f16 hh, ll;
+                split(v * sc, hh, ll);
+                h[e] = hh;
+                l[e] = ll;
+                ix += stride;
+                if (++ox == OW) {
+                    ox = 0;
+                    ix = kx - pad;
+                    iy += stride;
+                    if (++oy == OH) { oy = 0; iy = ky - pad; plane += C * H * W; }
                 }
-                if (++ox == OW) { ox = 0; if (++oy == OH) { oy = 0; ++b; } }
             }
         }
         *reinterpret_cast<f16x8 *>(xh + (size_t)j * rows_pad + r0) = h;
@@ -265,6 +275,113 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gram_f16x3(const f16 *__restri
     }
 }
 
+// The same product on 128 x 128 tiles fed by LDS-DMA (TRON_GRAM_V2, the default).  k_gram_f16x3 above stages its operands
+// through registers and ds_write_b128 — 48 stores per K chunk and workgroup at 13 LDS cycles each keep the CU's one store
+// path busy 80 % of the time — and its 128 x 64 tiles pull 49 KB from L2 per 1 M MACs.  Here a 16-wave workgroup (one per CU,
+// 4 waves per SIMD, each wave a 32 x 32 sub-tile) owns a 128 x 128 tile; a K chunk of 64 — rows m0 .. m0+127 and
+// n0 .. n0+127 of X, hi and lo: 64 KB — is copied global -> LDS by 64 `global_load_lds_dwordx4` (4 per wave), double
+// buffered, one barrier per chunk.  LDS rows are 128 bytes without padding; a row's eight 16-byte pieces are stored XOR-ed
+// with (row & 7) — the per-lane SOURCE address does the swizzle, the destination of an LDS-DMA is linear — which puts the
+// 16 lanes of every ds_read_b128 group on 16 different bank quads (rows r, r+4, r+8, r+12 of a group differ in row & 7).
+constexpr int G2_T = 128, G2_K = 64, G2_THREADS = 1024, G2_BUF = 2 * 2 * G2_T * G2_K * 2, G2_LDS = 2 * G2_BUF;   // 64 KB per buffer
+
+__global__ __launch_bounds__(G2_THREADS, 4) void k_gram2_f16x3(const f16 *__restrict__ Xh, const f16 *__restrict__ Xl, int d, int dpad,
+                                                               int64_t pitch, int nk, int ksplit, float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 3, wn = wave >> 2, li = lane & 15, g = lane >> 4;
+    const int nb = (dpad + G2_T - 1) / G2_T, ntiles = nb * nb;
+    const int tile = blockIdx.x % ntiles, s = blockIdx.x / ntiles;
+    const int bm = tile / nb, bn = tile % nb, m0 = bm * G2_T, n0 = bn * G2_T;
+    if (bn < bm) return;                                                // below the diagonal: k_gram_finish mirrors
+    const int k_lo = (int)((int64_t)nk * s / ksplit), k_hi = (int)((int64_t)nk * (s + 1) / ksplit);
+    if (k_lo >= k_hi) return;
+
+    // this wave's four 1 KB blocks of a chunk's image [hi | lo][256 rows: A then W][128 B]: block b = wave + 16 j
+    const unsigned char *src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = wave + 16 * j, half = b >> 5, row = 8 * (b & 31) + (lane >> 3), piece = (lane & 7) ^ (row & 7);
+        int grow = row < G2_T ? m0 + row : n0 + row - G2_T;
+        grow = grow < dpad ? grow : dpad - 1;
+        src[j] = reinterpret_cast<const unsigned char *>(half ? Xl : Xh) + (size_t)grow * pitch * 2 + piece * 16;
+    }
+    auto dma_chunk = [&](int kc, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[j] + (size_t)kc * (G2_K * 2)),
+                                             (__attribute__((address_space(3))) void *)(lds + buf * G2_BUF + (wave + 16 * j) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc0[2][2], acc1[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            acc0[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc1[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    // fragment addresses: row r, k pieces 4 sl + g of the slab, stored at piece ^ (r & 7); the lo image lies 32 KB further
+    int a_off[2], b_off[2], a_sw[2], b_sw[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ra = wm * 32 + t * 16 + li, rb = G2_T + wn * 32 + t * 16 + li;
+        a_off[t] = ra * 128;
+        a_sw[t] = ra & 7;
+        b_off[t] = rb * 128;
+        b_sw[t] = rb & 7;
+    }
+    dma_chunk(k_lo, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kc = k_lo; kc < k_hi; ++kc) {
+        const int cur = (kc - k_lo) & 1;
+        dma_chunk(kc + 1 < k_hi ? kc + 1 : kc, cur ^ 1);                 // (the last chunk is fetched again: no branch around the DMA)
+        const unsigned char *base = lds + cur * G2_BUF;
+#pragma unroll
+        for (int sl = 0; sl < G2_K / 32; ++sl) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int pa = ((4 * sl + g) ^ a_sw[t]) * 16, pb = ((4 * sl + g) ^ b_sw[t]) * 16;
+                ah[t] = *reinterpret_cast<const f16x8 *>(base + a_off[t] + pa);
+                al[t] = *reinterpret_cast<const f16x8 *>(base + G2_BUF / 2 + a_off[t] + pa);
+                bh[t] = *reinterpret_cast<const f16x8 *>(base + b_off[t] + pb);
+                bl[t] = *reinterpret_cast<const f16x8 *>(base + G2_BUF / 2 + b_off[t] + pb);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc1[t][n], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc0[t][n], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc1[t][n], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's pieces of the next chunk have landed ...
+        __syncthreads();                                                // ... everybody's have, and nobody reads this buffer any more
+    }
+    float *out = partial + (size_t)s * d * dpad;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = n0 + wn * 32 + n * 16 + li;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 v = (acc0[t][n] + acc1[t][n] * LO_UNSCALE) * GRAM_UNSCALE;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + t * 16 + 4 * g + r;
+                if (m < d && col < dpad) out[(size_t)m * dpad + col] += v[r];
+            }
+        }
+    }
+}
+
 __global__ void k_gram_finish(const float *__restrict__ partial, int ksplit, int d, int dpad, float scale,
                               const float *__restrict__ in_scale, float *__restrict__ gram)
 {
@@ -294,11 +411,16 @@ inline GramPlan gram_plan(int64_t rows_total, int64_t rows_unit, int d)
     if (rows < rows_unit) rows = rows_unit;
     if (rows > rows_total) rows = (rows_total + rows_unit - 1) / rows_unit * rows_unit;
     p.rows_chunk = (rows + 63) / 64 * 64;
+#if TRON_GRAM_V2
+    const int nb2 = (p.dpad + G2_T - 1) / G2_T, upper = nb2 * (nb2 + 1) / 2;
+    int ks = 768 / upper;                                               // one 16-wave workgroup per CU: three rounds of the chip
+#else
     const int nblocks = p.dpad / GN, mt = (d + GM - 1) / GM;
     int upper = 0;
     for (int bm = 0; bm < mt; ++bm)
         for (int bn = 0; bn < nblocks; ++bn) upper += (bn * GN + GN > bm * GM);
     int ks = 2048 / (upper > 0 ? upper : 1);                            // ~8 workgroups per CU in flight over the launch
+#endif
     const int64_t nk = p.rows_chunk / GK;
     if (ks > nk / 16) ks = (int)(nk / 16);                              // a split walks at least 16 K chunks
     if (ks < 1) ks = 1;
@@ -316,13 +438,20 @@ int gram_pass(const f16 *xh, const f16 *xl, const GramPlan &p, int d, int64_t ro
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
     if (!(prepared & (1ull << (dev & 63)))) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gram_f16x3), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gram_f16x3), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_gram2_f16x3), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess)
             (void)hipGetLastError();
         prepared |= 1ull << (dev & 63);
     }
+#if TRON_GRAM_V2
+    const int nb2 = (p.dpad + G2_T - 1) / G2_T;
+    hipLaunchKernelGGL(k_gram2_f16x3, dim3((unsigned)(nb2 * nb2 * p.ksplit)), dim3(G2_THREADS), G2_LDS, st, xh, xl, d, p.dpad, rows_pad,
+                       (int)(rows_pad / G2_K), p.ksplit, partial);
+#else
     const int ntiles = ((d + GM - 1) / GM) * (p.dpad / GN);
     hipLaunchKernelGGL(k_gram_f16x3, dim3((unsigned)(ntiles * p.ksplit)), dim3(G_THREADS), G_LDS, st, xh, xl, d, p.dpad, rows_pad,
                        (int)(rows_pad / GK), p.ksplit, partial);
+#endif
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
@@ -357,12 +486,14 @@ extern "C" int tron_kfac_patch_gram(const float *x, int64_t batch, int32_t chann
     float *partial = reinterpret_cast<float *>(wsb + 2 * p.x_bytes);
     if (hipMemsetAsync(partial, 0, (size_t)p.partial_bytes, st) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_LAUNCH; }
     const int64_t imgs_chunk = p.rows_chunk / per > 0 ? p.rows_chunk / per : 1;
+    if (imgs_chunk * channels * height * width >= (1ll << 31)) return TRON_ERR_UNSUPPORTED;   // (k_patches_t indexes a pass's input with 32 bits)
     for (int64_t i = 0; i < batch; i += imgs_chunk) {
         const int64_t n = batch - i < imgs_chunk ? batch - i : imgs_chunk;
         const int64_t rows = n * per, rows_pad = (rows + 63) / 64 * 64;
-        const int64_t items = (int64_t)p.dpad * (rows_pad / 8);
-        const unsigned blocks = (unsigned)(items / 256 + 1 < 65536 * 8 ? items / 256 + 1 : 65536 * 8);
-        hipLaunchKernelGGL(k_patches_t, dim3(blocks), dim3(256), 0, st, x + (size_t)i * channels * height * width, (int)n, channels,
+        int64_t gblocks = (rows_pad / 8 + 255) / 256;                    // (x: groups of 8 rows, grid-stride; y: patch column)
+        const int64_t want = 8192 / p.dpad > 0 ? 8192 / p.dpad : 1;       // ~32 workgroups per CU over the launch, tens of items per thread
+        if (gblocks > want) gblocks = want;
+        hipLaunchKernelGGL(k_patches_t, dim3((unsigned)gblocks, (unsigned)p.dpad), dim3(256), 0, st, x + (size_t)i * channels * height * width, (int)n, channels,
                            height, width, kh, kw, pad, stride, OH, OW, d, p.dpad, rows, rows_pad, in_scale, xh, xl);
         const int rc = gram_pass(xh, xl, p, d, rows_pad, partial, st);
         if (rc != TRON_OK) return rc;
