@@ -133,7 +133,10 @@ class Agent():
         self.qnetwork_target = Net(in_channels, width).to(self.device)
         self.action_size = 4
         self.steps = 0
-        self.optimizer = optim.Adam(self.qnetwork_local.parameters())            # DDQN.py:52
+        # DDQN.py:52.  On the GPU the update of all 22 tensors is one fused launch (the per-tensor loop is 22 x 5 small kernels,
+        # the multi-tensor form still six); TRON_ADAM_FUSED=0 keeps the multi-tensor form.
+        fused = self.device.type == "cuda" and os.environ.get("TRON_ADAM_FUSED", "1") != "0"
+        self.optimizer = optim.Adam(self.qnetwork_local.parameters(), fused=True) if fused else optim.Adam(self.qnetwork_local.parameters())
         self.epsilon = 0
         self.totalloss = 0
         self.batch_size = batch_size

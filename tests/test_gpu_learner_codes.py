@@ -126,7 +126,7 @@ def test_flat_gradient_buffer_and_deferred_update():
     a1 = DDQN.Agent(W, 3, device="cuda", make_memory=False)
     a1.qnetwork_local.dropout.p = 0.0
     a2 = copy.deepcopy(a1)
-    a2.optimizer = torch.optim.Adam(a2.qnetwork_local.parameters())
+    a2.optimizer = torch.optim.Adam(a2.qnetwork_local.parameters(), fused=bool(a1.optimizer.defaults.get("fused")))   # (as Agent builds it)
     for step in range(3):
         s, s2 = _codes(B, W + 2, step), _codes(B, W + 2, 50 + step)
         act = torch.randint(0, 4, (B, 1), device="cuda")
