@@ -236,12 +236,15 @@ class Agent():
         labels = self.targets(rewards, next_state, dones, gamma, plane4)
         loss = criterion(predicted_targets, labels)
         self.totalloss += loss.detach()
-        if self.device.type == "cuda":
+        # One rank per GPU: every .grad is a view of one flat buffer (one fill, one collective).  A single process has
+        # nothing to reduce, and a .grad that exists makes autograd ACCUMULATE into it — one small add kernel per
+        # parameter, 24 launches of ~5 us per learn step — so there the gradients are dropped and autograd assigns them.
+        if self.device.type == "cuda" and (_world() > 1 or getattr(self, "force_flat_grads", False)):
             flat = self.flat_grads()
             flat.zero_()
         else:
             flat = None
-            self.optimizer.zero_grad()
+            self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         if flat is not None and _world() > 1:      # RCCL over xGMI when run one-rank-per-GPU
             if getattr(self, "_side", None) is None:

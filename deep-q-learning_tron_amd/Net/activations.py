@@ -198,12 +198,13 @@ class _TrunkHIP(torch.autograd.Function):
         from Net import fused
         w, b = wb[0::2], wb[1::2]
         codes = x.dtype == torch.int8
-        a1, z1 = fused.conv3x3_raw(x, w[0], b[0], None, act=True, codes=codes, plane4=plane4, want_pre=True)
-        a2, z2 = fused.conv3x3_raw(a1, w[1], b[1], None, act=True, want_pre=True)
-        a3, z3 = fused.conv3x3_raw(a2, w[2], b[2], a1, act=True, want_pre=True)
-        a4, z4 = fused.conv3x3_raw(a3, w[3], b[3], None, act=True, want_pre=True)
-        a5, z5 = fused.conv3x3_raw(a4, w[4], b[4], None, act=True, want_pre=True)
-        a6, z6 = fused.conv3x3_raw(a5, w[5], b[5], a4, act=True, want_pre=True)
+        ws = fused.split_weights(list(w))                            # all six layers' split weights in one launch
+        a1, z1 = fused.conv3x3_raw(x, w[0], b[0], None, act=True, codes=codes, plane4=plane4, want_pre=True, presplit=ws[0])
+        a2, z2 = fused.conv3x3_raw(a1, w[1], b[1], None, act=True, want_pre=True, presplit=ws[1])
+        a3, z3 = fused.conv3x3_raw(a2, w[2], b[2], a1, act=True, want_pre=True, presplit=ws[2])
+        a4, z4 = fused.conv3x3_raw(a3, w[3], b[3], None, act=True, want_pre=True, presplit=ws[3])
+        a5, z5 = fused.conv3x3_raw(a4, w[4], b[4], None, act=True, want_pre=True, presplit=ws[4])
+        a6, z6 = fused.conv3x3_raw(a5, w[5], b[5], a4, act=True, want_pre=True, presplit=ws[5])
         ctx.save_for_backward(x, a1, a2, a3, a4, a5, z1, z2, z3, z4, z5, z6, *w)
         ctx.plane4 = plane4
         return a6

@@ -49,18 +49,19 @@ def split_weights(convs):
     import ctypes as C
     L = nat.lib()
     n = len(convs)
-    dev = convs[0].weight.device
-    sizes = [(int(L.tron_conv3x3_workspace(c.in_channels, c.out_channels)) + 255) // 256 * 256 for c in convs]
+    weights = [c if torch.is_tensor(c) else c.weight for c in convs]          # modules or their weight tensors [Cout, Cin, 3, 3]
+    dev = weights[0].device
+    sizes = [(int(L.tron_conv3x3_workspace(w.shape[1], w.shape[0])) + 255) // 256 * 256 for w in weights]
     buf = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
     views, off = [], 0
     for sz in sizes:
         views.append(buf[off:off + sz])
         off += sz
-    ws = [c.weight.detach() if c.weight.is_contiguous() else c.weight.detach().contiguous() for c in convs]
+    ws = [w.detach() if w.is_contiguous() else w.detach().contiguous() for w in weights]
     wp = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
     vp = (C.c_void_p * n)(*[v.data_ptr() for v in views])
-    ci = (C.c_int32 * n)(*[c.in_channels for c in convs])
-    co = (C.c_int32 * n)(*[c.out_channels for c in convs])
+    ci = (C.c_int32 * n)(*[w.shape[1] for w in weights])
+    co = (C.c_int32 * n)(*[w.shape[0] for w in weights])
     with torch.cuda.device(dev):
         nat.check(L.tron_conv3x3_split_weights(wp, ci, co, vp, n, nat.stream_ptr()), "tron_conv3x3_split_weights")
     return views

@@ -125,6 +125,7 @@ def test_flat_gradient_buffer_and_deferred_update():
     B, W = 256, 10
     a1 = DDQN.Agent(W, 3, device="cuda", make_memory=False)
     a1.qnetwork_local.dropout.p = 0.0
+    a1.force_flat_grads = True                 # (what one-rank-per-GPU runs use; a single process lets autograd assign the gradients)
     a2 = copy.deepcopy(a1)
     a2.optimizer = torch.optim.Adam(a2.qnetwork_local.parameters(), fused=bool(a1.optimizer.defaults.get("fused")))   # (as Agent builds it)
     for step in range(3):
