@@ -9,8 +9,8 @@
 // operands split in two halves (v = hi + lo 2^-11, three MFMAs per k-slab, f32 accumulation — csrc/tron_conv_f16.hip
 // has the derivation and the error bound), and the layers hand their outputs on already split:
 //     k_pool_split12    avg-pool 3/2/1 (count_include_pad) of the trunk's f32 output -> split f16 rows [B][2304]
-//     k_dense7_split    conv7's weight -> the dense matrix [576][2304], split            (per call: nothing cached)
-//     k_split_rows      an nn.Linear weight [N][K] -> split
+//     k_head_weights    every weight in the form its GEMM wants, one launch: conv7 -> the dense matrix [576][2304] split
+//                       (dense7_split), the nn.Linear weights [N][K] split (split_rows)     (per call: nothing cached)
 //     k_gemm_f16x3      C = act(A W^T + bias), A and W split f16 row-major; C as f32 and / or split f16
 //     k_q_head          actor2 (64 -> 4) in f32 + argmax
 // GEMM tile: 128 x 64 per 8-wave workgroup (wave = 32 x 32 = 2 x 2 MFMA tiles), K in chunks of 64 staged by 16-byte
@@ -87,12 +87,12 @@ __global__ __launch_bounds__(256) void k_pool_split12(const float *__restrict__ 
 // conv7 (Co x Ci x 7 x 7, stride 2, pad 3) on PS x PS planes as a dense [Co*OS*OS][Ci*PS*PS] matrix, split
 // (octets: the columns are ordered (channel octet, pixel, channel within the octet) — the order in which the PX16
 // pooling writes a row, 16 bytes per (octet, pixel) — instead of NCHW-flatten (channel, pixel))
-__global__ void k_dense7_split(const float *__restrict__ w, int Co, int Ci, int PS, int OS, int octets, f16 *__restrict__ oh,
-                               f16 *__restrict__ ol)
+__device__ __forceinline__ void dense7_split(const float *__restrict__ w, int Co, int Ci, int PS, int OS, int octets, f16 *__restrict__ oh,
+                                             f16 *__restrict__ ol, int first, int step)
 {
     const int K = Ci * PS * PS, N = Co * OS * OS;
     const int total = N * K;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    for (int i = first; i < total; i += step) {
         const int n = i / K, k = i - n * K;
         const int co = n / (OS * OS), op = n - co * (OS * OS), oy = op / OS, ox = op - oy * OS;
         const int ci = octets ? (k / (PS * PS * 8)) * 8 + (k & 7) : k / (PS * PS);
@@ -107,9 +107,10 @@ __global__ void k_dense7_split(const float *__restrict__ w, int Co, int Ci, int 
     }
 }
 
-__global__ void k_split_rows(const float *__restrict__ w, int total, f16 *__restrict__ oh, f16 *__restrict__ ol)
+__device__ __forceinline__ void split_rows(const float *__restrict__ w, int total, f16 *__restrict__ oh, f16 *__restrict__ ol, int first,
+                                           int step)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    for (int i = first; i < total; i += step) {
         f16 h, l;
         split(w[i], h, l);
         oh[i] = h;
@@ -336,7 +337,7 @@ __device__ __forceinline__ void px16_window_sum(const unsigned char *img, int S,
     }
 }
 
-// 12x12: rows [B][64 * 36] with the columns in (octet, pooled pixel, channel) order (k_dense7_split's `octets` order): a
+// 12x12: rows [B][64 * 36] with the columns in (octet, pooled pixel, channel) order (dense7_split's `octets` order): a
 // thread pools one (octet, pooled pixel) — eight channels — and writes their 16 bytes per half; no LDS, no barrier.
 __global__ __launch_bounds__(256) void k_pool_split12_px(const unsigned char *__restrict__ x, int64_t B, f16 *__restrict__ oh,
                                                          f16 *__restrict__ ol)
@@ -390,10 +391,10 @@ __global__ __launch_bounds__(256) void k_pool_split26_px(const unsigned char *__
 }
 
 // conv7's weight [64][64][7][7] -> [co][tap = 7 ky + kx][ci], split: the W matrix of the CONV7 GEMM
-__global__ void k_conv7w_split(const float *__restrict__ w, f16 *__restrict__ oh, f16 *__restrict__ ol)
+__device__ __forceinline__ void conv7w_split(const float *__restrict__ w, f16 *__restrict__ oh, f16 *__restrict__ ol, int first, int step)
 {
     const int total = 64 * 49 * 64;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    for (int i = first; i < total; i += step) {
         const int co = i / (49 * 64), r = i - co * (49 * 64), tap = r / 64, ci = r - tap * 64;
         f16 h, l;
         split(w[((size_t)co * 64 + ci) * 49 + tap], h, l);
@@ -404,15 +405,39 @@ __global__ void k_conv7w_split(const float *__restrict__ w, f16 *__restrict__ oh
 
 // fc1's weight [256][64 * 49] (columns in NCHW flatten order co * 49 + p) -> columns in the CONV7 GEMM's output order
 // p * 64 + co, split
-__global__ void k_fc1_split_nhwc(const float *__restrict__ w, f16 *__restrict__ oh, f16 *__restrict__ ol)
+__device__ __forceinline__ void fc1_split_nhwc(const float *__restrict__ w, f16 *__restrict__ oh, f16 *__restrict__ ol, int first, int step)
 {
     const int total = 256 * 3136;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    for (int i = first; i < total; i += step) {
         const int n = i / 3136, k = i - n * 3136, p = k / 64, co = k - p * 64;
         f16 h, l;
         split(w[(size_t)n * 3136 + co * 49 + p], h, l);
         oh[i] = h;
         ol[i] = l;
+    }
+}
+
+// Every weight of the head in the form its GEMM wants, in ONE launch (blockIdx.y = which): conv7 (dense matrix at 12x12,
+// [co][tap][ci] at 26x26), fc1 (columns permuted at 26x26), fc2, actor1 — four launches of ~5 us each otherwise, per forward.
+struct HeadWeights {
+    const float *conv7, *fc1, *fc2, *actor1;
+    f16 *d7h, *d7l, *w1h, *w1l, *w2h, *w2l, *w3h, *w3l;
+    int side26, octets, n_fc1;
+};
+__global__ void k_head_weights(HeadWeights a)
+{
+    const int first = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+    switch (blockIdx.y) {
+    case 0:
+        if (a.side26) conv7w_split(a.conv7, a.d7h, a.d7l, first, step);
+        else dense7_split(a.conv7, 64, 64, 6, 3, a.octets, a.d7h, a.d7l, first, step);
+        break;
+    case 1:
+        if (a.side26) fc1_split_nhwc(a.fc1, a.w1h, a.w1l, first, step);
+        else split_rows(a.fc1, a.n_fc1, a.w1h, a.w1l, first, step);
+        break;
+    case 2: split_rows(a.fc2, 128 * 256, a.w2h, a.w2l, first, step); break;
+    default: split_rows(a.actor1, 64 * 128, a.w3h, a.w3l, first, step); break;
     }
 }
 
@@ -430,7 +455,7 @@ constexpr int G_LDS = 2 * A_HALF + 2 * W_HALF;     // 61 440 bytes
 // zero-haloed channels-last split image [image][19 x 19 pixels][64 ci] (k_pool_split26), row m = (image, oy, ox) starts
 // at padded pixel (2 oy, 2 ox), and K chunk kc (64 channels of tap (ky, kx) = (kc / 7, kc % 7)) lies (19 ky + kx) pixels
 // further: an implicit GEMM whose im2col is two integer divisions per staged row.  W is conv7's weight as
-// [co][tap][ci] (k_conv7w_split); the output rows [image][oy][ox][co] are the next GEMM's A rows as they are.
+// [co][tap][ci] (conv7w_split); the output rows [image][oy][ox][co] are the next GEMM's A rows as they are.
 constexpr int P7_PIX = 19 * 19, O7 = 7, O7_PIX = O7 * O7;
 template <bool CONV7>
 __device__ __forceinline__ size_t a_row_bytes(int m, int K)
@@ -666,10 +691,9 @@ static int head_fwd(const void *trunk, bool px16, int64_t batch, int32_t side, c
         auto H = [&](int64_t off) { return reinterpret_cast<f16 *>(ws + off); };
         if (px16) hipLaunchKernelGGL(k_pool_split26_px, dim3((unsigned)((batch * 361 * 8 + 255) / 256 < (1 << 20) ? (batch * 361 * 8 + 255) / 256 : (1 << 20))), dim3(256), 0, st, trunk_px, batch, H(p.a7h), H(p.a7l));
         else hipLaunchKernelGGL(k_pool_split26, dim3((unsigned)(batch * 19)), dim3(256), 0, st, trunk_out, H(p.a7h), H(p.a7l));
-        hipLaunchKernelGGL(k_conv7w_split, dim3((64 * K7 + 255) / 256), dim3(256), 0, st, conv7_w, H(p.d7h), H(p.d7l));
-        hipLaunchKernelGGL(k_fc1_split_nhwc, dim3((256 * N1 + 255) / 256), dim3(256), 0, st, fc1_w, H(p.w1h), H(p.w1l));
-        hipLaunchKernelGGL(k_split_rows, dim3((128 * 256 + 255) / 256), dim3(256), 0, st, fc2_w, 128 * 256, H(p.w2h), H(p.w2l));
-        hipLaunchKernelGGL(k_split_rows, dim3((64 * 128 + 255) / 256), dim3(256), 0, st, actor1_w, 64 * 128, H(p.w3h), H(p.w3l));
+        const HeadWeights hw{conv7_w, fc1_w, fc2_w, actor1_w, H(p.d7h), H(p.d7l), H(p.w1h), H(p.w1l), H(p.w2h), H(p.w2l), H(p.w3h), H(p.w3l),
+                             1, 0, 256 * N1};
+        hipLaunchKernelGGL(k_head_weights, dim3(1024, 4), dim3(256), 0, st, hw);
         if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
         // conv7 as the implicit GEMM [B * 49] x [64] over K = 49 taps x 64 channels; its output rows are fc1's input rows
         int rc = gemm<true>(H(p.a7h), H(p.a7l), H(p.d7h), H(p.d7l), conv7_b, 1, batch * O7_PIX, 64, K7, 1, nullptr, H(p.c7h), H(p.c7l), st);
@@ -689,10 +713,9 @@ static int head_fwd(const void *trunk, bool px16, int64_t batch, int32_t side, c
     const int64_t nrows = batch * C * PS;
     if (px16) hipLaunchKernelGGL(k_pool_split12_px, dim3((unsigned)((batch * 288 + 255) / 256 < (1 << 20) ? (batch * 288 + 255) / 256 : (1 << 20))), dim3(256), 0, st, trunk_px, batch, H(p.a7h), H(p.a7l));
     else hipLaunchKernelGGL(k_pool_split12, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, trunk_out, nrows, H(p.a7h), H(p.a7l));
-    hipLaunchKernelGGL(k_dense7_split, dim3((N7 * K7 + 255) / 256), dim3(256), 0, st, conv7_w, C, C, PS, OS, px16 ? 1 : 0, H(p.d7h), H(p.d7l));
-    hipLaunchKernelGGL(k_split_rows, dim3((256 * N7 + 255) / 256), dim3(256), 0, st, fc1_w, 256 * N7, H(p.w1h), H(p.w1l));
-    hipLaunchKernelGGL(k_split_rows, dim3((128 * 256 + 255) / 256), dim3(256), 0, st, fc2_w, 128 * 256, H(p.w2h), H(p.w2l));
-    hipLaunchKernelGGL(k_split_rows, dim3((64 * 128 + 255) / 256), dim3(256), 0, st, actor1_w, 64 * 128, H(p.w3h), H(p.w3l));
+    const HeadWeights hw{conv7_w, fc1_w, fc2_w, actor1_w, H(p.d7h), H(p.d7l), H(p.w1h), H(p.w1l), H(p.w2h), H(p.w2l), H(p.w3h), H(p.w3l),
+                         0, px16 ? 1 : 0, 256 * N7};
+    hipLaunchKernelGGL(k_head_weights, dim3(1024, 4), dim3(256), 0, st, hw);
     if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
     int rc = gemm<false>(H(p.a7h), H(p.a7l), H(p.d7h), H(p.d7l), conv7_b, OS * OS, batch, N7, K7, 1, nullptr, H(p.c7h), H(p.c7l), st);
     if (rc == TRON_OK) rc = gemm<false>(H(p.c7h), H(p.c7l), H(p.w1h), H(p.w1l), fc1_b, 1, batch, 256, N7, 1, nullptr, H(p.c1h), H(p.c1l), st);
