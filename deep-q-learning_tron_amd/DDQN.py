@@ -104,6 +104,37 @@ def all_reduce_mean_(flat, group=None):
     flat /= world
 
 
+class _TDLoss(torch.autograd.Function):
+    """The Double-DQN loss of DDQN.py:129-146 (gather, arg-max, gather, target, MSELoss) and its gradient at the local net's
+    Q-values as one launch of csrc/tron_dqn.hip instead of fourteen small ones."""
+
+    @staticmethod
+    def forward(ctx, q, actions, rewards, dones, ql_next, qt_next, gamma):
+        from tron import _native as nat
+        q = q.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=q.device)
+        grad_q = torch.empty_like(q)
+        with torch.cuda.device(q.device):
+            nat.check(nat.lib().tron_ddqn_td_loss(nat.ptr(q), nat.ptr(actions), nat.ptr(rewards), nat.ptr(dones), nat.ptr(ql_next),
+                                                  nat.ptr(qt_next), float(gamma), q.shape[0], nat.ptr(loss), nat.ptr(grad_q),
+                                                  nat.stream_ptr()), "tron_ddqn_td_loss")
+        ctx.save_for_backward(grad_q)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (grad_q,) = ctx.saved_tensors
+        return grad_q * grad_loss, None, None, None, None, None, None
+
+
+def _td_fusable(q, actions, rewards, dones, ql_next, qt_next):
+    return (q.is_cuda and q.dim() == 2 and q.shape[1] == 4 and q.dtype == torch.float32 and actions.dtype == torch.int64
+            and rewards.dtype == torch.float32 and dones.dtype == torch.float32 and ql_next.shape == q.shape == qt_next.shape
+            and all(t.is_contiguous() for t in (actions, rewards, dones, ql_next, qt_next))
+            and actions.numel() == rewards.numel() == dones.numel() == q.shape[0] and q.shape[0] > 0
+            and os.environ.get("TRON_TD_FUSED", "1") != "0")
+
+
 def average_gradients(model, group=None):
     """The model's gradients averaged over the ranks.  When every .grad is a view of one flat buffer (Agent.flat_grads:
     what the trainer sets up) that buffer is reduced as it is — no cat, no copy back; otherwise the gradients are
@@ -138,6 +169,7 @@ class Agent():
         fused = self.device.type == "cuda" and os.environ.get("TRON_ADAM_FUSED", "1") != "0"
         self.optimizer = optim.Adam(self.qnetwork_local.parameters(), fused=True) if fused else optim.Adam(self.qnetwork_local.parameters())
         self.epsilon = 0
+        self._eps_seed, self._eps_rank = (0x5EED if seed is None else int(seed)), int(rank)      # act_batch's exploration draws
         self.totalloss = 0
         self.batch_size = batch_size
         self.memory = (ReplayBuffer(4, buffer_size, batch_size, width, in_channels, seed=seed, rank=rank)
@@ -174,6 +206,16 @@ class Agent():
         """Batched epsilon-greedy on the device: obs f32 planes [B,C,S,S] — or, codes=True, the env's int8
         observation codes [B,S,S] — -> int8 actions [B].  The greedy forward runs on Net.infer (HIP conv kernels)."""
         greedy = self.qnetwork_local.infer(obs, codes=codes, greedy=True)
+        if (greedy.is_cuda and greedy.dtype == torch.int8 and greedy.is_contiguous() and torch.is_tensor(epsilon) and epsilon.is_cuda
+                and epsilon.dtype == torch.float32 and epsilon.numel() == 1):
+            # one launch (csrc/tron_dqn.hip): Philox draws keyed by (seed, rank) at counter (observation, call); epsilon stays on the device
+            from tron import _native as nat
+            out = torch.empty_like(greedy)
+            self._eps_calls = getattr(self, "_eps_calls", 0) + 1
+            with torch.cuda.device(greedy.device):
+                nat.check(nat.lib().tron_eps_greedy(nat.ptr(greedy), greedy.numel(), nat.ptr(epsilon.reshape(1)), self._eps_seed & 0xFFFFFFFF,
+                                                    self._eps_rank, self._eps_calls, nat.ptr(out), nat.stream_ptr()), "tron_eps_greedy")
+            return out
         rnd = torch.randint(0, self.action_size, greedy.shape, device=greedy.device, dtype=torch.int8)
         explore = torch.rand(greedy.shape, device=greedy.device) <= epsilon
         return torch.where(explore, rnd, greedy)
@@ -229,12 +271,19 @@ class Agent():
         self.qnetwork_local.train()
         self.qnetwork_target.eval()
         plane4 = self.memory.plane4 if self.memory is not None else 0.0
-        if states.dtype == torch.int8:
-            predicted_targets = self.qnetwork_local.forward_codes(states, plane4).gather(1, actions)
-        else:
-            predicted_targets = self.qnetwork_local(states).gather(1, actions)
-        labels = self.targets(rewards, next_state, dones, gamma, plane4)
-        loss = criterion(predicted_targets, labels)
+        q_all = self.qnetwork_local.forward_codes(states, plane4) if states.dtype == torch.int8 else self.qnetwork_local(states)
+        loss = None
+        if q_all.is_cuda:
+            codes = next_state.dtype == torch.int8
+            ql_next = self.qnetwork_local.infer(next_state, codes=codes, plane4=plane4)
+            qt_next = self.qnetwork_target.infer(next_state, codes=codes, plane4=plane4)
+            if _td_fusable(q_all, actions, rewards, dones, ql_next, qt_next):
+                loss = _TDLoss.apply(q_all, actions, rewards, dones, ql_next, qt_next, gamma)
+            else:
+                labels = rewards + (gamma * qt_next.gather(1, ql_next.max(1)[1].unsqueeze(1).long()) * (1 - dones))
+                loss = criterion(q_all.gather(1, actions), labels)
+        if loss is None:
+            loss = criterion(q_all.gather(1, actions), self.targets(rewards, next_state, dones, gamma, plane4))
         self.totalloss += loss.detach()
         # One rank per GPU: every .grad is a view of one flat buffer (one fill, one collective).  A single process has
         # nothing to reduce, and a .grad that exists makes autograd ACCUMULATE into it — one small add kernel per
@@ -350,6 +399,9 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
     decays_max = torch.tensor(_decays_left(eps0), dtype=torch.int64, device=dev)
     eps_d = torch.tensor(eps0, dtype=torch.float64, device=dev)
     decay_d = torch.tensor(DECAY_RATE, dtype=torch.float64, device=dev)
+    # the same bookkeeping as ONE launch per env step (tron_eps_schedule) when the env is on the GPU: {games, cycles, decays, decays_max}
+    sched = torch.tensor([0, 0, 0, _decays_left(eps0)], dtype=torch.int64, device=dev) if dev.type == "cuda" else None
+    eps_f32 = torch.tensor([eps0], dtype=torch.float32, device=dev)
     learn_steps, transitions, games_seen = 0, 0, 0
     writer = None
     if log_dir and rank == 0:
@@ -358,7 +410,7 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(steps):
-        actions = brain.act_batch(codes, eps_d.to(torch.float32), codes=True).reshape(n_envs, 2)   # conv1 reads the codes
+        actions = brain.act_batch(codes, eps_f32 if sched is not None else eps_d.to(torch.float32), codes=True).reshape(n_envs, 2)   # conv1 reads the codes
         brain.finish_learn()                       # (one rank per GPU: the previous learn step's all-reduce ran under this forward)
         if in_place:
             brain.memory.memory.add_states(codes)
@@ -372,16 +424,25 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
         codes = env.obs.reshape(2 * n_envs, S, S)
         if not in_place:
             codes = codes.clone()
-        games_d += done.sum()
+        if sched is None:
+            games_d += done.sum()
         if it % learn_every == learn_every - 1 and len(brain.memory) > batch_size:    # len(): a host counter
             brain.steps += 1
             brain.learn(brain.memory.sample_codes(), GAMMA, defer=True)   # the batch as int8 codes: conv1 and the target chain read them
             learn_steps += 1
         # DDQN.py:313-315, once per finished 20-game cycle
-        new_cycles = torch.div(games_d, GAME_CYCLE, rounding_mode="floor")
-        decays_d = torch.minimum(decays_d + (new_cycles - cycles_d), decays_max)
-        cycles_d = new_cycles
-        eps_d = eps0 * torch.pow(decay_d, decays_d)
+        if sched is not None:
+            from tron import _native as nat
+            d8 = done if done.dtype == torch.int8 else done.to(torch.int8)
+            with torch.cuda.device(dev):
+                nat.check(nat.lib().tron_eps_schedule(nat.ptr(d8.contiguous()), d8.numel(), nat.ptr(sched), GAME_CYCLE, eps0, DECAY_RATE,
+                                                      nat.ptr(eps_d.reshape(1)), nat.ptr(eps_f32), nat.stream_ptr()), "tron_eps_schedule")
+            games_d = sched[0]
+        else:
+            new_cycles = torch.div(games_d, GAME_CYCLE, rounding_mode="floor")
+            decays_d = torch.minimum(decays_d + (new_cycles - cycles_d), decays_max)
+            cycles_d = new_cycles
+            eps_d = eps0 * torch.pow(decay_d, decays_d)
         if log_every and rank == 0 and it % log_every == log_every - 1:
             loss, games_seen, epsilon = float(brain.get_loss()), int(games_d), float(eps_d)
             print(f"step {it + 1}: games {games_seen} eps {epsilon:.4f} loss {loss:.4f}", flush=True)

@@ -1,0 +1,141 @@
+// tron_dqn.hip — the small device-side pieces of the batched DDQN trainer around the network (DDQN.py:90-151,313-315):
+// each is a handful of elementwise / reduction steps that PyTorch runs as one ~5 us launch apiece — 14 for the loss, 4 for
+// the epsilon-greedy mix, 8 for the epsilon schedule — on tensors of a few thousand elements.  One launch each here:
+//   k_td_loss        the Double-DQN loss and its gradient at the local net's Q-values
+//   k_eps_greedy     actions = greedy or uniform random, per observation, with epsilon read from device memory
+//   k_eps_schedule   finished-game counter, 20-game cycles, epsilon = eps0 * rate ^ decays — without leaving the device
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tron_hip.h"
+#include "tron_device.hpp"
+
+namespace {
+
+constexpr int TD_THREADS = 1024;
+
+// loss = mean_b (q[b][a_b] - y_b)^2,  y_b = r_b + gamma * qt_next[b][argmax_a ql_next[b][a]] * (1 - done_b)   (DDQN.py:129-146:
+// gather, max(1)[1], gather, MSELoss).  grad_q[b][a] = 2 (q[b][a_b] - y_b) / B at a = a_b, 0 elsewhere.  One workgroup: the sum
+// runs in a fixed order (deterministic).  argmax takes the first maximum, as torch.max does.
+__global__ __launch_bounds__(TD_THREADS) void k_td_loss(const float *__restrict__ q, const int64_t *__restrict__ actions,
+                                                        const float *__restrict__ rewards, const float *__restrict__ dones,
+                                                        const float *__restrict__ ql_next, const float *__restrict__ qt_next, float gamma,
+                                                        int B, float *__restrict__ loss, float *__restrict__ grad_q)
+{
+    __shared__ float red[TD_THREADS / 64];
+    float acc = 0.0f;
+    const float inv = 1.0f / (float)B;
+    for (int b = threadIdx.x; b < B; b += TD_THREADS) {
+        const float4 ql = reinterpret_cast<const float4 *>(ql_next)[b], qt = reinterpret_cast<const float4 *>(qt_next)[b];
+        int am = 0;
+        float best = ql.x;
+        if (ql.y > best) { best = ql.y; am = 1; }
+        if (ql.z > best) { best = ql.z; am = 2; }
+        if (ql.w > best) { best = ql.w; am = 3; }
+        const float qn = am == 0 ? qt.x : am == 1 ? qt.y : am == 2 ? qt.z : qt.w;
+        const float y = rewards[b] + (gamma * qn) * (1.0f - dones[b]);
+        const int a = (int)actions[b] & 3;
+        const float4 qv = reinterpret_cast<const float4 *>(q)[b];
+        const float p = a == 0 ? qv.x : a == 1 ? qv.y : a == 2 ? qv.z : qv.w;
+        const float e = p - y;
+        acc += e * e;
+        const float g = 2.0f * e * inv;
+        reinterpret_cast<float4 *>(grad_q)[b] = make_float4(a == 0 ? g : 0.0f, a == 1 ? g : 0.0f, a == 2 ? g : 0.0f, a == 3 ? g : 0.0f);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.0f;
+        for (int k = 0; k < TD_THREADS / 64; ++k) s += red[k];
+        *loss = s * inv;
+    }
+}
+
+// DDQN.py:105-110 per observation: u <= epsilon ? uniform action : greedy.  One Philox block (key = seed, counter = call,
+// observation quad) gives four observations their two draws each.
+__global__ void k_eps_greedy(const int8_t *__restrict__ greedy, int64_t n, const float *__restrict__ epsilon, uint32_t seed,
+                             uint32_t stream, uint32_t call_lo, uint32_t call_hi, int8_t *__restrict__ out)
+{
+    const float eps = *epsilon;
+    const int64_t quads = (n + 3) / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t x[4];
+        tron::philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), call_lo, call_hi, seed, stream, x);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t j = 4 * i + k;
+            if (j >= n) break;
+            // 16 bits decide explore / exploit (u = (h + 0.5) / 65536 in (0, 1)), 2 bits the action
+            const float u = ((float)(x[k] >> 16) + 0.5f) * (1.0f / 65536.0f);
+            out[j] = u <= eps ? (int8_t)(x[k] & 3u) : greedy[j];
+        }
+    }
+}
+
+// DDQN.py:313-315 once per env step: games += finished; one decay of epsilon per finished 20-game cycle, at most
+// decays_max of them; epsilon = eps0 * rate ^ decays (the closed form of the repeated multiply).  state = {games, cycles,
+// decays, decays_max} (int64, device); one workgroup.
+__global__ __launch_bounds__(1024) void k_eps_schedule(const int8_t *__restrict__ done, int64_t n, int64_t *__restrict__ state,
+                                                       int64_t cycle, double eps0, double rate, double *__restrict__ eps_out,
+                                                       float *__restrict__ eps_out_f32)
+{
+    __shared__ int red[16];
+    int cnt = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) cnt += done[i] != 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int k = 0; k < 16; ++k) total += red[k];
+        const int64_t games = state[0] + total;
+        const int64_t cycles = games / cycle;
+        int64_t decays = state[2] + (cycles - state[1]);
+        decays = decays < state[3] ? decays : state[3];
+        state[0] = games;
+        state[1] = cycles;
+        state[2] = decays;
+        const double e = eps0 * pow(rate, (double)decays);
+        *eps_out = e;
+        *eps_out_f32 = (float)e;
+    }
+}
+
+}  // namespace
+
+extern "C" int tron_ddqn_td_loss(const float *q, const int64_t *actions, const float *rewards, const float *dones,
+                                 const float *q_local_next, const float *q_target_next, float gamma, int64_t batch, float *loss,
+                                 float *grad_q, void *stream)
+{
+    if (!q || !actions || !rewards || !dones || !q_local_next || !q_target_next || !loss || !grad_q || batch < 1) return TRON_ERR_BAD_ARG;
+    if (batch > (1ll << 24)) return TRON_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(q_local_next) | reinterpret_cast<uintptr_t>(q_target_next) |
+         reinterpret_cast<uintptr_t>(grad_q)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_td_loss, dim3(1), dim3(TD_THREADS), 0, reinterpret_cast<hipStream_t>(stream), q, actions, rewards, dones,
+                       q_local_next, q_target_next, gamma, (int)batch, loss, grad_q);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int tron_eps_greedy(const int8_t *greedy, int64_t n, const float *epsilon, uint32_t seed, uint32_t stream_id,
+                               uint64_t call, int8_t *actions, void *stream)
+{
+    if (!greedy || !epsilon || !actions || n < 0) return TRON_ERR_BAD_ARG;
+    if (n == 0) return TRON_OK;
+    const int64_t quads = (n + 3) / 4, blocks = (quads + 255) / 256;
+    hipLaunchKernelGGL(k_eps_greedy, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       greedy, n, epsilon, seed, stream_id, (uint32_t)call, (uint32_t)(call >> 32), actions);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int tron_eps_schedule(const int8_t *done, int64_t n, int64_t *state4, int64_t games_per_cycle, double eps0, double rate,
+                                 double *epsilon_out, float *epsilon_out_f32, void *stream)
+{
+    if (!done || !state4 || !epsilon_out || !epsilon_out_f32 || n < 0 || games_per_cycle < 1) return TRON_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_eps_schedule, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), done, n, state4, games_per_cycle,
+                       eps0, rate, epsilon_out, epsilon_out_f32);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}

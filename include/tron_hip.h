@@ -219,6 +219,24 @@ int tron_replay_sample(tron_replay_handle r, int32_t batch, int32_t channels, fl
 int tron_replay_sample_codes(tron_replay_handle r, int32_t batch, int8_t *states, int64_t *actions, float *rewards,
                              int8_t *next_states, float *dones, void *stream);
 int tron_replay_size(tron_replay_handle r, int64_t *size, int64_t *capacity);
+
+/* ---- the trainer's small device-side steps around the network, one launch each (csrc/tron_dqn.hip) ---------------
+ * tron_ddqn_td_loss: the Double-DQN loss of DDQN.py:129-146 and its gradient at the local net's Q-values:
+ *   y = rewards + gamma * q_target_next[b][argmax_a q_local_next[b][a]] * (1 - dones),  loss = mean (q[b][actions[b]] - y)^2,
+ *   grad_q[b][a] = 2 (q[b][a] - y) / batch at a = actions[b], else 0.  q / q_*_next / grad_q f32[batch][4] (16-byte aligned),
+ *   actions i64[batch], rewards / dones f32[batch], loss f32[1]; sums in a fixed order.
+ * tron_eps_greedy: DDQN.py:105-110 for n observations: actions[i] = u_i <= *epsilon ? uniform{0..3} : greedy[i]; epsilon is
+ *   read on the device; draws are Philox-4x32-10 keyed (seed, stream_id) at counter (i / 4, call).
+ * tron_eps_schedule: DDQN.py:313-315 per env step: state4 = {games, cycles, decays, decays_max} (i64 on the device):
+ *   games += count(done != 0); cycles = games / games_per_cycle; decays = min(decays + new cycles, decays_max);
+ *   epsilon = eps0 * rate ^ decays, written as f64 and f32 — nothing is read back.                                  */
+int tron_ddqn_td_loss(const float *q, const int64_t *actions, const float *rewards, const float *dones,
+                      const float *q_local_next, const float *q_target_next, float gamma, int64_t batch, float *loss,
+                      float *grad_q, void *stream);
+int tron_eps_greedy(const int8_t *greedy, int64_t n, const float *epsilon, uint32_t seed, uint32_t stream_id, uint64_t call,
+                    int8_t *actions, void *stream);
+int tron_eps_schedule(const int8_t *done, int64_t n, int64_t *state4, int64_t games_per_cycle, double eps0, double rate,
+                      double *epsilon_out, float *epsilon_out_f32, void *stream);
 /* The slots drawn by the last tron_replay_sample, i64[batch] (tests, logging). */
 int tron_replay_indices(tron_replay_handle r, int32_t batch, int64_t *indices_out, void *stream);
 
