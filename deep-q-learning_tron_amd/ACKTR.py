@@ -68,11 +68,30 @@ class Brain(object):
         v = getattr(args, "v", None)
         self.policy_loss_coef = config.policy_loss_coef if p is None else float(p)
         self.value_loss_coef = config.value_loss_coef if v is None else float(v)
+        # the sampled-Fisher backward pass computes statistics only (see update()); TRON_ACKTR_FISHER_FULL=1: as two full passes
+        self.fisher_stats_only = os.environ.get("TRON_ACKTR_FISHER_FULL", "0") == "0"
+        self._cheap = None
         if acktr:
             self.optimizer = KFACOptimizer(self.actor_critic)
         else:
             self.optimizer = optim.RMSprop(self.actor_critic.parameters(), config.lr, eps=config.eps,
                                            alpha=config.alpha)
+
+    def _cheap_parameters(self):
+        """Every parameter except the weights whose gradient is a large product (convolutions over >= 16 input channels,
+        Linear layers with >= 1024 inputs): biases, the first convolution, the small Linear layers.  Asking autograd for
+        these reaches every module of the net (each module's output gradient is needed on the way down), which is all
+        the statistics pass needs."""
+        if self._cheap is None:
+            import torch.nn as nn
+            heavy = set()
+            for m in self.actor_critic.modules():
+                if isinstance(m, nn.Conv2d) and m.in_channels >= 16:
+                    heavy.add(id(m.weight))
+                elif isinstance(m, nn.Linear) and m.in_features >= 1024:
+                    heavy.add(id(m.weight))
+            self._cheap = [p for p in self.actor_critic.parameters() if id(p) not in heavy and p.requires_grad]
+        return self._cheap
 
     def update(self, rollouts, micro_batch=None):
         """One update from a full rollout (ACKTR.py:88-159).  With `micro_batch`, the T*N samples are
@@ -115,15 +134,32 @@ class Brain(object):
                 pg_fisher_loss = -action_log_probs.mean()
                 sample_values = values + noise[lo:hi]
                 vf_fisher_loss = -(values - sample_values.detach()).pow(2).mean()
+                fisher_loss = pg_fisher_loss + vf_fisher_loss
                 self.optimizer.acc_stats = True
-                ((pg_fisher_loss + vf_fisher_loss) * w).backward(retain_graph=True)
+                if self.fisher_stats_only:
+                    # This pass exists for K-FAC's gradient statistics (the hooks on every module's output gradient);
+                    # weight gradients are a by-product — and the expensive half of a backward pass.  Ask autograd only
+                    # for the cheap parameters (every module's hook still fires: its input gradient is on the way to
+                    # them), drop what that leaves in .grad, and let the loss pass below carry the Fisher loss as well.
+                    from Net import activations
+                    activations.skip_weight_gradients = True        # (the hand-written convolution nodes: see there)
+                    try:
+                        (fisher_loss * w).backward(retain_graph=True, inputs=self._cheap_parameters())
+                    finally:
+                        activations.skip_weight_gradients = False
+                    self.actor_critic.zero_grad()
+                else:
+                    (fisher_loss * w).backward(retain_graph=True)
                 self.optimizer.acc_stats = False
                 # NB the reference does not clear .grad here (ACKTR.py:131-150): the Fisher loss's
-                # gradient stays in and is added to the update's gradient.  Honoured.
+                # gradient stays in and is added to the update's gradient.  Honoured (either way: d(fisher) + d(total)).
             # the reference's loss reads the coefficients from config, not from the Brain (ACKTR.py:147-148)
             total = (value_loss * config.value_loss_coef - action_gain * config.policy_loss_coef
                      - entropy * config.entropy_coef)
-            (total * w).backward()
+            if fisher and self.fisher_stats_only:
+                ((total + fisher_loss) * w).backward()
+            else:
+                (total * w).backward()
             if split and fisher:                        # keep this slice's gradient: the next Fisher pass zeroes .grad
                 g = [p.grad.detach().clone() for p in self.actor_critic.parameters()]
                 grads = g if grads is None else [x.add_(y) for x, y in zip(grads, g)]

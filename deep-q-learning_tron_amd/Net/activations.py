@@ -131,6 +131,12 @@ class _Conv1CodesHIP(torch.autograd.Function):
         return None, gw, (gb if ctx.needs_input_grad[2] else None), None
 
 
+# Set (by ACKTR.Brain.update) around a backward pass that exists only for K-FAC's gradient statistics: a custom Function's
+# ctx.needs_input_grad is fixed at forward time, so `backward(inputs=...)` alone cannot tell it that nobody wants the weight
+# gradient of this pass; the library operators learn it from the engine.
+skip_weight_gradients = False
+
+
 class _Conv3x3HIP(torch.autograd.Function):
     """conv3x3(x, weight, padding=1) (+ bias) alone — no activation — on the hand-written kernels, for modules whose bias
     and activation are separate layers: the ACKTR nets after KFACOptimizer split their biases (Net/kfac.py::SplitBias),
@@ -159,7 +165,7 @@ class _Conv3x3HIP(torch.autograd.Function):
             else:
                 gx = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not (skip_weight_gradients and weight.shape[1] >= 16):
             if fused.wgrad_supported(weight, x.shape[-1]):
                 gw = fused.conv3x3_wgrad(x, g, absmax)
             else:                                             # (34x34: the weight gradient stays on the library)
