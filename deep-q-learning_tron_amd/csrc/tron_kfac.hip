@@ -278,12 +278,13 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gram_f16x3(const f16 *__restri
 // The same product on 128 x 128 tiles fed by LDS-DMA (TRON_GRAM_V2, the default).  k_gram_f16x3 above stages its operands
 // through registers and ds_write_b128 — 48 stores per K chunk and workgroup at 13 LDS cycles each keep the CU's one store
 // path busy 80 % of the time — and its 128 x 64 tiles pull 49 KB from L2 per 1 M MACs.  Here a 16-wave workgroup (one per CU,
-// 4 waves per SIMD, each wave a 32 x 32 sub-tile) owns a 128 x 128 tile; a K chunk of 64 — rows m0 .. m0+127 and
-// n0 .. n0+127 of X, hi and lo: 64 KB — is copied global -> LDS by 64 `global_load_lds_dwordx4` (4 per wave), double
-// buffered, one barrier per chunk.  LDS rows are 128 bytes without padding; a row's eight 16-byte pieces are stored XOR-ed
-// with (row & 7) — the per-lane SOURCE address does the swizzle, the destination of an LDS-DMA is linear — which puts the
-// 16 lanes of every ds_read_b128 group on 16 different bank quads (rows r, r+4, r+8, r+12 of a group differ in row & 7).
-constexpr int G2_T = 128, G2_K = 64, G2_THREADS = 1024, G2_BUF = 2 * 2 * G2_T * G2_K * 2, G2_LDS = 2 * G2_BUF;   // 64 KB per buffer
+// 4 waves per SIMD, each wave a 32 x 32 sub-tile) owns a 128 x 128 tile; a K chunk of 32 — rows m0 .. m0+127 and
+// n0 .. n0+127 of X, hi and lo: 32 KB — is copied global -> LDS by 32 `global_load_lds_dwordx4` (2 per wave) into a ring of
+// FOUR stages: three chunks in flight while one is multiplied, one barrier per chunk.  LDS rows are 64 bytes without padding;
+// a row's four 16-byte pieces are stored XOR-ed with (-(row >> 2)) & 3 — the per-lane SOURCE address does the swizzle, the
+// destination of an LDS-DMA is linear — which puts the 16 lanes of every ds_read_b128 group on 16 different bank quads.
+constexpr int G2_T = 128, G2_K = 32, G2_THREADS = 1024, G2_STAGES = 4;
+constexpr int G2_STAGE = 2 * 2 * G2_T * G2_K * 2, G2_LDS = G2_STAGES * G2_STAGE;          // 32 KB per stage, 128 KB
 
 __global__ __launch_bounds__(G2_THREADS, 4) void k_gram2_f16x3(const f16 *__restrict__ Xh, const f16 *__restrict__ Xl, int d, int dpad,
                                                                int64_t pitch, int nk, int ksplit, float *__restrict__ partial)
@@ -298,20 +299,22 @@ __global__ __launch_bounds__(G2_THREADS, 4) void k_gram2_f16x3(const f16 *__rest
     const int k_lo = (int)((int64_t)nk * s / ksplit), k_hi = (int)((int64_t)nk * (s + 1) / ksplit);
     if (k_lo >= k_hi) return;
 
-    // this wave's four 1 KB blocks of a chunk's image [hi | lo][256 rows: A then W][128 B]: block b = wave + 16 j
-    const unsigned char *src[4];
+    // A stage = a K chunk of 32: [hi | lo][256 rows: A then W][64 B], 32 blocks of 1 KB (16 rows each); this wave copies blocks
+    // wave and wave + 16.  A row's four 16-byte pieces are stored at piece ^ sw(row), sw(row) = (-(row >> 2)) & 3: the four
+    // rows r, r+4, r+8, r+12 that share a ds_read_b128 lane group's bank span then sit in four different slots.
+    const unsigned char *src[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int b = wave + 16 * j, half = b >> 5, row = 8 * (b & 31) + (lane >> 3), piece = (lane & 7) ^ (row & 7);
+    for (int j = 0; j < 2; ++j) {
+        const int b = wave + 16 * j, half = b >> 4, row = 16 * (b & 15) + (lane >> 2), piece = (lane & 3) ^ ((0 - (row >> 2)) & 3);
         int grow = row < G2_T ? m0 + row : n0 + row - G2_T;
         grow = grow < dpad ? grow : dpad - 1;
         src[j] = reinterpret_cast<const unsigned char *>(half ? Xl : Xh) + (size_t)grow * pitch * 2 + piece * 16;
     }
-    auto dma_chunk = [&](int kc, int buf) {
+    auto dma_chunk = [&](int kc, int stage) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[j] + (size_t)kc * (G2_K * 2)),
-                                             (__attribute__((address_space(3))) void *)(lds + buf * G2_BUF + (wave + 16 * j) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(lds + stage * G2_STAGE + (wave + 16 * j) * 1024), 16, 0, 0);
     };
 
     f32x4 acc0[2][2], acc1[2][2];
@@ -322,50 +325,50 @@ __global__ __launch_bounds__(G2_THREADS, 4) void k_gram2_f16x3(const f16 *__rest
             acc0[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc1[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    // fragment addresses: row r, k pieces 4 sl + g of the slab, stored at piece ^ (r & 7); the lo image lies 32 KB further
-    int a_off[2], b_off[2], a_sw[2], b_sw[2];
+    int a_off[2], b_off[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int ra = wm * 32 + t * 16 + li, rb = G2_T + wn * 32 + t * 16 + li;
-        a_off[t] = ra * 128;
-        a_sw[t] = ra & 7;
-        b_off[t] = rb * 128;
-        b_sw[t] = rb & 7;
+        a_off[t] = ra * 64 + ((g ^ ((0 - (ra >> 2)) & 3)) * 16);
+        b_off[t] = rb * 64 + ((g ^ ((0 - (rb >> 2)) & 3)) * 16);
     }
+    // Three chunks are in flight while one is multiplied (a chunk's 32 KB take longer to arrive than its 768 MFMA cycles per
+    // SIMD last): chunk c lives in stage (c - k_lo) % 4; every iteration issues exactly one chunk (past the end: the last one
+    // again, unused), so "this wave's copies of the chunk about to be used have landed" is always vmcnt(4).
+    const int last = k_hi - 1;
     dma_chunk(k_lo, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    dma_chunk(k_lo + 1 < k_hi ? k_lo + 1 : last, 1);
+    dma_chunk(k_lo + 2 < k_hi ? k_lo + 2 : last, 2);
     for (int kc = k_lo; kc < k_hi; ++kc) {
-        const int cur = (kc - k_lo) & 1;
-        dma_chunk(kc + 1 < k_hi ? kc + 1 : kc, cur ^ 1);                 // (the last chunk is fetched again: no branch around the DMA)
-        const unsigned char *base = lds + cur * G2_BUF;
+        const int st = (kc - k_lo) & 3;
+        // (a bare s_barrier: __syncthreads() carries a fence, and with LDS-DMA writes in flight hipcc turns that into vmcnt(0) —
+        //  draining the three chunks this ring exists to keep in flight; the counted wait above is all the ordering needed:
+        //  LDS is only written by these copies and only read below)
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");     // everybody's copies of chunk kc are in; stage (st + 3) % 4 is free
+        dma_chunk(kc + 3 < k_hi ? kc + 3 : last, (st + 3) & 3);
+        const unsigned char *base = lds + st * G2_STAGE;
+        f16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-        for (int sl = 0; sl < G2_K / 32; ++sl) {
-            f16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int pa = ((4 * sl + g) ^ a_sw[t]) * 16, pb = ((4 * sl + g) ^ b_sw[t]) * 16;
-                ah[t] = *reinterpret_cast<const f16x8 *>(base + a_off[t] + pa);
-                al[t] = *reinterpret_cast<const f16x8 *>(base + G2_BUF / 2 + a_off[t] + pa);
-                bh[t] = *reinterpret_cast<const f16x8 *>(base + b_off[t] + pb);
-                bl[t] = *reinterpret_cast<const f16x8 *>(base + G2_BUF / 2 + b_off[t] + pb);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc1[t][n], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc0[t][n], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc1[t][n], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) {
+            ah[t] = *reinterpret_cast<const f16x8 *>(base + a_off[t]);
+            al[t] = *reinterpret_cast<const f16x8 *>(base + G2_STAGE / 2 + a_off[t]);
+            bh[t] = *reinterpret_cast<const f16x8 *>(base + b_off[t]);
+            bl[t] = *reinterpret_cast<const f16x8 *>(base + G2_STAGE / 2 + b_off[t]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's pieces of the next chunk have landed ...
-        __syncthreads();                                                // ... everybody's have, and nobody reads this buffer any more
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc1[t][n], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc0[t][n], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc1[t][n], 0, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (the surplus copies: nothing may still be writing LDS at exit)
     float *out = partial + (size_t)s * d * dpad;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
