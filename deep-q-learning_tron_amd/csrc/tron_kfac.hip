@@ -137,6 +137,53 @@ __global__ __launch_bounds__(256) void k_patches_t(const float *__restrict__ x, 
     }
 }
 
+// The same matrix written plane by plane: a workgroup = one (image, channel) plane, staged once in LDS with its zero
+// halo; the kh * kw patch columns of that channel are shifted views of the staged plane, written four output positions
+// per thread (8-byte stores: rows of an image start at image * OH * OW, a multiple of 4 when OH * OW is).  The image tensor is
+// read once instead of kh * kw times, the index arithmetic is LDS-local, the kernel runs at the rate of its stores.  The
+// last image's workgroups also zero the K padding (rows .. rows_pad) of their columns.
+__global__ __launch_bounds__(256) void k_patches_t_plane(const float *__restrict__ x, int n_img, int C, int H, int W, int kh, int kw,
+                                                         int pad, int stride, int OH, int OW, int64_t rows, int64_t rows_pad,
+                                                         const float *__restrict__ in_scale, f16 *__restrict__ xh, f16 *__restrict__ xl)
+{
+    extern __shared__ float plane[];                                     // [(H + 2 pad)][(W + 2 pad)]
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const float sc = ACT_SCALE * (in_scale ? *in_scale : 1.0f);
+    const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const float *src = x + ((size_t)b * C + c) * H * W;
+    for (int i = threadIdx.x; i < Hp * Wp; i += 256) {
+        const int y = i / Wp - pad, xx = i % Wp - pad;
+        plane[i] = ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) ? src[y * W + xx] * sc : 0.0f;
+    }
+    __syncthreads();
+    const int per = OH * OW, quads = per / 4, taps = kh * kw;
+    const size_t r_img = (size_t)b * per;
+    for (int i = threadIdx.x; i < taps * quads; i += 256) {
+        const int t = i / quads, q = i - t * quads, ky = t / kw, kx = t - ky * kw;
+        f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int pos = 4 * q + e, oy = pos / OW, ox = pos - oy * OW;
+            f16 hh, ll;
+            split(plane[(oy * stride + ky) * Wp + ox * stride + kx], hh, ll);
+            h[e] = hh;
+            l[e] = ll;
+        }
+        const size_t o = (size_t)(c * taps + t) * rows_pad + r_img + 4 * q;
+        *reinterpret_cast<f16x4 *>(xh + o) = h;
+        *reinterpret_cast<f16x4 *>(xl + o) = l;
+    }
+    if (b == n_img - 1) {                                                // the K padding of this channel's columns
+        const int tail = (int)(rows_pad - rows);
+        for (int i = threadIdx.x; i < taps * tail; i += 256) {
+            const size_t o = (size_t)(c * taps + i / tail) * rows_pad + rows + i % tail;
+            xh[o] = (f16)0.0f;
+            xl[o] = (f16)0.0f;
+        }
+    }
+}
+
 // a f32 [rows][d] -> a^T split [dpad][rows_pad]; a workgroup = a 64 x 64 tile through LDS (reads along d, writes along rows)
 __global__ __launch_bounds__(256) void k_transpose_split(const float *__restrict__ a, int64_t rows, int d, int dpad, int64_t rows_pad,
                                                          const float *__restrict__ in_scale, f16 *__restrict__ xh, f16 *__restrict__ xl)
@@ -493,6 +540,17 @@ extern "C" int tron_kfac_patch_gram(const float *x, int64_t batch, int32_t chann
     for (int64_t i = 0; i < batch; i += imgs_chunk) {
         const int64_t n = batch - i < imgs_chunk ? batch - i : imgs_chunk;
         const int64_t rows = n * per, rows_pad = (rows + 63) / 64 * 64;
+        const size_t plane_bytes = (size_t)(height + 2 * pad) * (width + 2 * pad) * sizeof(float);
+        if (per % 4 == 0 && plane_bytes <= 48 * 1024 && n * channels < (1ll << 31)) {
+            // (columns d .. dpad of the operand stay unwritten: k_gram2 clamps its row index to dpad - 1 and never stores what those
+            //  rows produce where k_gram_finish reads)
+            hipLaunchKernelGGL(k_patches_t_plane, dim3((unsigned)(n * channels)), dim3(256), plane_bytes, st,
+                               x + (size_t)i * channels * height * width, (int)n, channels, height, width, kh, kw, pad, stride, OH, OW, rows,
+                               rows_pad, in_scale, xh, xl);
+            const int rc = gram_pass(xh, xl, p, d, rows_pad, partial, st);
+            if (rc != TRON_OK) return rc;
+            continue;
+        }
         int64_t gblocks = (rows_pad / 8 + 255) / 256;                    // (x: groups of 8 rows, grid-stride; y: patch column)
         const int64_t want = 8192 / p.dpad > 0 ? 8192 / p.dpad : 1;       // ~32 workgroups per CU over the launch, tens of items per thread
         if (gblocks > want) gblocks = want;
