@@ -66,6 +66,17 @@ class SplitBias(nn.Module):
     def forward(self, input, residual=None, act=False):
         """add_bias(module(input)); with act=True: mish(add_bias(module(input)) + residual) — what every conv layer of the
         nets' trunk is followed by (ACNet.py:97-116) — fused behind the (still hooked) module where the kernels cover it."""
+        if act and not torch.is_grad_enabled():
+            # gradient-free forwards (the rollouts' acting): nothing to hook, so bias, residual and activation ride in the
+            # convolution kernel's epilogue instead of a pass of their own
+            from Net import fused
+            from Net.activations import Conv3x3, _aligned16
+            m = self.module
+            if (isinstance(m, Conv3x3) and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and input.shape[0] > 0
+                    and input.shape[-1] == input.shape[-2] and input.shape[1] == m.in_channels and fused.supported(m, input.shape[-1])
+                    and m.in_channels in (3, 4, 32, 64) and _aligned16(input, residual)
+                    and (residual is None or (residual.dtype == torch.float32 and residual.is_contiguous()))):
+                return fused.conv3x3_raw(input.contiguous(), m.weight, self.add_bias._bias.reshape(-1), residual, act=True)
         y = self.module(input)
         if act:
             from Net.activations import bias_mish_supported, mish

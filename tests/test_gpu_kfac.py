@@ -211,6 +211,9 @@ def test_fused_bias_residual_mish_keeps_kfac_statistics(width, model, monkeypatc
     assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-5 and (outs[0][1] - outs[1][1]).abs().max().item() < 1e-5
     for (name, p), (_, r) in zip(net.named_parameters(), ref.named_parameters()):
         assert (p.grad - r.grad).abs().max().item() / (r.grad.abs().max().item() + 1e-30) < 1e-4, name
+    with torch.no_grad():            # gradient-free forwards put bias / residual / activation into the convolution's epilogue
+        v0, a0 = net(x, *extra)
+    assert (v0 - outs[0][0]).abs().max().item() < 1e-5 and (torch.log_softmax(a0, 1).gather(1, acts) - outs[0][1]).abs().max().item() < 1e-5
     for ma, mb in zip(opts[0].modules, opts[1].modules):
         for store in ("m_aa", "m_gg"):
             a, b = getattr(opts[0], store)[ma], getattr(opts[1], store)[mb]
