@@ -163,6 +163,39 @@ def test_learn_step_at_the_learn_batch_matches_float64(fused):
         assert err < 5e-5 * scale, (n, err, scale)
 
 
+@pytest.mark.parametrize("W", [10, 24])
+def test_trunk_node_at_the_learn_batch(fused, W):
+    """Agent.learn() at batch 4 096 from int8 codes — the trunk as one autograd node with the fused input-gradient /
+    activation-backward launches (tron_conv3x3_dgrad_mish), the one-launch loss — against the layer-by-layer graph with the
+    composed loss: the same loss and, to rounding, the same gradient for every parameter (both configs' observation sizes)."""
+    import copy
+    import DDQN
+    torch.manual_seed(W)
+    B = 4096
+    a1 = DDQN.Agent(W, 3, device="cuda", make_memory=False, seed=3)
+    a1.qnetwork_local.dropout.p = 0.0
+    a2 = copy.deepcopy(a1)
+    a2.qnetwork_local.fuse_trunk = False
+    s, s2 = _codes(B, W + 2, 1), _codes(B, W + 2, 2)
+    act = torch.randint(0, 4, (B, 1), device="cuda")
+    r = torch.randn(B, 1, device="cuda")
+    d = (torch.rand(B, 1, device="cuda") < 0.3).float()
+    grads = []
+    for agent, fused_td in ((a1, "1"), (a2, "0")):
+        import os
+        os.environ["TRON_TD_FUSED"] = fused_td
+        try:
+            agent.optimizer = torch.optim.SGD(agent.qnetwork_local.parameters(), lr=0.0)     # keep the weights: compare gradients
+            loss = agent.learn((s, act, r, s2, d), DDQN.GAMMA)
+        finally:
+            os.environ.pop("TRON_TD_FUSED", None)
+        grads.append((loss, [p.grad.clone() for p in agent.qnetwork_local.parameters()]))
+    assert abs(grads[0][0].item() - grads[1][0].item()) < 1e-6 * max(1.0, abs(grads[1][0].item()))
+    for (name, _), g1, g2 in zip(a1.qnetwork_local.named_parameters(), grads[0][1], grads[1][1]):
+        scale = g2.abs().max().item() + 1e-30
+        assert (g1 - g2).abs().max().item() / scale < 3e-5, name
+
+
 PROBE = ["conv1.module.weight", "conv1.add_bias._bias", "conv7.module.weight", "fc1.module.weight",
          "actor2.module.weight", "critic3.add_bias._bias"]
 
