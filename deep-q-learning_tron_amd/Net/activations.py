@@ -156,8 +156,11 @@ class _Conv3x3HIP(torch.autograd.Function):
         g = grad_out.contiguous()
         if not _aligned16(g):
             g = g.clone(memory_format=torch.contiguous_format)
-        lo, hi = torch.aminmax(g)                             # one pass: the gradient's scale on its way into f16 (tron_conv3x3_dgrad)
-        absmax = torch.maximum(hi, -lo).reshape(1)
+        from tron import _native as nat                       # max |g| in one launch: the gradient's scale on its way into f16 (tron_conv3x3_dgrad)
+        o4 = torch.zeros(4, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            nat.check(nat.lib().tron_absmax_pow2(nat.ptr(g), g.numel(), 16, nat.ptr(o4), nat.stream_ptr()), "tron_absmax_pow2")
+        absmax = o4[1:2]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if weight.shape[1] in (32, 64):
@@ -369,7 +372,10 @@ class _PoolConv7(torch.autograd.Function):
             nat.check(L.tron_pool12(nat.ptr(x), nat.ptr(pooled), B * C, 0, st), "tron_pool12")
             dense = torch.empty(Co * 9, C * 36, dtype=torch.float32, device=x.device)
             nat.check(L.tron_conv7_dense(nat.ptr(weight), nat.ptr(dense), Co, C, 0, st), "tron_conv7_dense")
-            pre = torch.addmm(bias.repeat_interleave(9), pooled, dense.t())
+            from Net import fused
+            pre = fused.gemm_f16x3(pooled, dense, bias.repeat_interleave(9))            # [B, Ci*36] x [Co*9, Ci*36]^T
+            if pre is None:
+                pre = torch.addmm(bias.repeat_interleave(9), pooled, dense.t())
             out = torch.empty_like(pre)
             nat.check(L.tron_mish_fwd(nat.ptr(pre), nat.ptr(out), pre.numel(), st), "tron_mish_fwd")
         ctx.save_for_backward(pooled, dense, pre)
@@ -391,12 +397,19 @@ class _PoolConv7(torch.autograd.Function):
         with torch.cuda.device(pre.device):
             gp = torch.empty_like(pre)
             nat.check(L.tron_mish_bwd(nat.ptr(pre), nat.ptr(g), nat.ptr(gp), pre.numel(), st), "tron_mish_bwd")
+            from Net import fused
+            from Net.kfac import _pow2_scale
+            sc = _pow2_scale(gp) if fused.use_gemm else None                # the gradient's scale on its way into f16 (a device scalar)
             if ctx.needs_input_grad[0]:
-                gpool = gp @ dense
+                gpool = fused.gemm_f16x3(gp, dense, b_transposed=True, a_scale=sc)       # gp [B, Co*9] x dense [Co*9, Ci*36]
+                if gpool is None:
+                    gpool = gp @ dense
                 gx = torch.empty(ctx.shape, dtype=torch.float32, device=pre.device)
                 nat.check(L.tron_pool12(nat.ptr(gpool), nat.ptr(gx), B * C, 1, st), "tron_pool12")
             if ctx.needs_input_grad[1]:
-                gdense = gp.t() @ pooled
+                gdense = fused.gemm_f16x3(gp, pooled, a_transposed=True, b_transposed=True, a_scale=sc)   # gp^T [Co*9, B] x pooled [B, Ci*36]
+                if gdense is None:
+                    gdense = gp.t() @ pooled
                 gw = torch.empty(Co, C, 7, 7, dtype=torch.float32, device=pre.device)
                 nat.check(L.tron_conv7_dense(nat.ptr(gdense), nat.ptr(gw), Co, C, 1, st), "tron_conv7_dense")
             if ctx.needs_input_grad[2]:

@@ -379,3 +379,28 @@ def pool_s2(x):
             nat.check(nat.lib().tron_pool_s2(x.data_ptr(), y.data_ptr(), B * C, S, torch.cuda.current_stream(x.device).cuda_stream),
                       "tron_pool_s2")
     return y
+
+
+use_gemm = _os.environ.get("TRON_HEAD_GEMM", "1") != "0"      # the training head's dense products on tron_gemm_f16x3 (0: the library)
+
+
+def gemm_f16x3(a, b, bias=None, a_transposed=False, b_transposed=False, a_scale=None):
+    """a @ b.T + bias on the split-f16 matrix cores (tron_gemm_f16x3), f32 in and out.  a: [M, K] (or [K, M] with
+    a_transposed), b: [N, K] (or [K, N] with b_transposed).  None where the kernel does not cover the shape (the caller then
+    uses the library).  a_scale: a device scalar (power of two) for a gradient operand `a`."""
+    if not (use_gemm and default_math == "f16x3" and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
+            and a.dim() == 2 and b.dim() == 2):
+        return None
+    M, K = (a.shape[1], a.shape[0]) if a_transposed else a.shape
+    N, Kb = (b.shape[1], b.shape[0]) if b_transposed else b.shape
+    L = nat.lib()
+    nbytes = int(L.tron_gemm_f16x3_workspace(M, N, K)) if Kb == K and M > 0 else 0
+    if nbytes <= 0 or ((not a_transposed or not b_transposed) and K % 64 != 0):
+        return None
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device):
+        nat.check(L.tron_gemm_f16x3(nat.ptr(a), int(a_transposed), nat.ptr(b), int(b_transposed), nat.ptr(None if bias is None else bias.contiguous()),
+                                    nat.ptr(a_scale), nat.ptr(out), M, N, K, nat.ptr(ws), nat.stream_ptr()), "tron_gemm_f16x3")
+    return out

@@ -171,6 +171,12 @@ def _gram_hip(a, module, scale, geometry=None, in_scale=None):
 def _pow2_scale(g):
     """A device scalar 2^k that brings max |g| to [2^9, 2^10) (f16's comfortable range after the kernels' 2^-6), without
     reading anything back; 1 for an all-zero tensor."""
+    if g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.data_ptr() % 16 == 0:
+        from tron import _native as nat
+        out = torch.zeros(4, dtype=torch.float32, device=g.device)          # {scale, max |g|, scratch, scratch}: tron_absmax_pow2, one launch
+        with torch.cuda.device(g.device):
+            nat.check(nat.lib().tron_absmax_pow2(nat.ptr(g), g.numel(), 16, nat.ptr(out), nat.stream_ptr()), "tron_absmax_pow2")
+        return out[:1]
     lo, hi = torch.aminmax(g)
     m = torch.maximum(hi, -lo).to(torch.float32)
     e = torch.frexp(m)[1]                                   # m = f 2^e, f in [0.5, 1)

@@ -4,6 +4,8 @@
 //   k_td_loss        the Double-DQN loss and its gradient at the local net's Q-values
 //   k_eps_greedy     actions = greedy or uniform random, per observation, with epsilon read from device memory
 //   k_eps_schedule   finished-game counter, 20-game cycles, epsilon = eps0 * rate ^ decays — without leaving the device
+//   k_absmax_pow2    max |x| of a gradient tensor and the power of two the split-f16 kernels scale it by (six launches as
+//                    tensor expressions), for the learner's head, the ACKTR nets' convolutions and K-FAC's gradient factors
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -104,7 +106,53 @@ __global__ __launch_bounds__(1024) void k_eps_schedule(const int8_t *__restrict_
     }
 }
 
+// max |x| and the power of two that brings it to [2^(t-1), 2^t): what the split-f16 kernels scale a gradient tensor by on its
+// way into f16 (aminmax + frexp + ldexp + where on the device: six small launches as tensor expressions).  out = {scale,
+// max |x|, (scratch: the maximum's bits while the blocks run), (scratch: blocks done)}, zeroed by the caller; non-negative
+// floats order like their bit patterns, so the block maxima meet in an integer atomicMax and the last block to finish
+// writes the result.
+__global__ __launch_bounds__(256) void k_absmax_pow2(const float *__restrict__ x, int64_t n, int target_exp, float *__restrict__ out)
+{
+    __shared__ float red[4];
+    float m = 0.0f;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        unsigned int *bits = reinterpret_cast<unsigned int *>(out + 2), *ticket = reinterpret_cast<unsigned int *>(out + 3);
+        if (m == m) atomicMax(bits, __float_as_uint(m));                // (a NaN block maximum is left out)
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            const float mx = __uint_as_float(atomicMax(bits, 0u));
+            const int e = (int)((__float_as_uint(mx) >> 23) & 255u) - 126;   // mx = f 2^e, f in [0.5, 1)
+            int k = target_exp - e;
+            k = k < -60 ? -60 : (k > 60 ? 60 : k);                        // (the scale's square must stay finite)
+            out[0] = mx > 0.0f ? __uint_as_float((uint32_t)(127 + k) << 23) : 1.0f;
+            out[1] = mx;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int tron_absmax_pow2(const float *x, int64_t n, int32_t target_exp, float *out4, void *stream)
+{
+    if (!x || !out4 || n < 0 || target_exp < -60 || target_exp > 60) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(out4) & 15u)) return TRON_ERR_BAD_ARG;
+    const int64_t blocks = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(k_absmax_pow2, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, n, target_exp, out4);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
 
 extern "C" int tron_ddqn_td_loss(const float *q, const int64_t *actions, const float *rewards, const float *dones,
                                  const float *q_local_next, const float *q_target_next, float gamma, int64_t batch, float *loss,

@@ -477,7 +477,8 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_f16x3(const f16 *__restri
                                                              const f16 *__restrict__ Wh, const f16 *__restrict__ Wl,
                                                              const float *__restrict__ bias, int bias_div, int M, int N,
                                                              int K, int act, float *__restrict__ out_f32,
-                                                             f16 *__restrict__ out_h, f16 *__restrict__ out_l)
+                                                             f16 *__restrict__ out_h, f16 *__restrict__ out_l,
+                                                             const float *__restrict__ a_scale = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *a_h = lds, *a_l = lds + A_HALF, *w_h = lds + 2 * A_HALF, *w_l = w_h + W_HALF;
@@ -564,6 +565,8 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_f16x3(const f16 *__restri
         }
     }
 
+    // (A arrives pre-scaled by 2^-6 — and, tron_gemm_f16x3's gradient operands, by the power of two *a_scale on top)
+    const float out_scale = a_scale ? ACT_UNSCALE / *a_scale : ACT_UNSCALE;
     // epilogue: D row = 4 * (lane >> 4) + r, column = lane & 15
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_f16x3(const f16 *__restri
         const float bv = bias ? bias[col / bias_div] : 0.0f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const f32x4 v = (acc0[t][n] + acc1[t][n] * LO_UNSCALE) * ACT_UNSCALE + bv;
+            const f32x4 v = (acc0[t][n] + acc1[t][n] * LO_UNSCALE) * out_scale + bv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * 32 + t * 16 + 4 * g + r;
@@ -642,7 +645,7 @@ HeadPlan plan(int64_t B, int K7, int N7, int64_t a7_per_image = 0, int d7_rows =
 
 template <bool CONV7>
 int gemm(const f16 *Ah, const f16 *Al, const f16 *Wh, const f16 *Wl, const float *bias, int bias_div, int64_t M, int N, int K,
-         int act, float *out_f32, f16 *out_h, f16 *out_l, hipStream_t st)
+         int act, float *out_f32, f16 *out_h, f16 *out_l, hipStream_t st, const float *a_scale = nullptr)
 {
     static uint64_t prepared = 0;
     int dev = 0;
@@ -656,11 +659,95 @@ int gemm(const f16 *Ah, const f16 *Al, const f16 *Wh, const f16 *Wl, const float
     if (M >= (1ll << 31) || N % GN != 0 || K % GK != 0) return TRON_ERR_UNSUPPORTED;
     const int64_t blocks = ((M + GM - 1) / GM) * (N / GN);
     hipLaunchKernelGGL(k_gemm_f16x3<CONV7>, dim3((unsigned)blocks), dim3(G_THREADS), G_LDS, st, Ah, Al, Wh, Wl, bias, bias_div,
-                       (int)M, N, K, act, out_f32, out_h, out_l);
+                       (int)M, N, K, act, out_f32, out_h, out_l, a_scale);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
+// ---- operands of tron_gemm_f16x3: f32 matrices -> split f16 [rows][K padded to 64], K contiguous --------------------------
+// as given ([rows][K], K % 64 == 0) ...
+__global__ void k_split_scaled(const float *__restrict__ a, int64_t total, const float *__restrict__ scale, float fixed, f16 *__restrict__ oh,
+                               f16 *__restrict__ ol)
+{
+    const float sc = fixed * (scale ? *scale : 1.0f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        f16 h, l;
+        split(a[i] * sc, h, l);
+        oh[i] = h;
+        ol[i] = l;
+    }
+}
+// ... or transposed (given as [K][rows]): a 64 x 64 tile through LDS, K zero-padded to kpad
+__global__ __launch_bounds__(256) void k_transpose_split_scaled(const float *__restrict__ a, int64_t K, int rows, int64_t kpad,
+                                                                const float *__restrict__ scale, float fixed, f16 *__restrict__ oh,
+                                                                f16 *__restrict__ ol)
+{
+    __shared__ float tile[64][65];
+    const float sc = fixed * (scale ? *scale : 1.0f);
+    const int64_t k0 = (int64_t)blockIdx.x * 64;
+    const int j0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int kk = i >> 6, jj = i & 63;
+        tile[kk][jj] = (k0 + kk < K && j0 + jj < rows) ? a[(size_t)(k0 + kk) * rows + j0 + jj] * sc : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {                   // (row jj, 8 consecutive k)
+        const int jj = i >> 3, g = i & 7;
+        if (j0 + jj >= rows) continue;
+        f16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            f16 hh, ll;
+            split(tile[g * 8 + e][jj], hh, ll);
+            h[e] = hh;
+            l[e] = ll;
+        }
+        *reinterpret_cast<f16x8 *>(oh + (size_t)(j0 + jj) * kpad + k0 + g * 8) = h;
+        *reinterpret_cast<f16x8 *>(ol + (size_t)(j0 + jj) * kpad + k0 + g * 8) = l;
+    }
+}
+
 }  // namespace
+
+// C[M][N] = A B^T + bias[n] on the split-f16 matrix cores (three MFMAs per slab, f32 accumulation: f32-grade), f32 in and out.
+// A: [M][K], or (a_transposed) given as [K][M]; B: [N][K], or (b_transposed) given as [K][N]; N % 64 == 0; K % 64 == 0 for an
+// operand given K-contiguous (a transposed one is zero-padded).  a_scale (may be NULL): one f32 on the device, a power of two
+// A is multiplied by on its way into f16 and C divided by — gradient operands.  workspace: tron_gemm_f16x3_workspace bytes.
+extern "C" int64_t tron_gemm_f16x3_workspace(int64_t M, int32_t N, int64_t K)
+{
+    if (M < 1 || N < 1 || K < 1 || N % 64 != 0 || M >= (1ll << 31) || K >= (1ll << 31)) return 0;
+    const int64_t kpad = (K + 63) / 64 * 64;
+    return 2 * align256(M * kpad * 2) + 2 * align256((int64_t)N * kpad * 2) + 256;
+}
+
+extern "C" int tron_gemm_f16x3(const float *A, int32_t a_transposed, const float *B, int32_t b_transposed, const float *bias,
+                               const float *a_scale, float *C, int64_t M, int32_t N, int64_t K, void *workspace, void *stream)
+{
+    if (!A || !B || !C || !workspace || M < 0 || N < 1 || K < 1) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(C)) & 15u) return TRON_ERR_BAD_ARG;
+    if (M == 0) return TRON_OK;
+    if (N % 64 != 0 || M >= (1ll << 31) || K >= (1ll << 31)) return TRON_ERR_UNSUPPORTED;
+    if ((!a_transposed || !b_transposed) && K % 64 != 0) return TRON_ERR_UNSUPPORTED;
+    const int64_t kpad = (K + 63) / 64 * 64;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    const int64_t abytes = align256(M * kpad * 2), bbytes = align256((int64_t)N * kpad * 2);
+    f16 *ah = reinterpret_cast<f16 *>(ws), *al = reinterpret_cast<f16 *>(ws + abytes);
+    f16 *bh = reinterpret_cast<f16 *>(ws + 2 * abytes), *bl = reinterpret_cast<f16 *>(ws + 2 * abytes + bbytes);
+    auto blocks_for = [](int64_t total) { const int64_t b = (total + 255) / 256; return (unsigned)(b < 8192 ? b : 8192); };
+    if (a_transposed)
+        hipLaunchKernelGGL(k_transpose_split_scaled, dim3((unsigned)(kpad / 64), (unsigned)((M + 63) / 64)), dim3(256), 0, st, A, K, (int)M, kpad,
+                           a_scale, ACT_SCALE, ah, al);
+    else
+        hipLaunchKernelGGL(k_split_scaled, dim3(blocks_for(M * K)), dim3(256), 0, st, A, M * K, a_scale, ACT_SCALE, ah, al);
+    if (b_transposed)
+        hipLaunchKernelGGL(k_transpose_split_scaled, dim3((unsigned)(kpad / 64), (unsigned)(N / 64)), dim3(256), 0, st, B, K, N, kpad,
+                           (const float *)nullptr, 1.0f, bh, bl);
+    else
+        hipLaunchKernelGGL(k_split_scaled, dim3(blocks_for((int64_t)N * K)), dim3(256), 0, st, B, (int64_t)N * K, (const float *)nullptr, 1.0f, bh, bl);
+    if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
+    return gemm<false>(ah, al, bh, bl, bias, 1, M, N, (int)kpad, 0, C, nullptr, nullptr, st, a_scale);
+}
+
 
 extern "C" int64_t tron_dqn_head_workspace(int64_t batch, int32_t side)
 {

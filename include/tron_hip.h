@@ -220,6 +220,16 @@ int tron_replay_sample_codes(tron_replay_handle r, int32_t batch, int8_t *states
                              int8_t *next_states, float *dones, void *stream);
 int tron_replay_size(tron_replay_handle r, int64_t *size, int64_t *capacity);
 
+/* C f32[M][N] = A B^T + bias[n] on the split-f16 matrix cores (operands split in two halves, three MFMAs per slab, f32
+ * accumulation: relative error ~1e-6), f32 in and out — the dense products of the training-path head (conv7 in its dense
+ * form: Net/activations.py::_PoolConv7, DQNNet.py:52-55).  A: f32[M][K], or (a_transposed) given as f32[K][M]; B: f32[N][K],
+ * or (b_transposed) given as f32[K][N]; N % 64 == 0, and K % 64 == 0 unless both operands are transposed ones (those are
+ * zero-padded).  bias may be NULL.  a_scale (may be NULL): one f32 on the device, a power of two A is multiplied by on its
+ * way into f16 and C divided by (gradient operands).  workspace: tron_gemm_f16x3_workspace(M, N, K) bytes (0: unsupported). */
+int tron_gemm_f16x3(const float *A, int32_t a_transposed, const float *B, int32_t b_transposed, const float *bias,
+                    const float *a_scale, float *C, int64_t M, int32_t N, int64_t K, void *workspace, void *stream);
+int64_t tron_gemm_f16x3_workspace(int64_t M, int32_t N, int64_t K);
+
 /* ---- the trainer's small device-side steps around the network, one launch each (csrc/tron_dqn.hip) ---------------
  * tron_ddqn_td_loss: the Double-DQN loss of DDQN.py:129-146 and its gradient at the local net's Q-values:
  *   y = rewards + gamma * q_target_next[b][argmax_a q_local_next[b][a]] * (1 - dones),  loss = mean (q[b][actions[b]] - y)^2,
@@ -230,6 +240,10 @@ int tron_replay_size(tron_replay_handle r, int64_t *size, int64_t *capacity);
  * tron_eps_schedule: DDQN.py:313-315 per env step: state4 = {games, cycles, decays, decays_max} (i64 on the device):
  *   games += count(done != 0); cycles = games / games_per_cycle; decays = min(decays + new cycles, decays_max);
  *   epsilon = eps0 * rate ^ decays, written as f64 and f32 — nothing is read back.                                  */
+/* out4 (f32[4] on the device, zeroed by the caller, 16-byte aligned) <- {scale, max |x|, scratch, scratch}: scale = the power
+ * of two that brings max |x| into [2^(target_exp-1), 2^target_exp) (1 for an all-zero x; the exponent clamped to +-60) —
+ * the device-side scale the split-f16 kernels take for gradient operands (in_scale / a_scale / grad_absmax), one launch.   */
+int tron_absmax_pow2(const float *x, int64_t n, int32_t target_exp, float *out4, void *stream);
 int tron_ddqn_td_loss(const float *q, const int64_t *actions, const float *rewards, const float *dones,
                       const float *q_local_next, const float *q_target_next, float gamma, int64_t batch, float *loss,
                       float *grad_q, void *stream);

@@ -551,3 +551,23 @@ def test_conv3x3_module_matches_float64_conv2d(fused, S, B, cin, cout, bias):
     x2 = x.detach().clone().requires_grad_(True)
     m(x2).backward(g)
     assert torch.equal(seen["a"], x2) and torch.equal(seen["g"], g)
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(1, 64, 64, False, False), (300, 576, 2304, False, False), (4096, 2304, 576, False, True),
+                                          (576, 2304, 4096, True, True), (576, 2304, 300, True, True), (129, 128, 1000, True, True),
+                                          (4099, 64, 128, False, False)])
+@pytest.mark.parametrize("magnitude", [1.0, 1e-7])
+def test_gemm_f16x3_matches_float64(fused, M, N, K, ta, tb, magnitude):
+    """tron_gemm_f16x3 (the training head's dense products, Net/activations.py::_PoolConv7): every operand layout, ragged M,
+    a reduction length that needs zero padding, a gradient-sized A operand with its device-side power-of-two scale."""
+    from Net.kfac import _pow2_scale
+    torch.manual_seed(M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), device="cuda") * magnitude
+    b = torch.randn((K, N) if tb else (N, K), device="cuda")
+    bias = torch.randn(N, device="cuda") * magnitude
+    got = fused.gemm_f16x3(a, b, bias, a_transposed=ta, b_transposed=tb, a_scale=_pow2_scale(a) if magnitude != 1.0 else None)
+    want = (a.double().t() if ta else a.double()) @ (b.double() if tb else b.double().t()) + bias.double()
+    assert got is not None and got.shape == want.shape
+    assert (got.double() - want).abs().max().item() / want.abs().max().item() < 2e-6
+    assert fused.gemm_f16x3(torch.randn(8, 100, device="cuda"), torch.randn(64, 100, device="cuda")) is None      # K % 64 != 0, not transposed
+    assert fused.gemm_f16x3(torch.randn(8, 64, device="cuda"), torch.randn(48, 64, device="cuda")) is None        # N % 64 != 0

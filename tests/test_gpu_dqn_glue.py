@@ -84,3 +84,23 @@ def test_eps_schedule_equals_the_tensor_expressions():
         want = eps0 * DDQN.DECAY_RATE ** decays
         assert abs(eps64.item() - want) < 1e-12 and abs(eps32.item() - want) < 1e-7
     assert decays == left or decays > 0
+
+
+@pytest.mark.parametrize("n", [1, 5, 4096, 1_000_003, 37_000_000])
+@pytest.mark.parametrize("magnitude", [1.0, 3e-9, 7e5, 0.0])
+def test_absmax_pow2(n, magnitude):
+    """tron_absmax_pow2: max |x| exactly, and the power of two that puts it in [2^15, 2^16) (1 for an all-zero tensor)."""
+    from Net.kfac import _pow2_scale
+    from tron import _native as nat
+    torch.manual_seed(n)
+    x = torch.randn(n, device="cuda") * magnitude
+    out = torch.zeros(4, device="cuda")
+    nat.check(nat.lib().tron_absmax_pow2(nat.ptr(x), n, 16, nat.ptr(out), nat.stream_ptr()), "tron_absmax_pow2")
+    want = x.abs().max().item()
+    assert out[1].item() == want
+    s = out[0].item()
+    if want == 0.0:
+        assert s == 1.0
+    else:
+        assert 2.0 ** 15 <= want * s < 2.0 ** 16 and abs(torch.log2(torch.tensor(s)).item() - round(torch.log2(torch.tensor(s)).item())) == 0.0
+    assert _pow2_scale(x).item() == s
