@@ -335,7 +335,8 @@ def main():
                 "rollout_seconds_per_iteration": o["rollout_seconds"] / o["iterations"],
                 "samples_per_update": 5 * envs, "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9,
                 "config": {"workload": f"{envs} parallel {width}x{width} self-play envs (temper mode), Mulnet actor-critic, "
-                                       f"ACKTR: Fisher statistics + eigendecompositions every step (kfac.py:202-254), "
+                                       f"ACKTR: Fisher statistics every update (Ts = 1), eigendecompositions every tenth (Tf = 10, kfac.py:107-110,217: "
+                                       f"a run starts at update 0, so each player's first update of the timed run pays one), "
                                        f"micro-batches of 8 192", "parallelism": f"env-shard x{world}"}}), flush=True)
         if world > 1:
             dist.destroy_process_group()
