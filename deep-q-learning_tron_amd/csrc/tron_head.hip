@@ -255,54 +255,49 @@ __global__ void k_dense7(const float *__restrict__ src, float *__restrict__ dst,
 }
 
 // ---- 24x24 boards: 26x26 trunk planes -> 13x13 pooled -> conv7 -> 7x7 ---------------------------------------------------
-// avg-pool 3/2/1 of x f32 [B][64][26][26] into the zero-haloed channels-last split image [B][19][19][64] (pooled pixel
-// (py, px) at padded (py + 3, px + 3)), pre-scaled by 2^-6.  One workgroup = one padded row of one image: the 64 x 13
-// results go through LDS so that the stores are contiguous 128-byte pixels; halo rows and columns are written as zeros.
+// avg-pool 3/2/1 of x f32 [B][64][26][26] into the channels-last split image [B][13][13][64], pre-scaled by 2^-6.  One
+// workgroup = one pooled row of one image: the 64 x 13 results go through LDS so that the stores are contiguous 128-byte
+// pixels.  (No zero halo: the CONV7 GEMM's loader predicates the taps that fall outside — the halo'd 19 x 19 image was
+// 2.1x the bytes to write and to fetch.)
 __global__ __launch_bounds__(256) void k_pool_split26(const float *__restrict__ x, f16 *__restrict__ oh, f16 *__restrict__ ol)
 {
     constexpr int S = 26, PS = 13, C = 64;
     __shared__ float raw[C * 3 * S];                                     // [c][dy][x]: the three input rows of every channel
     __shared__ f16 th[PS * C], tl[PS * C];                               // [px][c]
-    const int r = blockIdx.x % 19, py = r - 3;
-    const int64_t b = blockIdx.x / 19;
-    if (py >= 0 && py < PS) {
-        const float *img = x + b * C * S * S;
-        // rows 2 py - 1 .. 2 py + 1 of all channels as 8-byte loads, consecutive lanes on consecutive pairs of a row
-        for (int i = threadIdx.x; i < C * 3 * (S / 2); i += 256) {
-            const int q = i % (S / 2), rowi = i / (S / 2), dy = rowi % 3, c = rowi / 3;
-            const int yy = 2 * py + dy - 1;
-            float2 v = make_float2(0.0f, 0.0f);
-            if (yy >= 0) v = *reinterpret_cast<const float2 *>(img + ((size_t)c * S + yy) * S + 2 * q);   // yy <= 25 always
-            raw[(c * 3 + dy) * S + 2 * q] = v.x;
-            raw[(c * 3 + dy) * S + 2 * q + 1] = v.y;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < C * PS; i += 256) {
-            const int c = i % C, px = i / C;                             // lanes walk the channels: th / tl rows are contiguous
-            float sum = 0.0f;
+    const int py = blockIdx.x % PS;
+    const int64_t b = blockIdx.x / PS;
+    const float *img = x + b * C * S * S;
+    // rows 2 py - 1 .. 2 py + 1 of all channels as 8-byte loads, consecutive lanes on consecutive pairs of a row
+    for (int i = threadIdx.x; i < C * 3 * (S / 2); i += 256) {
+        const int q = i % (S / 2), rowi = i / (S / 2), dy = rowi % 3, c = rowi / 3;
+        const int yy = 2 * py + dy - 1;
+        float2 v = make_float2(0.0f, 0.0f);
+        if (yy >= 0) v = *reinterpret_cast<const float2 *>(img + ((size_t)c * S + yy) * S + 2 * q);   // yy <= 25 always
+        raw[(c * 3 + dy) * S + 2 * q] = v.x;
+        raw[(c * 3 + dy) * S + 2 * q + 1] = v.y;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * PS; i += 256) {
+        const int c = i % C, px = i / C;                                 // lanes walk the channels: th / tl rows are contiguous
+        float sum = 0.0f;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int xx = 2 * px + dx;
-                    if (xx >= 0) sum += raw[(c * 3 + dy) * S + xx];      // xx <= 25 always
-                }
-            f16 h, l;
-            split(sum * (1.0f / 9.0f) * ACT_SCALE, h, l);
-            th[px * C + c] = h;
-            tl[px * C + c] = l;
-        }
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = 2 * px + dx;
+                if (xx >= 0) sum += raw[(c * 3 + dy) * S + xx];          // xx <= 25 always
+            }
+        f16 h, l;
+        split(sum * (1.0f / 9.0f) * ACT_SCALE, h, l);
+        th[px * C + c] = h;
+        tl[px * C + c] = l;
     }
     __syncthreads();
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    const size_t row = ((size_t)b * 19 + r) * 19 * C;
-    for (int i = threadIdx.x; i < 19 * C / 2; i += 256) {               // two channels per thread: 4-byte stores
-        const int pix = (2 * i) / C, c = (2 * i) - pix * C, px = pix - 3;
-        const bool in = py >= 0 && py < PS && px >= 0 && px < PS;
-        const f16x2 h = in ? (f16x2){th[px * C + c], th[px * C + c + 1]} : (f16x2){(f16)0.0f, (f16)0.0f};
-        const f16x2 l = in ? (f16x2){tl[px * C + c], tl[px * C + c + 1]} : (f16x2){(f16)0.0f, (f16)0.0f};
-        *reinterpret_cast<f16x2 *>(oh + row + 2 * i) = h;
-        *reinterpret_cast<f16x2 *>(ol + row + 2 * i) = l;
+    const size_t row = ((size_t)b * PS + py) * PS * C;                   // the row's 13 pixels x 64 channels are contiguous
+    for (int i = threadIdx.x; i < PS * C / 2; i += 256) {
+        *reinterpret_cast<f16x2 *>(oh + row + 2 * i) = (f16x2){th[2 * i], th[2 * i + 1]};
+        *reinterpret_cast<f16x2 *>(ol + row + 2 * i) = (f16x2){tl[2 * i], tl[2 * i + 1]};
     }
 }
 
@@ -362,28 +357,26 @@ __global__ __launch_bounds__(256) void k_pool_split12_px(const unsigned char *__
     }
 }
 
-// 26x26: the zero-haloed channels-last split image [B][19][19][64] (what k_pool_split26 writes).  One thread = one padded
-// pixel x one channel octet: a 16-byte store per half, zeros in the halo.
+// 26x26: the channels-last split image [B][13][13][64] (what k_pool_split26 writes).  One thread = one pooled pixel x one
+// channel octet: a 16-byte store per half.
 __global__ __launch_bounds__(256) void k_pool_split26_px(const unsigned char *__restrict__ x, int64_t B, f16 *__restrict__ oh,
                                                          f16 *__restrict__ ol)
 {
     constexpr int S = 26, PS = 13, C = 64, HALF = (C / 8) * S * S * 16;
-    const int64_t total = B * 19 * 19 * 8;
+    const int64_t total = B * PS * PS * 8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int oct = (int)(i & 7);
-        const int64_t pix = i >> 3, b = pix / 361;
-        const int r = (int)(pix - b * 361), py = r / 19 - 3, px = r % 19 - 3;
-        f16x8h h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (py >= 0 && py < PS && px >= 0 && px < PS) {
-            float sum[8];
-            px16_window_sum(x + (size_t)b * 2 * HALF, S, HALF, oct, py, px, sum);
+        const int64_t pix = i >> 3, b = pix / (PS * PS);
+        const int r = (int)(pix - b * (PS * PS)), py = r / PS, px = r % PS;
+        float sum[8];
+        px16_window_sum(x + (size_t)b * 2 * HALF, S, HALF, oct, py, px, sum);
+        f16x8h h, l;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                f16 hh, ll;
-                split(sum[j] * (1.0f / 9.0f), hh, ll);
-                h[j] = hh;
-                l[j] = ll;
-            }
+        for (int j = 0; j < 8; ++j) {
+            f16 hh, ll;
+            split(sum[j] * (1.0f / 9.0f), hh, ll);
+            h[j] = hh;
+            l[j] = ll;
         }
         *reinterpret_cast<f16x8h *>(oh + (size_t)pix * C + oct * 8) = h;
         *reinterpret_cast<f16x8h *>(ol + (size_t)pix * C + oct * 8) = l;
@@ -452,24 +445,22 @@ constexpr int G_LDS = 2 * A_HALF + 2 * W_HALF;     // 61 440 bytes
 // row-major with K contiguous.  N % 64 == 0, K % 64 == 0.  out_f32 and / or (out_h, out_l) (pre-scaled by 2^-6 again).
 //
 // CONV7 (24x24 boards): the same GEMM as the 7x7 / stride 2 / pad 3 convolution of 13x13 pooled planes — A is then the
-// zero-haloed channels-last split image [image][19 x 19 pixels][64 ci] (k_pool_split26), row m = (image, oy, ox) starts
-// at padded pixel (2 oy, 2 ox), and K chunk kc (64 channels of tap (ky, kx) = (kc / 7, kc % 7)) lies (19 ky + kx) pixels
-// further: an implicit GEMM whose im2col is two integer divisions per staged row.  W is conv7's weight as
-// [co][tap][ci] (conv7w_split); the output rows [image][oy][ox][co] are the next GEMM's A rows as they are.
-constexpr int P7_PIX = 19 * 19, O7 = 7, O7_PIX = O7 * O7;
+// channels-last split image [image][13 x 13 pixels][64 ci] (k_pool_split26), row m = (image, oy, ox), and K chunk kc is
+// the 64 channels of pixel (2 oy + ky - 3, 2 ox + kx - 3), (ky, kx) = (kc / 7, kc % 7) — or zeros where that pixel is
+// conv7's padding (30 % of the pieces: not fetched): an implicit GEMM whose im2col is a few integer operations per staged
+// piece.  W is conv7's weight as [co][tap][ci] (conv7w_split); the output rows [image][oy][ox][co] are the next GEMM's A
+// rows as they are.
+constexpr int P7 = 13, P7_PIX = P7 * P7, O7 = 7, O7_PIX = O7 * O7;
+// byte offset of the 128-byte K chunk kc of A row m, or -1: the tap falls on conv7's zero padding (CONV7 only)
 template <bool CONV7>
-__device__ __forceinline__ size_t a_row_bytes(int m, int K)
+__device__ __forceinline__ int64_t a_piece_bytes(int m, int kc, int K)
 {
-    if (!CONV7) return (size_t)m * K * 2;
+    if (!CONV7) return (int64_t)m * K * 2 + kc * GK * 2;
     const int b = m / O7_PIX, p = m - b * O7_PIX, oy = p / O7, ox = p - oy * O7;
-    return ((size_t)b * P7_PIX + (2 * oy) * 19 + 2 * ox) * 128;
-}
-template <bool CONV7>
-__device__ __forceinline__ int a_chunk_bytes(int kc)
-{
-    if (!CONV7) return kc * GK * 2;
     const int ky = kc / 7, kx = kc - ky * 7;
-    return (ky * 19 + kx) * 128;
+    const int iy = 2 * oy + ky - 3, ix = 2 * ox + kx - 3;
+    if ((unsigned)iy >= (unsigned)P7 || (unsigned)ix >= (unsigned)P7) return -1;
+    return ((int64_t)b * P7_PIX + iy * P7 + ix) * 128;
 }
 
 template <bool CONV7>
@@ -495,8 +486,9 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_f16x3(const f16 *__restri
             const int q = tid + j * G_THREADS, half = q >> 10, r = q & 1023, row = r >> 3, pc = r & 7;
             int m = m0 + row;
             m = m < M ? m : M - 1;
-            ra[j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(half ? Al : Ah) +
-                                                     a_row_bytes<CONV7>(m, K) + a_chunk_bytes<CONV7>(kc) + pc * 16);
+            const int64_t ab = a_piece_bytes<CONV7>(m, kc, K);
+            ra[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!CONV7 || ab >= 0) ra[j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(half ? Al : Ah) + ab + pc * 16);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -776,8 +768,8 @@ static int head_fwd(const void *trunk, bool px16, int64_t batch, int32_t side, c
         const HeadPlan p = plan(batch, K7, N1, (int64_t)P7_PIX * 64, 64);
         unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
         auto H = [&](int64_t off) { return reinterpret_cast<f16 *>(ws + off); };
-        if (px16) hipLaunchKernelGGL(k_pool_split26_px, dim3((unsigned)((batch * 361 * 8 + 255) / 256 < (1 << 20) ? (batch * 361 * 8 + 255) / 256 : (1 << 20))), dim3(256), 0, st, trunk_px, batch, H(p.a7h), H(p.a7l));
-        else hipLaunchKernelGGL(k_pool_split26, dim3((unsigned)(batch * 19)), dim3(256), 0, st, trunk_out, H(p.a7h), H(p.a7l));
+        if (px16) hipLaunchKernelGGL(k_pool_split26_px, dim3((unsigned)((batch * 169 * 8 + 255) / 256 < (1 << 20) ? (batch * 169 * 8 + 255) / 256 : (1 << 20))), dim3(256), 0, st, trunk_px, batch, H(p.a7h), H(p.a7l));
+        else hipLaunchKernelGGL(k_pool_split26, dim3((unsigned)(batch * 13)), dim3(256), 0, st, trunk_out, H(p.a7h), H(p.a7l));
         const HeadWeights hw{conv7_w, fc1_w, fc2_w, actor1_w, H(p.d7h), H(p.d7l), H(p.w1h), H(p.w1l), H(p.w2h), H(p.w2l), H(p.w3h), H(p.w3l),
                              1, 0, 256 * N1};
         hipLaunchKernelGGL(k_head_weights, dim3(1024, 4), dim3(256), 0, st, hw);
