@@ -196,6 +196,41 @@ def test_trunk_node_at_the_learn_batch(fused, W):
         assert (g1 - g2).abs().max().item() / scale < 3e-5, name
 
 
+def test_kfac_factors_at_the_config5_micro_batch(fused):
+    """K-FAC's two Kronecker factors of a 64-channel 3x3 layer at BASELINE config 5's micro-batch (8 192 samples of 34x34:
+    9.5 M patch rows, 41 passes of the Gram kernel) against float64, and the 34x34 convolution kernel at that batch against a
+    float64 convolution of sampled rows."""
+    import torch.nn as nn
+    from Net import kfac
+    from Net.activations import Conv3x3
+    torch.manual_seed(34)
+    B = 8192
+    conv = Conv3x3(64, 64, 3, padding=1).cuda()
+    a = torch.randn(B, 64, 34, 34, device="cuda")
+    g = torch.randn(B, 64, 34, 34, device="cuda") * 1e-5
+    got_a, got_g = kfac.cov_inputs(a, conv), kfac.cov_grads(g, conv)
+    with torch.no_grad():
+        y = conv(a)
+        rows = torch.arange(0, B, 997, device="cuda")
+        want_y = F.conv2d(a[rows].double(), conv.weight.double(), conv.bias.double(), padding=1)
+    assert (y[rows].double() - want_y).abs().max().item() < TOL
+    del y
+    # float64 references, in chunks (an f32 library GEMM over 9.5 M rows is itself off by ~4e-4 on the diagonal)
+    want_a = torch.zeros(576, 576, dtype=torch.float64, device="cuda")
+    want_g = torch.zeros(64, 64, dtype=torch.float64, device="cuda")
+    for i in range(0, B, 64):
+        cols = F.unfold(a[i:i + 64].double(), (3, 3), padding=1)
+        P = cols.transpose(1, 2).reshape(-1, 576)
+        want_a += P.t() @ P
+        gc = g[i:i + 64].double().permute(1, 0, 2, 3).reshape(64, -1)
+        want_g += gc @ gc.t()
+    want_a /= B * 1156.0 ** 2                                             # kfac.py:41-58
+    want_g *= (1156.0 * B) ** 2 / (B * 1156.0)                            # kfac.py:61-76: g_ = g (oh ow) batch; g_^T g_ / rows
+    for got, want in ((got_a, want_a), (got_g, want_g)):
+        assert (got.double() - want).abs().max().item() / want.abs().max().item() < 3e-6
+        assert torch.equal(got, got.t())
+
+
 PROBE = ["conv1.module.weight", "conv1.add_bias._bias", "conv7.module.weight", "fc1.module.weight",
          "actor2.module.weight", "critic3.add_bias._bias"]
 
