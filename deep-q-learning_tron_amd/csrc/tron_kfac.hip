@@ -432,6 +432,110 @@ __global__ __launch_bounds__(G2_THREADS, 4) void k_gram2_f16x3(const f16 *__rest
     }
 }
 
+// The gradient factor of a convolution straight from the NCHW tensor g [B][C][per]: G = sum over images and positions of
+// g[b, :, pos] g[b, :, pos]^T (C = 32 or 64 output channels).  The tensor is already "channel rows, positions contiguous" image by
+// image, so instead of writing its split transpose (k_patches_t_plane as a 1x1 patch matrix: 4 bytes written and read again
+// per element) a workgroup walks its share of the images slab by slab (32 positions): 256 threads load the C x 32 f32 block,
+// split it in registers into a double-buffered LDS image [C rows][64 B, pieces XOR-swizzled as in k_gram2], and four waves
+// multiply it with itself (wave = a 32 x 32 block of G, or 16 x 16 at C = 32).  Memory-bound by construction: g is read once.
+template <int C>
+__global__ __launch_bounds__(256) void k_gram_nchw(const float *__restrict__ g, int64_t B, int per, const float *__restrict__ in_scale,
+                                                   int nsplit, float *__restrict__ partial)
+{
+    constexpr int TW = C / 32;                                           // MFMA tiles per wave and side: 2 (C = 64) or 1
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][C * 64];   // [buffer][hi | lo][row][64 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, gq = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;
+    const float sc = ACT_SCALE * (in_scale ? *in_scale : 1.0f);
+    const int s = blockIdx.x;
+    const int64_t b_lo = B * s / nsplit, b_hi = B * (s + 1) / nsplit;
+    const int slabs = (per + 31) / 32;
+    // staging: thread -> (row c, quad q of the slab's 8 float4): C * 8 float4 per slab, C / 32 per thread
+    constexpr int NLD = C * 8 / 256;
+    f32x4 v[NLD];
+    auto load = [&](int64_t b, int sl) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * 256, c = i >> 3, q = i & 7, pos = sl * 32 + q * 4;
+            v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (pos < per) v[j] = *reinterpret_cast<const f32x4 *>(g + ((size_t)b * C + c) * per + pos);   // per % 4 == 0
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * 256, c = i >> 3, q = i & 7;          // q-th float4 = k 4q .. 4q+3: half of piece q / 2
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f16 hh, ll;
+                split(v[j][e] * sc, hh, ll);
+                h[e] = hh;
+                l[e] = ll;
+            }
+            const int off = c * 64 + (((q >> 1) ^ ((0 - (c >> 2)) & 3)) * 16) + (q & 1) * 8;
+            *reinterpret_cast<f16x4 *>(&lds[buf][0][off]) = h;
+            *reinterpret_cast<f16x4 *>(&lds[buf][1][off]) = l;
+        }
+    };
+    f32x4 acc0[TW][TW], acc1[TW][TW];
+#pragma unroll
+    for (int a = 0; a < TW; ++a)
+#pragma unroll
+        for (int b = 0; b < TW; ++b) {
+            acc0[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc1[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    int a_off[TW], b_off[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const int ra = (wm * TW + t) * 16 + li, rb = (wn * TW + t) * 16 + li;
+        a_off[t] = ra * 64 + ((gq ^ ((0 - (ra >> 2)) & 3)) * 16);
+        b_off[t] = rb * 64 + ((gq ^ ((0 - (rb >> 2)) & 3)) * 16);
+    }
+    const int64_t total = (b_hi - b_lo) * slabs;
+    if (total > 0) {
+        load(b_lo, 0);
+        stage(0);
+        __syncthreads();
+        for (int64_t it = 0; it < total; ++it) {
+            const int buf = (int)(it & 1);
+            const int64_t nx = it + 1;
+            if (nx < total) load(b_lo + nx / slabs, (int)(nx % slabs));  // in flight under the MFMAs
+            f16x8 ah[TW], al[TW], bh[TW], bl[TW];
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                ah[t] = *reinterpret_cast<const f16x8 *>(&lds[buf][0][a_off[t]]);
+                al[t] = *reinterpret_cast<const f16x8 *>(&lds[buf][1][a_off[t]]);
+                bh[t] = *reinterpret_cast<const f16x8 *>(&lds[buf][0][b_off[t]]);
+                bl[t] = *reinterpret_cast<const f16x8 *>(&lds[buf][1][b_off[t]]);
+            }
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int n = 0; n < TW; ++n) {
+                    acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc1[t][n], 0, 0, 0);
+                    acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc0[t][n], 0, 0, 0);
+                    acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc1[t][n], 0, 0, 0);
+                }
+            if (nx < total) stage(buf ^ 1);                               // (the other buffer: nobody reads it during this slab)
+            __syncthreads();
+        }
+    }
+    float *out = partial + (size_t)s * C * C;
+#pragma unroll
+    for (int n = 0; n < TW; ++n) {
+        const int col = (wn * TW + n) * 16 + li;
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            const f32x4 r4 = (acc0[t][n] + acc1[t][n] * LO_UNSCALE) * GRAM_UNSCALE;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)((wm * TW + t) * 16 + 4 * gq + r) * C + col] = r4[r];
+        }
+    }
+}
+
 __global__ void k_gram_finish(const float *__restrict__ partial, int ksplit, int d, int dpad, float scale,
                               const float *__restrict__ in_scale, float *__restrict__ gram)
 {
@@ -530,6 +634,18 @@ extern "C" int tron_kfac_patch_gram(const float *x, int64_t batch, int32_t chann
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (batch == 0) return hipMemsetAsync(gram, 0, (size_t)d * d * sizeof(float), st) == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
     const int64_t per = (int64_t)OH * OW;
+    if (kh == 1 && kw == 1 && pad == 0 && stride == 1 && (channels == 32 || channels == 64) && per % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+        // a gradient factor (or any 1x1 "patch matrix"): straight from the NCHW tensor, k_gram_nchw
+        const int nsplit = (int)(batch < 2048 ? batch : 2048);
+        float *partial = reinterpret_cast<float *>(workspace);           // nsplit * C * C floats (<= 32 MB: within every plan's total)
+        if (channels == 64)
+            hipLaunchKernelGGL(k_gram_nchw<64>, dim3(nsplit), dim3(256), 0, st, x, batch, (int)per, in_scale, nsplit, partial);
+        else
+            hipLaunchKernelGGL(k_gram_nchw<32>, dim3(nsplit), dim3(256), 0, st, x, batch, (int)per, in_scale, nsplit, partial);
+        hipLaunchKernelGGL(k_gram_finish, dim3(16), dim3(256), 0, st, partial, nsplit, d, d, scale, in_scale, gram);
+        return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+    }
     const GramPlan p = gram_plan(batch * per, per, d);
     unsigned char *wsb = reinterpret_cast<unsigned char *>(workspace);
     f16 *xh = reinterpret_cast<f16 *>(wsb), *xl = reinterpret_cast<f16 *>(wsb + p.x_bytes);
