@@ -71,6 +71,23 @@ def test_cov_inputs_gpu_matches_cpu(C, side, k, pad, stride):
     assert torch.allclose(parts.cpu(), want, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,C,S", [(1, 32, 12), (7, 64, 12), (300, 32, 34), (33, 64, 34), (5000, 32, 12), (9, 64, 26), (4, 48, 12), (4, 64, 9)])
+def test_gradient_factor_from_nchw_matches_float64(B, C, S):
+    """tron_kfac_patch_gram with a 1x1 geometry — a convolution's gradient factor — runs k_gram_nchw for 32 / 64 channels and
+    positions % 4 == 0 (the last two shapes take the general path): float64 reference, symmetric, deterministic."""
+    import torch.nn as nn
+    from Net import kfac
+    torch.manual_seed(B + C + S)
+    g = torch.randn(B, C, S, S, device="cuda") * 1e-4
+    sc = kfac._pow2_scale(g)
+    got = kfac._gram_hip(g, nn.Conv2d(8, C, 3, padding=1), 2.0, geometry=(1, 1, 0, 1), in_scale=sc)
+    gd = g.double().permute(1, 0, 2, 3).reshape(C, -1)
+    want = 2.0 * (gd @ gd.t())
+    assert (got.double() - want).abs().max().item() / want.abs().max().item() < 2e-6
+    assert torch.equal(got, got.t())
+    assert torch.equal(got, kfac._gram_hip(g, nn.Conv2d(8, C, 3, padding=1), 2.0, geometry=(1, 1, 0, 1), in_scale=sc))
+
+
 GRAM_SHAPES = [  # B, C, H, W, k, pad, stride
     (5, 3, 12, 12, 3, 1, 1),      # conv1 at 10x10 (d = 27: one ragged tile)
     (9, 4, 34, 34, 3, 1, 1),      # conv1 of MapNet at 32x32
