@@ -544,9 +544,14 @@ __global__ void k_gram_finish(const float *__restrict__ partial, int ksplit, int
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / d), c = (int)(i - (int64_t)r * d);
         const int lo = r < c ? r : c, hi = r < c ? c : r;
-        float sum = 0.0f;
-        for (int s = 0; s < ksplit; ++s) sum += partial[((size_t)s * d + lo) * dpad + hi];
-        gram[i] = sum * scale;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};                              // four independent chains, joined in a fixed order
+        int s = 0;
+        for (; s + 3 < ksplit; s += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += partial[((size_t)(s + k) * d + lo) * dpad + hi];
+        }
+        for (int k = 0; s < ksplit; ++s, ++k) acc[k] += partial[((size_t)s * d + lo) * dpad + hi];
+        gram[i] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * scale;
     }
 }
 
