@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 from config import MAP_WIDTH
 from Net.activations import (mish as _mish, conv_bias_mish as _conv_bias_mish, pool_conv7_mish as _pool_conv7_mish,
-                             pool_conv7_supported as _pool_conv7_supported, pool_s2 as _pool_s2)
+                             pool_conv7_supported as _pool_conv7_supported, pool_s2 as _pool_s2, linear as _linear)
 
 
 def _pool_is_reference(pool):
@@ -104,9 +104,9 @@ class Net(nn.Module):
             x = _pool_s2(self.pool, x)                                   # (24x24 boards: the row kernels, both directions)
             x = _conv_bias_mish(self.conv7, x)
             x = x.reshape(-1, self.flat)
-        x = self.dropout(self.activation(self.fc1(x)))
-        x = self.dropout(self.activation(self.fc2(x)))
-        return self.actor2(self.activation(self.actor1(x)))
+        x = self.dropout(self.activation(_linear(self.fc1, x)))
+        x = self.dropout(self.activation(_linear(self.fc2, x)))
+        return _linear(self.actor2, self.activation(_linear(self.actor1, x)))
 
     def _forward_plain(self, x):
         x = self.activation(self.conv1(x))

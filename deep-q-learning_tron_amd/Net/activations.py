@@ -417,6 +417,50 @@ class _PoolConv7(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _LinearHIP(torch.autograd.Function):
+    """F.linear whose weight and bias gradients come from one launch pair of csrc/tron_dqn.hip (tron_linear_wgrad: the batch
+    split over workgroups) — the library's kernels for these small outputs over a batch of 4 096 run on 1 to 144 workgroups,
+    26-41 us each, plus a 7-19 us column reduction for the bias.  Forward and input gradient are the library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from tron import _native as nat
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            B, O, I = x.shape[0], weight.shape[0], weight.shape[1]
+            L = nat.lib()
+            gw = torch.empty_like(weight)
+            gb = torch.empty(O, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            ws = torch.empty(max(16, int(L.tron_linear_wgrad_workspace(B, O, I))), dtype=torch.uint8, device=x.device)
+            with torch.cuda.device(x.device):
+                nat.check(L.tron_linear_wgrad(nat.ptr(gy), nat.ptr(x), B, O, I, nat.ptr(gw), nat.ptr(gb), nat.ptr(ws), nat.stream_ptr()),
+                          "tron_linear_wgrad")
+        return gx, gw, gb
+
+
+import os as _os
+_use_linear_hip = _os.environ.get("TRON_LINEAR_HIP", "1") != "0"           # 0: the library's weight-gradient GEMMs (A/B measurements)
+
+
+def linear(layer, x):
+    """layer(x) for an nn.Linear, with its parameter gradients on tron_linear_wgrad where that applies (f32 CUDA, 2-D input, a
+    batch worth splitting); the plain module otherwise."""
+    if (_use_linear_hip and isinstance(layer, torch.nn.Linear) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 256
+            and torch.is_grad_enabled() and layer.weight.requires_grad and layer.weight.dtype == torch.float32 and x.is_contiguous()
+            and layer.weight.is_contiguous()):
+        return _LinearHIP.apply(x, layer.weight, layer.bias)
+    return layer(x)
+
+
 class _PoolS2(torch.autograd.Function):
     """AvgPool2d(3, stride 2, padding 1) (DQNNet.py:20,52) of even-sided planes, both directions on csrc/tron_head.hip's
     row kernels: torch's avg_pool2d backward takes 1.5 ms for 4 096 x 64 planes of 26x26 (one thread per INPUT element

@@ -69,6 +69,8 @@ SIGNATURES = {
     "tron_gemm_f16x3": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "tron_gemm_f16x3_workspace": (C.c_int64, [_i64, _i32, _i64]),
     "tron_absmax_pow2": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "tron_linear_wgrad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "tron_linear_wgrad_workspace": (C.c_int64, [_i64, _i32, _i32]),
     "tron_ddqn_td_loss": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp, _vp, _vp]),
     "tron_eps_greedy": (C.c_int, [_vp, _i64, _vp, C.c_uint32, C.c_uint32, C.c_uint64, _vp, _vp]),
     "tron_eps_schedule": (C.c_int, [_vp, _i64, _vp, _i64, C.c_double, C.c_double, _vp, _vp, _vp]),

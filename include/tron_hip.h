@@ -244,6 +244,13 @@ int64_t tron_gemm_f16x3_workspace(int64_t M, int32_t N, int64_t K);
  * of two that brings max |x| into [2^(target_exp-1), 2^target_exp) (1 for an all-zero x; the exponent clamped to +-60) —
  * the device-side scale the split-f16 kernels take for gradient operands (in_scale / a_scale / grad_absmax), one launch.   */
 int tron_absmax_pow2(const float *x, int64_t n, int32_t target_exp, float *out4, void *stream);
+/* An nn.Linear layer's parameter gradients (DQNNet.py:24-31's fc1 / fc2 / actor1 / actor2 in loss.backward(), DDQN.py:148):
+ * grad_weight f32[out][in] = grad_out^T input, grad_bias f32[out] (may be NULL) = column sums of grad_out; grad_out
+ * f32[batch][out], input f32[batch][in].  Exact f32 FMAs; the batch is split over workgroups and the slices added in a fixed
+ * order (deterministic).  workspace: tron_linear_wgrad_workspace(batch, out, in) bytes (0: not supported).               */
+int tron_linear_wgrad(const float *grad_out, const float *input, int64_t batch, int32_t out_features, int32_t in_features,
+                      float *grad_weight, float *grad_bias, void *workspace, void *stream);
+int64_t tron_linear_wgrad_workspace(int64_t batch, int32_t out_features, int32_t in_features);
 int tron_ddqn_td_loss(const float *q, const int64_t *actions, const float *rewards, const float *dones,
                       const float *q_local_next, const float *q_target_next, float gamma, int64_t batch, float *loss,
                       float *grad_q, void *stream);

@@ -104,3 +104,24 @@ def test_absmax_pow2(n, magnitude):
     else:
         assert 2.0 ** 15 <= want * s < 2.0 ** 16 and abs(torch.log2(torch.tensor(s)).item() - round(torch.log2(torch.tensor(s)).item())) == 0.0
     assert _pow2_scale(x).item() == s
+
+
+@pytest.mark.parametrize("B,O,I", [(4096, 256, 576), (4096, 128, 256), (4096, 64, 128), (4096, 4, 64), (300, 256, 3136), (257, 70, 65), (1000, 1, 1)])
+def test_linear_wgrad_matches_float64(B, O, I):
+    """tron_linear_wgrad (an nn.Linear layer's weight and bias gradient with the batch split over workgroups) against float64;
+    through Net/activations.py::linear against the plain module."""
+    from Net.activations import linear
+    torch.manual_seed(B + O + I)
+    lin = torch.nn.Linear(I, O).cuda()
+    x = torch.randn(B, I, device="cuda", requires_grad=True)
+    gy = torch.randn(B, O, device="cuda") * 1e-3
+    y = linear(lin, x)
+    assert torch.equal(y, lin(x))
+    y.backward(gy)
+    want_w, want_b, want_x = gy.double().t() @ x.detach().double(), gy.double().sum(0), gy.double() @ lin.weight.detach().double()
+    for got, want in ((lin.weight.grad, want_w), (lin.bias.grad, want_b), (x.grad, want_x)):
+        assert (got.double() - want).abs().max().item() / want.abs().max().item() < 3e-6
+    g1 = lin.weight.grad.clone()
+    lin.weight.grad = None
+    linear(lin, x).backward(gy)
+    assert torch.equal(lin.weight.grad, g1)                                # fixed-order sums
