@@ -18,7 +18,8 @@ import torch.nn.functional as F
 
 from config import MAP_WIDTH
 from Net.DQNNet import conv7_side
-from Net.activations import mish as _mish, Conv3x3 as _Conv3x3, pool_s2 as _pool_s2, conv_bias_mish as _conv_bias_mish
+from Net.activations import (mish as _mish, Conv3x3 as _Conv3x3, pool_s2 as _pool_s2, conv_bias_mish as _conv_bias_mish,
+                             pool_conv7_cl_mish as _pool_conv7_cl_mish, pool_conv7_cl_supported as _pool_conv7_cl_supported)
 from Net.kfac import SplitBias as _SplitBias
 
 
@@ -93,9 +94,13 @@ class Net(nn.Module):
         idx = x
         x = self._conv_act(self.conv5, x)
         x = self._conv_act(self.conv6, x, idx)
-        x = _pool_s2(self.pool, x)            # (csrc/tron_head.hip's row kernels at 12 / 26 / 34, both directions; else self.pool)
-        x = self._conv_act(self.conv7, x)
-        x = x.reshape(-1, self.flat)
+        if ((a is Net.mish or a is self.mish) and isinstance(self.conv7, nn.Conv2d) and torch.is_grad_enabled()
+                and _pool_conv7_cl_supported(self.pool, self.conv7, x)):
+            x = _pool_conv7_cl_mish(self.pool, self.conv7, x)   # 24x24 / 32x32 boards, plain A2C: tron_pool_conv7_fwd / _bwd
+        else:                                 # (under K-FAC conv7 is the hooked SplitBias module: its factors need the pooled planes)
+            x = _pool_s2(self.pool, x)        # (csrc/tron_head.hip's row kernels at 12 / 26 / 34, both directions; else self.pool)
+            x = self._conv_act(self.conv7, x)
+            x = x.reshape(-1, self.flat)
         return self.dropout(a(self.fc1(x)))
 
     def _heads(self, x):

@@ -15,7 +15,8 @@ import torch.nn.functional as F
 
 from config import MAP_WIDTH
 from Net.activations import (mish as _mish, conv_bias_mish as _conv_bias_mish, pool_conv7_mish as _pool_conv7_mish,
-                             pool_conv7_supported as _pool_conv7_supported, pool_s2 as _pool_s2, linear as _linear)
+                             pool_conv7_supported as _pool_conv7_supported, pool_s2 as _pool_s2, linear as _linear,
+                             pool_conv7_cl_mish as _pool_conv7_cl_mish, pool_conv7_cl_supported as _pool_conv7_cl_supported)
 
 
 def _pool_is_reference(pool):
@@ -100,6 +101,8 @@ class Net(nn.Module):
     def _after_trunk(self, x):
         if _pool_conv7_supported(self.pool, self.conv7, x):
             x = _pool_conv7_mish(self.pool, self.conv7, x)              # the two layers as GEMMs on conv7's dense form
+        elif _pool_conv7_cl_supported(self.pool, self.conv7, x):
+            x = _pool_conv7_cl_mish(self.pool, self.conv7, x)           # 24x24 / 32x32 boards: implicit GEMMs, both directions
         else:
             x = _pool_s2(self.pool, x)                                   # (24x24 boards: the row kernels, both directions)
             x = _conv_bias_mish(self.conv7, x)

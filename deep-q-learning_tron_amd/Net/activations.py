@@ -417,6 +417,55 @@ class _PoolConv7(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _PoolConv7CL(torch.autograd.Function):
+    """mish(conv7(avg_pool(x))) flattened, for 26x26 / 34x34 planes (24x24 / 32x32 boards; Net/DQNNet.py:52-55): csrc/tron_head.hip's
+    tron_pool_conv7_fwd / _bwd — the pooled planes kept channels-last and split, conv7 forward as the implicit GEMM the
+    gradient-free head uses, its input gradient as four implicit GEMMs (one per parity class of the pooled pixel), its weight
+    gradient from the two channels-last operands read transposed out of LDS.  Replaces MIOpen's NHWC igemm fwd / bwd / wrw
+    kernels and their layout transposes (2.9 ms of the 21.8 ms learn step at 4 096 x 26x26)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from tron import _native as nat
+        L = nat.lib()
+        B, side = x.shape[0], x.shape[-1]
+        o = (side // 2 + 1) // 2
+        dev = x.device
+        with torch.cuda.device(dev):
+            saved = torch.empty(int(L.tron_pool_conv7_saved_bytes(B, side)), dtype=torch.uint8, device=dev)
+            ws = torch.empty(int(L.tron_pool_conv7_workspace(B, side)), dtype=torch.uint8, device=dev)
+            pre = torch.empty(B, o * o, 64, dtype=torch.float32, device=dev)
+            y = torch.empty(B, 64 * o * o, dtype=torch.float32, device=dev)
+            nat.check(L.tron_pool_conv7_fwd(nat.ptr(x), B, side, nat.ptr(weight), nat.ptr(bias), nat.ptr(saved), nat.ptr(pre), nat.ptr(y),
+                                            nat.ptr(ws), nat.stream_ptr()), "tron_pool_conv7_fwd")
+        ctx.save_for_backward(saved, pre, weight)
+        ctx.geometry = (B, side)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from tron import _native as nat
+        L = nat.lib()
+        saved, pre, weight = ctx.saved_tensors
+        B, side = ctx.geometry
+        g = grad_out.contiguous()
+        if not _aligned16(g):
+            g = g.clone(memory_format=torch.contiguous_format)
+        dev = pre.device
+        gx = gw = gb = None
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty(B, 64, side, side, dtype=torch.float32, device=dev)
+            if ctx.needs_input_grad[1] and not skip_weight_gradients:
+                gw = torch.empty_like(weight)
+            if ctx.needs_input_grad[2]:
+                gb = torch.empty(64, dtype=torch.float32, device=dev)
+            ws = torch.empty(int(L.tron_pool_conv7_workspace(B, side)), dtype=torch.uint8, device=dev)
+            nat.check(L.tron_pool_conv7_bwd(nat.ptr(g), nat.ptr(pre), nat.ptr(saved), nat.ptr(weight), B, side, nat.ptr(gx), nat.ptr(gw),
+                                            nat.ptr(gb), nat.ptr(ws), nat.stream_ptr()), "tron_pool_conv7_bwd")
+        return gx, gw, gb
+
+
 class _LinearHIP(torch.autograd.Function):
     """F.linear whose weight and bias gradients come from one launch pair of csrc/tron_dqn.hip (tron_linear_wgrad: the batch
     split over workgroups) — the library's kernels for these small outputs over a batch of 4 096 run on 1 to 144 workgroups,
@@ -514,6 +563,27 @@ def pool_conv7_supported(pool, conv, x):
 def pool_conv7_mish(pool, conv, x):
     """mish(conv7(pool(x))) as [B, Co*3*3] (already flattened in NCHW order) — DQNNet.py:52-55."""
     return _PoolConv7.apply(x, conv.weight, conv.bias)
+
+
+_use_pool_conv7_cl = _os.environ.get("TRON_POOL_CONV7_HIP", "1") != "0"
+
+
+def pool_conv7_cl_supported(pool, conv, x):
+    """The same two layers at 26x26 / 34x34 planes (24x24 / 32x32 boards) on tron_pool_conv7_fwd / _bwd."""
+    if not (_use_pool_conv7_cl and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] == x.shape[-2]
+            and x.shape[-1] in (26, 34) and 0 < x.shape[0] <= (1 << 20) and x.shape[1] == 64 and x.is_contiguous() and _aligned16(x)):
+        return False
+    from Net import fused
+    return (fused.default_math == "f16x3" and isinstance(pool, torch.nn.AvgPool2d) and pool.kernel_size == 3 and pool.stride == 2
+            and pool.padding == 1 and pool.count_include_pad and not pool.ceil_mode and pool.divisor_override is None
+            and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (7, 7) and conv.stride == (2, 2)
+            and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None
+            and conv.in_channels == 64 and conv.out_channels == 64 and conv.weight.is_contiguous() and conv.weight.dtype == torch.float32)
+
+
+def pool_conv7_cl_mish(pool, conv, x):
+    """mish(conv7(pool(x))) as [B, 64 * O * O] (flattened in NCHW order) for 26x26 / 34x34 planes — DQNNet.py:52-55."""
+    return _PoolConv7CL.apply(x, conv.weight, conv.bias)
 
 
 def conv_bias_mish(conv, x, residual=None):

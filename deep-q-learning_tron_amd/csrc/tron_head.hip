@@ -259,9 +259,10 @@ __global__ void k_dense7(const float *__restrict__ src, float *__restrict__ dst,
 // workgroup = one pooled row of one image: the 64 x 13 results go through LDS so that the stores are contiguous 128-byte
 // pixels.  (No zero halo: the CONV7 GEMM's loader predicates the taps that fall outside — the halo'd 19 x 19 image was
 // 2.1x the bytes to write and to fetch.)
-__global__ __launch_bounds__(256) void k_pool_split26(const float *__restrict__ x, f16 *__restrict__ oh, f16 *__restrict__ ol)
+template <int S>
+__global__ __launch_bounds__(256) void k_pool_split_cl(const float *__restrict__ x, f16 *__restrict__ oh, f16 *__restrict__ ol)
 {
-    constexpr int S = 26, PS = 13, C = 64;
+    constexpr int PS = S / 2, C = 64;
     __shared__ float raw[C * 3 * S];                                     // [c][dy][x]: the three input rows of every channel
     __shared__ f16 th[PS * C], tl[PS * C];                               // [px][c]
     const int py = blockIdx.x % PS;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void k_pool_split26(const float *__restrict__ 
         const int q = i % (S / 2), rowi = i / (S / 2), dy = rowi % 3, c = rowi / 3;
         const int yy = 2 * py + dy - 1;
         float2 v = make_float2(0.0f, 0.0f);
-        if (yy >= 0) v = *reinterpret_cast<const float2 *>(img + ((size_t)c * S + yy) * S + 2 * q);   // yy <= 25 always
+        if (yy >= 0) v = *reinterpret_cast<const float2 *>(img + ((size_t)c * S + yy) * S + 2 * q);   // yy <= S - 1 always
         raw[(c * 3 + dy) * S + 2 * q] = v.x;
         raw[(c * 3 + dy) * S + 2 * q + 1] = v.y;
     }
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void k_pool_split26(const float *__restrict__ 
 #pragma unroll
             for (int dx = -1; dx <= 1; ++dx) {
                 const int xx = 2 * px + dx;
-                if (xx >= 0) sum += raw[(c * 3 + dy) * S + xx];          // xx <= 25 always
+                if (xx >= 0) sum += raw[(c * 3 + dy) * S + xx];          // xx <= S - 1 always
             }
         f16 h, l;
         split(sum * (1.0f / 9.0f) * ACT_SCALE, h, l);
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void k_pool_split12_px(const unsigned char *__
     }
 }
 
-// 26x26: the channels-last split image [B][13][13][64] (what k_pool_split26 writes).  One thread = one pooled pixel x one
+// 26x26: the channels-last split image [B][13][13][64] (what k_pool_split_cl<26> writes).  One thread = one pooled pixel x one
 // channel octet: a 16-byte store per half.
 __global__ __launch_bounds__(256) void k_pool_split26_px(const unsigned char *__restrict__ x, int64_t B, f16 *__restrict__ oh,
                                                          f16 *__restrict__ ol)
@@ -445,31 +446,73 @@ constexpr int G_LDS = 2 * A_HALF + 2 * W_HALF;     // 61 440 bytes
 // row-major with K contiguous.  N % 64 == 0, K % 64 == 0.  out_f32 and / or (out_h, out_l) (pre-scaled by 2^-6 again).
 //
 // CONV7 (24x24 boards): the same GEMM as the 7x7 / stride 2 / pad 3 convolution of 13x13 pooled planes — A is then the
-// channels-last split image [image][13 x 13 pixels][64 ci] (k_pool_split26), row m = (image, oy, ox), and K chunk kc is
+// channels-last split image [image][13 x 13 pixels][64 ci] (k_pool_split_cl), row m = (image, oy, ox), and K chunk kc is
 // the 64 channels of pixel (2 oy + ky - 3, 2 ox + kx - 3), (ky, kx) = (kc / 7, kc % 7) — or zeros where that pixel is
 // conv7's padding (30 % of the pieces: not fetched): an implicit GEMM whose im2col is a few integer operations per staged
 // piece.  W is conv7's weight as [co][tap][ci] (conv7w_split); the output rows [image][oy][ox][co] are the next GEMM's A
 // rows as they are.
+// DGRAD7 (training, tron_pool_conv7_bwd): conv7's input gradient as four such GEMMs, one per parity class (iy & 1, ix & 1) of
+// the pooled pixel — tap ky reaches input row iy from output row (iy + 3 - ky) / 2, so a row's taps all have the parity of
+// iy + 3: 3 x 3, 3 x 4, 4 x 3 and 4 x 4 taps for the classes (0,0) (0,1) (1,0) (1,1), no MFMA spent on the 3/4 of the 49 taps
+// that cannot reach a pixel.  A is the gradient at conv7's output, channels-last split [image][OS x OS][64 co]; row m =
+// (image, yy, xx) of the class (iy = 2 yy + py), chunk kc = (jy, jx) is output pixel (yy + (py ? 2 : 1) - jy, ...) or zeros
+// outside; W is [ci][class tap][co] (conv7w_dgrad_split); output row m lands at pooled pixel (iy, ix) of a channels-last f32 image.
+enum { G_PLAIN = 0, G_CONV7 = 1, G_DGRAD7 = 2 };
+template <int PS>
+struct G7 {
+    static constexpr int P = PS, PIX = PS * PS, O = (PS + 1) / 2, OPIX = O * O;
+};
 constexpr int P7 = 13, P7_PIX = P7 * P7, O7 = 7, O7_PIX = O7 * O7;
-// byte offset of the 128-byte K chunk kc of A row m, or -1: the tap falls on conv7's zero padding (CONV7 only)
-template <bool CONV7>
-__device__ __forceinline__ int64_t a_piece_bytes(int m, int kc, int K)
+struct RowGeo {                       // what a_piece_bytes needs of an A row: fixed over the K loop
+    int b, y, x;
+};
+template <int MODE, int PS>
+__device__ __forceinline__ RowGeo row_geo(int m, int cls)
 {
-    if (!CONV7) return (int64_t)m * K * 2 + kc * GK * 2;
-    const int b = m / O7_PIX, p = m - b * O7_PIX, oy = p / O7, ox = p - oy * O7;
-    const int ky = kc / 7, kx = kc - ky * 7;
-    const int iy = 2 * oy + ky - 3, ix = 2 * ox + kx - 3;
-    if ((unsigned)iy >= (unsigned)P7 || (unsigned)ix >= (unsigned)P7) return -1;
-    return ((int64_t)b * P7_PIX + iy * P7 + ix) * 128;
+    RowGeo r{m, 0, 0};
+    if constexpr (MODE == G_CONV7) {
+        using G = G7<PS>;
+        r.b = m / G::OPIX;
+        const int p = m - r.b * G::OPIX;
+        r.y = p / G::O;
+        r.x = p - r.y * G::O;
+    } else if constexpr (MODE == G_DGRAD7) {
+        const int ny = (cls & 2) ? PS / 2 : (PS + 1) / 2, nx = (cls & 1) ? PS / 2 : (PS + 1) / 2;
+        r.b = m / (ny * nx);
+        const int p = m - r.b * (ny * nx);
+        r.y = p / nx;
+        r.x = p - r.y * nx;
+    }
+    return r;
+}
+// byte offset of the 128-byte K chunk kc of an A row, or -1: the tap falls on zero padding (CONV7) / outside the output (DGRAD7)
+template <int MODE, int PS>
+__device__ __forceinline__ int64_t a_piece_bytes(const RowGeo &r, int kc, int K, int cls)
+{
+    if constexpr (MODE == G_PLAIN) return (int64_t)r.b * K * 2 + kc * GK * 2;
+    else if constexpr (MODE == G_CONV7) {
+        using G = G7<PS>;
+        const int ky = kc / 7, kx = kc - ky * 7;
+        const int iy = 2 * r.y + ky - 3, ix = 2 * r.x + kx - 3;
+        if ((unsigned)iy >= (unsigned)G::P || (unsigned)ix >= (unsigned)G::P) return -1;
+        return ((int64_t)r.b * G::PIX + iy * G::P + ix) * 128;
+    } else {
+        using G = G7<PS>;
+        const int tx = (cls & 1) ? 4 : 3;
+        const int jy = kc / tx, jx = kc - jy * tx;
+        const int oy = r.y + ((cls & 2) ? 2 : 1) - jy, ox = r.x + ((cls & 1) ? 2 : 1) - jx;
+        if ((unsigned)oy >= (unsigned)G::O || (unsigned)ox >= (unsigned)G::O) return -1;
+        return ((int64_t)r.b * G::OPIX + oy * G::O + ox) * 128;
+    }
 }
 
-template <bool CONV7>
+template <int MODE, int PS>
 __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_f16x3(const f16 *__restrict__ Ah, const f16 *__restrict__ Al,
                                                              const f16 *__restrict__ Wh, const f16 *__restrict__ Wl,
                                                              const float *__restrict__ bias, int bias_div, int M, int N,
                                                              int K, int act, float *__restrict__ out_f32,
                                                              f16 *__restrict__ out_h, f16 *__restrict__ out_l,
-                                                             const float *__restrict__ a_scale = nullptr)
+                                                             const float *__restrict__ a_scale, int cls)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *a_h = lds, *a_l = lds + A_HALF, *w_h = lds + 2 * A_HALF, *w_l = w_h + W_HALF;
@@ -480,15 +523,20 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_f16x3(const f16 *__restri
 
     // staging: 16-byte pieces; A: [2 halves][128 rows][8 pieces], W: [2 halves][64 rows][8 pieces]
     f32x4 ra[4], rw[2];
+    RowGeo rg[2];                                                         // (pieces j and j + 2 of a thread are the two halves of one row)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int m = m0 + ((tid + j * G_THREADS) & 1023) / 8;
+        m = m < M ? m : M - 1;
+        rg[j] = row_geo<MODE, PS>(m, cls);
+    }
     auto load_chunk = [&](int kc) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int q = tid + j * G_THREADS, half = q >> 10, r = q & 1023, row = r >> 3, pc = r & 7;
-            int m = m0 + row;
-            m = m < M ? m : M - 1;
-            const int64_t ab = a_piece_bytes<CONV7>(m, kc, K);
+            const int q = tid + j * G_THREADS, half = q >> 10, pc = q & 7;
+            const int64_t ab = a_piece_bytes<MODE, PS>(rg[j & 1], kc, K, cls);
             ra[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (!CONV7 || ab >= 0) ra[j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(half ? Al : Ah) + ab + pc * 16);
+            if (MODE == G_PLAIN || ab >= 0) ra[j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(half ? Al : Ah) + ab + pc * 16);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -572,6 +620,12 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_f16x3(const f16 *__restri
                 const int m = m0 + wm * 32 + t * 16 + 4 * g + r;
                 if (m >= M) continue;
                 const float y = act ? mish1(v[r]) : v[r];
+                if constexpr (MODE == G_DGRAD7) {                        // row m of the class -> its pooled pixel, channels-last
+                    const RowGeo o = row_geo<MODE, PS>(m, cls);
+                    const int iy = 2 * o.y + ((cls & 2) ? 1 : 0), ix = 2 * o.x + (cls & 1);
+                    out_f32[((size_t)o.b * G7<PS>::PIX + iy * PS + ix) * N + col] = y;
+                    continue;
+                }
                 if (out_f32) out_f32[(size_t)m * N + col] = y;
                 if (out_h) {
                     f16 hh, ll;
@@ -635,23 +689,24 @@ HeadPlan plan(int64_t B, int K7, int N7, int64_t a7_per_image = 0, int d7_rows =
     return p;
 }
 
-template <bool CONV7>
+template <int MODE, int PS = 13>
 int gemm(const f16 *Ah, const f16 *Al, const f16 *Wh, const f16 *Wl, const float *bias, int bias_div, int64_t M, int N, int K,
-         int act, float *out_f32, f16 *out_h, f16 *out_l, hipStream_t st, const float *a_scale = nullptr)
+         int act, float *out_f32, f16 *out_h, f16 *out_l, hipStream_t st, const float *a_scale = nullptr, int cls = 0)
 {
     static uint64_t prepared = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
     if (!(prepared & (1ull << (dev & 63)))) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3<CONV7>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3<MODE, PS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 G_LDS) != hipSuccess)
             (void)hipGetLastError();
         prepared |= 1ull << (dev & 63);
     }
     if (M >= (1ll << 31) || N % GN != 0 || K % GK != 0) return TRON_ERR_UNSUPPORTED;
+    if (M == 0) return TRON_OK;
     const int64_t blocks = ((M + GM - 1) / GM) * (N / GN);
-    hipLaunchKernelGGL(k_gemm_f16x3<CONV7>, dim3((unsigned)blocks), dim3(G_THREADS), G_LDS, st, Ah, Al, Wh, Wl, bias, bias_div,
-                       (int)M, N, K, act, out_f32, out_h, out_l, a_scale);
+    hipLaunchKernelGGL((k_gemm_f16x3<MODE, PS>), dim3((unsigned)blocks), dim3(G_THREADS), G_LDS, st, Ah, Al, Wh, Wl, bias, bias_div,
+                       (int)M, N, K, act, out_f32, out_h, out_l, a_scale, cls);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
@@ -698,6 +753,336 @@ __global__ __launch_bounds__(256) void k_transpose_split_scaled(const float *__r
     }
 }
 
+// ---- training side of the same layers at 24x24 / 32x32 boards (tron_pool_conv7_fwd / _bwd) -------------------------------
+// conv7's weight [64][64][7][7] -> the four DGRAD7 matrices [class][ci][class tap = jy * tx + jx][co], split; class c = 2 py + px
+// starts at 64 * 64 * {0, 9, 21, 33} elements; tap (ky, kx) = ((py ? 0 : 1) + 2 jy, (px ? 0 : 1) + 2 jx)
+__global__ void k_conv7w_dgrad_split(const float *__restrict__ w, f16 *__restrict__ oh, f16 *__restrict__ ol)
+{
+    const int total = 49 * 64 * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int cls = i < 9 * 4096 ? 0 : (i < 21 * 4096 ? 1 : (i < 33 * 4096 ? 2 : 3));
+        const int base = (cls == 0 ? 0 : (cls == 1 ? 9 : (cls == 2 ? 21 : 33))) * 4096;
+        const int ty = (cls & 2) ? 4 : 3, tx = (cls & 1) ? 4 : 3, taps = ty * tx;
+        const int r = i - base, ci = r / (taps * 64), q = r - ci * (taps * 64), tap = q >> 6, co = q & 63;
+        const int jy = tap / tx, jx = tap - jy * tx;
+        const int ky = ((cls & 2) ? 0 : 1) + 2 * jy, kx = ((cls & 1) ? 0 : 1) + 2 * jx;
+        f16 h, l;
+        split(w[((size_t)co * 64 + ci) * 49 + ky * 7 + kx], h, l);
+        oh[i] = h;
+        ol[i] = l;
+    }
+}
+__global__ void k_conv7w_fwd_split(const float *__restrict__ w, f16 *__restrict__ oh, f16 *__restrict__ ol)
+{
+    conv7w_split(w, oh, ol, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// y[b][co * OPIX + p] = mish(pre[b][p][co]): conv7's pre-activation rows (the CONV7 GEMM's output order) -> the flattened NCHW
+// activation fc1 reads (DQNNet.py:55: x.view(-1, 64 * 7 * 7)).  One image per workgroup pass, through LDS.
+template <int OPIX>
+__global__ __launch_bounds__(256) void k_mish_cl_to_nchw(const float *__restrict__ pre, float *__restrict__ y, int B)
+{
+    __shared__ float t[OPIX * 65];
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const float *src = pre + (size_t)b * OPIX * 64;
+        for (int i = threadIdx.x; i < OPIX * 64; i += 256) t[(i >> 6) * 65 + (i & 63)] = mish1(src[i]);
+        __syncthreads();
+        float *dst = y + (size_t)b * OPIX * 64;
+        for (int i = threadIdx.x; i < OPIX * 64; i += 256) {
+            const int co = i / OPIX, pp = i - co * OPIX;
+            dst[i] = t[pp * 65 + co];
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ float mish_grad1(float x)                    // d mish / dx, as csrc/tron_conv_f16.hip's mish_grad4
+{
+    const uint32_t eb = __float_as_uint(__builtin_amdgcn_exp2f(x * 1.44269504088896341f));
+    const float e = __uint_as_float(eb < 0x5D5E0B6Bu ? eb : 0x5D5E0B6Bu);      // e^x capped at 1e18: t is exactly 1 up there
+    const float n = __fmaf_rn(e, e, e + e);                              // tanh(softplus x) = n / (n + 2)
+    const float r = __builtin_amdgcn_rcpf(n + 2.0f), q = __builtin_amdgcn_rcpf(e + 1.0f);
+    const float t = n * r;
+    return t + x * ((r + r) * (1.0f + t)) * (e * q);                     // t + x (1 - t^2) sigmoid(x)
+}
+
+// gp[b][p][co] = gy[b][co * OPIX + p] * mish'(pre[b][p][co]), written channels-last split (scaled by 2^-6 and the power of two
+// *scale: the DGRAD7 GEMMs' and the weight-gradient kernel's operand) — and its sum over (b, p) per channel, one partial row
+// per workgroup (k_colsum_finish adds them in order).
+template <int OPIX>
+__global__ __launch_bounds__(256) void k_mish_bwd_to_cl(const float *__restrict__ gy, const float *__restrict__ pre, int B,
+                                                        const float *__restrict__ scale, f16 *__restrict__ oh, f16 *__restrict__ ol,
+                                                        float *__restrict__ partial)
+{
+    __shared__ float t[OPIX * 65];
+    __shared__ float red[256];
+    const float sc = *scale * ACT_SCALE;
+    const int co = threadIdx.x & 63;
+    float sum = 0.0f;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const float *src = gy + (size_t)b * OPIX * 64;
+        for (int i = threadIdx.x; i < OPIX * 64; i += 256) {
+            const int c = i / OPIX, pp = i - c * OPIX;
+            t[pp * 65 + c] = src[i];
+        }
+        __syncthreads();
+        const float *pr = pre + (size_t)b * OPIX * 64;
+        for (int i = threadIdx.x; i < OPIX * 64; i += 256) {            // i & 63 == co for every i of this thread
+            const float g = t[(i >> 6) * 65 + co] * mish_grad1(pr[i]);
+            sum += g;
+            f16 h, l;
+            split(g * sc, h, l);
+            oh[(size_t)b * OPIX * 64 + i] = h;
+            ol[(size_t)b * OPIX * 64 + i] = l;
+        }
+        __syncthreads();
+    }
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x < 64) partial[blockIdx.x * 64 + co] = (red[co] + red[co + 64]) + (red[co + 128] + red[co + 192]);
+}
+__global__ __launch_bounds__(1024) void k_colsum_finish(const float *__restrict__ partial, int rows, float *__restrict__ out)
+{
+    __shared__ float red[1024];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;                // sixteen threads per column, each a fixed sixteenth of the rows
+    float a0 = 0.f, a1 = 0.f;                                            // (independent chains: a dependent load -> add chain is ~65 ns a link)
+    int r = q;
+    for (; r + 16 < rows; r += 32) {
+        a0 += partial[r * 64 + c];
+        a1 += partial[(r + 16) * 64 + c];
+    }
+    if (r < rows) a0 += partial[r * 64 + c];
+    red[threadIdx.x] = a0 + a1;
+    __syncthreads();
+    if (q == 0) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s0 += red[c + 128 * k];
+            s1 += red[c + 128 * k + 64];
+        }
+        out[c] = s0 + s1;
+    }
+}
+
+// gx[b][c][y][x] = (1/9) sum of gpool[b][py][px][c] over the pooling windows that contain (y, x): AvgPool2d(3, 2, 1)'s backward
+// from the channels-last pooled gradient (the DGRAD7 GEMMs' output) to the NCHW planes the trunk's backward reads.  One
+// workgroup = input rows 2 py, 2 py + 1 of one image (window rows py and py + 1).
+template <int S>
+__global__ __launch_bounds__(256) void k_pool_bwd_cl(const float *__restrict__ gpool, float *__restrict__ gx)
+{
+    constexpr int PS = S / 2, C = 64;
+    __shared__ float t[2 * (PS + 1) * 65];                               // [window row 0 / 1][px (+ a zero column)][c]
+    const int py = blockIdx.x % PS;
+    const int64_t b = blockIdx.x / PS;
+    for (int i = threadIdx.x; i < 2 * (PS + 1) * C; i += 256) {
+        const int c = i & 63, px = (i >> 6) % (PS + 1), wr = (i >> 6) / (PS + 1);
+        const bool ok = px < PS && py + wr < PS;
+        t[(wr * (PS + 1) + px) * 65 + c] = ok ? gpool[(((size_t)b * PS + py + wr) * PS + px) * C + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 2 * (S / 2); i += 256) {           // (channel, row 0 / 1, pair of columns)
+        const int q = i % (S / 2), yr = (i / (S / 2)) & 1, c = i / S;
+        // even row 2 py: window row py only; odd row 2 py + 1: rows py and py + 1.  Column 2 q: window column q; 2 q + 1: q and q + 1.
+        const float a0 = t[(0 * (PS + 1) + q) * 65 + c] + (yr ? t[(1 * (PS + 1) + q) * 65 + c] : 0.0f);
+        const float a1 = t[(0 * (PS + 1) + q + 1) * 65 + c] + (yr ? t[(1 * (PS + 1) + q + 1) * 65 + c] : 0.0f);
+        *reinterpret_cast<float2 *>(gx + (((size_t)b * C + c) * S + 2 * py + yr) * S + 2 * q) =
+            make_float2(a0 * (1.0f / 9.0f), (a0 + a1) * (1.0f / 9.0f));
+    }
+}
+
+// conv7's WEIGHT gradient, dW[co][ci][ky][kx] = sum over images and output pixels m = (oy, ox) of
+//     gp[m][co] * pooled[2 oy + ky - 3][2 ox + kx - 3][ci]
+// — a product over the SLOW index of two channels-last operands (both are [pixel][64 channels] rows), so the MFMA operands
+// (8 consecutive k per lane for a fixed channel) are read out of LDS transposed: ds_read_b64_tr_b16 hands every lane of a
+// 16-lane group four k-rows of its channel column, each row's address supplied by one lane — which also makes conv7's
+// stride-2 im2col free: the lane that supplies row m of the pooled operand points at pixel (2 oy + ky - 3, 2 ox + kx - 3), or
+// at a row of zeros where that is padding.  No transposed or im2col copy of either operand is ever written.
+//   * a workgroup (4 waves, one per SIMD with the whole register file) owns ONE ky and all seven kx, a slice of the images, all
+//     64 x 64 channel pairs: wave w = input channels 16 w .. 16 w + 15 x four 16-channel output tiles x seven taps = 28 tiles,
+//     224 accumulator registers; the gradient fragments of a k-slab are read once and used for the seven taps;
+//   * per image it needs the gradient rows (OPIX x 64, hi and lo) and the pooled rows iy = 2 oy + ky - 3 (the valid ones of O
+//     rows x PS pixels), 36 KB at 13x13: copied global -> LDS by LDS-DMA into one of two stages while the other is multiplied,
+//     one barrier per image.  Pooled pixels are stored even columns first, then odd, so that consecutive ox are consecutive
+//     LDS rows for either parity of kx.  LDS rows are 160 bytes apart (128 of data): the eight consecutive rows a 32-lane
+//     half reads then start on eight different bank octets — and every address is base + immediate;
+//   * the k of a slab that lane (i, g) holds in element e is 16 (e >> 2) + 4 g + (e & 3) — any assignment works as long as
+//     both operands use it, and this one makes each transposed read's two 16-lane groups of a half fetch rows 8 h .. 8 h + 7;
+//   * K per image = OPIX pixels padded to a multiple of 32 with rows of zeros (49 -> 64: 1.3x; 81 -> 96: 1.19x).
+// Per-(slice, ky) partial sums, added in a fixed order and folded to [co][ci][7][7] by k_conv7_wgrad_finish (deterministic).
+constexpr int W7_THREADS = 256, W7_SLICES = 36, W7_PITCH = 160, W7_PCS = W7_PITCH / 16;
+template <int PS>
+struct W7 {
+    static constexpr int O = (PS + 1) / 2, OPIX = O * O, PIX = PS * PS;
+    static constexpr int SLABS = (OPIX + 31) / 32;
+    static constexpr int GROWS = OPIX + 1, PROWS = O * PS + 1;           // + the row of zeros
+    static constexpr int ROWS = 2 * GROWS + 2 * PROWS, STAGE = ROWS * W7_PITCH, LDS = 2 * STAGE;
+    static constexpr int NSLOT = (ROWS * W7_PCS + W7_THREADS - 1) / W7_THREADS;
+    static constexpr int G_LO = GROWS * W7_PITCH, P_BASE = 2 * GROWS * W7_PITCH, P_LO = PROWS * W7_PITCH;
+    static_assert(LDS <= 160 * 1024 && NSLOT <= 32, "layout");
+};
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_tr(const unsigned char *p)           // ds_read_b64_tr_b16 (EXEC must be all ones)
+{
+    typedef __attribute__((address_space(3))) s16x4 lds_v;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v *)p);
+}
+__device__ __forceinline__ f16x8 lds_tr8(const unsigned char *p0, const unsigned char *p1)
+{
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x4 a = lds_tr(p0), b = lds_tr(p1);
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(f16x8, v);
+}
+
+template <int PS>
+__global__ __launch_bounds__(W7_THREADS) void k_conv7_wgrad(const f16 *__restrict__ gph, const f16 *__restrict__ gpl,
+                                                            const f16 *__restrict__ ph, const f16 *__restrict__ pl, int B, int nsl,
+                                                            float *__restrict__ partial)
+{
+    using C = W7<PS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, g = lane >> 4;
+    const int ky = (int)blockIdx.x % 7, sl = (int)blockIdx.x / 7;
+    const int nimg = sl < B ? (B - sl + nsl - 1) / nsl : 0;              // this workgroup's images: sl, sl + nsl, ...
+
+    for (int i = tid * 16; i < C::LDS; i += W7_THREADS * 16) *reinterpret_cast<f32x4 *>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // what each DMA slot of this thread copies: LDS piece P = slot * 256 + tid (linear: row P / 10, 16-byte position P % 10,
+    // positions 8 and 9 are the padding).  slot_src: the source for this workgroup's first image, or nullptr: the piece stays zero
+    const unsigned char *slot_src[C::NSLOT];
+    uint32_t pooled_slots = 0;                                            // bit j: slot j reads a pooled array (its image stride)
+#pragma unroll
+    for (int j = 0; j < C::NSLOT; ++j) {
+        const int P = j * W7_THREADS + tid, row = P / W7_PCS, pos = P - row * W7_PCS;
+        const unsigned char *src = nullptr;
+        if (pos < 8 && row < 2 * C::GROWS) {
+            const int lo = row >= C::GROWS, r = row - lo * C::GROWS;
+            if (r < C::OPIX) src = reinterpret_cast<const unsigned char *>(lo ? gpl : gph) + ((size_t)sl * C::OPIX + r) * 128 + pos * 16;
+        } else if (pos < 8 && row < C::ROWS) {
+            const int q = row - 2 * C::GROWS, lo = q >= C::PROWS, r = q - lo * C::PROWS;
+            const int oy = r / PS, c = r - oy * PS, ix = c < C::O ? 2 * c : 2 * (c - C::O) + 1, iy = 2 * oy + ky - 3;
+            if (r < C::O * PS && iy >= 0 && iy < PS) {
+                src = reinterpret_cast<const unsigned char *>(lo ? pl : ph) + ((size_t)sl * C::PIX + iy * PS + ix) * 128 + pos * 16;
+                pooled_slots |= 1u << j;
+            }
+        }
+        slot_src[j] = src;
+    }
+    auto dma_image = [&](int stage) {                                     // copies the next image of this workgroup, then steps the sources
+#pragma unroll
+        for (int j = 0; j < C::NSLOT; ++j)
+            if (slot_src[j]) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)slot_src[j],
+                                                 (__attribute__((address_space(3))) void *)(lds + stage * C::STAGE + j * (W7_THREADS * 16) + wave * 1024),
+                                                 16, 0, 0);
+                slot_src[j] += (size_t)nsl * (((pooled_slots >> j) & 1u) ? C::PIX * 128 : C::OPIX * 128);
+            }
+    };
+
+    // LDS byte offsets (within a stage) of the rows this lane supplies to the transposed reads: k = 32 s + 16 j + 4 g + (li >> 2)
+    int a_addr[C::SLABS][2], b_addr[7][C::SLABS][2];
+#pragma unroll
+    for (int s = 0; s < C::SLABS; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = 32 * s + 16 * j + 4 * g + (li >> 2);
+            const int mm = m < C::OPIX ? m : C::OPIX;                    // beyond the image: the row of zeros
+            a_addr[s][j] = mm * W7_PITCH + (li & 3) * 8;                 // output tile t: + 32 t
+            const int oy = m / C::O, ox = m - oy * C::O;
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const int ix = 2 * ox + kx - 3;
+                const bool ok = m < C::OPIX && ix >= 0 && ix < PS;
+                const int R = ok ? oy * PS + ((ix & 1) ? C::O + (ix >> 1) : (ix >> 1)) : C::O * PS;
+                b_addr[kx][s][j] = C::P_BASE + R * W7_PITCH + (4 * wave + (li & 3)) * 8;
+            }
+        }
+
+    f32x4 acc0[7][4], acc1[7][4];
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc0[kx][t] = acc1[kx][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // One (slab, tap) step = 12 MFMAs; the next step's pooled fragments (and, at a slab's last tap, the next slab's gradient
+    // fragments) are requested first and land under them.  The sched_barrier keeps the compiler from hoisting every read of
+    // the image to the top (which it does at one wave per SIMD, and then spills).
+    auto multiply = [&](const unsigned char *S) {
+        f16x8 ah[4], al[4], bh, bl;
+        auto load_a = [&](int s) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ah[t] = lds_tr8(S + a_addr[s][0] + 32 * t, S + a_addr[s][1] + 32 * t);
+                al[t] = lds_tr8(S + C::G_LO + a_addr[s][0] + 32 * t, S + C::G_LO + a_addr[s][1] + 32 * t);
+            }
+        };
+        load_a(0);
+        bh = lds_tr8(S + b_addr[0][0][0], S + b_addr[0][0][1]);
+        bl = lds_tr8(S + C::P_LO + b_addr[0][0][0], S + C::P_LO + b_addr[0][0][1]);
+#pragma unroll
+        for (int s = 0; s < C::SLABS; ++s)
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const f16x8 ch = bh, cl = bl;
+                f16x8 a0[4], a1[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { a0[t] = ah[t]; a1[t] = al[t]; }
+                const int nk = kx == 6 ? 0 : kx + 1, ns = kx == 6 ? s + 1 : s;
+                if (ns < C::SLABS) {
+                    bh = lds_tr8(S + b_addr[nk][ns][0], S + b_addr[nk][ns][1]);
+                    bl = lds_tr8(S + C::P_LO + b_addr[nk][ns][0], S + C::P_LO + b_addr[nk][ns][1]);
+                    if (kx == 6) load_a(ns);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc1[kx][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[t], cl, acc1[kx][t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc0[kx][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[t], ch, acc0[kx][t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc1[kx][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[t], ch, acc1[kx][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    __syncthreads();                                                     // the zeros are in before any copy lands
+    if (nimg > 0) dma_image(0);
+    for (int n = 0; n < nimg; ++n) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // image n is in; everybody is done with the other stage
+        if (n + 1 < nimg) dma_image((n + 1) & 1);
+        multiply(lds + (n & 1) * C::STAGE);
+    }
+
+    // D row = 4 g + r (output channel within the tile), column = li (input channel): partial[slice][ky][kx][co][ci]
+    float *out = partial + ((size_t)(sl * 7 + ky) * 7) * 4096;
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 v = acc0[kx][t] + acc1[kx][t] * LO_UNSCALE;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)kx * 4096 + (16 * t + 4 * g + r) * 64 + 16 * wave + li] = v[r];
+        }
+}
+
+// dW[co][ci][tap] = (2^12 / scale) * sum over the slices of partial[slice][tap][co][ci]   (both operands carry 2^-6, the
+// gradient the power of two *scale on top)
+__global__ void k_conv7_wgrad_finish(const float *__restrict__ partial, int nsl, const float *__restrict__ scale, float *__restrict__ gw)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;                 // (tap, co, ci), ci fastest
+    if (i >= 49 * 4096) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < nsl; s += 4) {
+        a0 += partial[(size_t)(s + 0) * 49 * 4096 + i];
+        a1 += partial[(size_t)(s + 1) * 49 * 4096 + i];
+        a2 += partial[(size_t)(s + 2) * 49 * 4096 + i];
+        a3 += partial[(size_t)(s + 3) * 49 * 4096 + i];
+    }
+    for (; s < nsl; ++s) a0 += partial[(size_t)s * 49 * 4096 + i];
+    const int tap = i >> 12, coci = i & 4095;
+    gw[(size_t)coci * 49 + tap] = ((a0 + a1) + (a2 + a3)) * (4096.0f / *scale);
+}
+
 }  // namespace
 
 // C[M][N] = A B^T + bias[n] on the split-f16 matrix cores (three MFMAs per slab, f32 accumulation: f32-grade), f32 in and out.
@@ -737,7 +1122,7 @@ extern "C" int tron_gemm_f16x3(const float *A, int32_t a_transposed, const float
     else
         hipLaunchKernelGGL(k_split_scaled, dim3(blocks_for((int64_t)N * K)), dim3(256), 0, st, B, (int64_t)N * K, (const float *)nullptr, 1.0f, bh, bl);
     if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
-    return gemm<false>(ah, al, bh, bl, bias, 1, M, N, (int)kpad, 0, C, nullptr, nullptr, st, a_scale);
+    return gemm<G_PLAIN>(ah, al, bh, bl, bias, 1, M, N, (int)kpad, 0, C, nullptr, nullptr, st, a_scale);
 }
 
 
@@ -769,17 +1154,17 @@ static int head_fwd(const void *trunk, bool px16, int64_t batch, int32_t side, c
         unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
         auto H = [&](int64_t off) { return reinterpret_cast<f16 *>(ws + off); };
         if (px16) hipLaunchKernelGGL(k_pool_split26_px, dim3((unsigned)((batch * 169 * 8 + 255) / 256 < (1 << 20) ? (batch * 169 * 8 + 255) / 256 : (1 << 20))), dim3(256), 0, st, trunk_px, batch, H(p.a7h), H(p.a7l));
-        else hipLaunchKernelGGL(k_pool_split26, dim3((unsigned)(batch * 13)), dim3(256), 0, st, trunk_out, H(p.a7h), H(p.a7l));
+        else hipLaunchKernelGGL(k_pool_split_cl<26>, dim3((unsigned)(batch * 13)), dim3(256), 0, st, trunk_out, H(p.a7h), H(p.a7l));
         const HeadWeights hw{conv7_w, fc1_w, fc2_w, actor1_w, H(p.d7h), H(p.d7l), H(p.w1h), H(p.w1l), H(p.w2h), H(p.w2l), H(p.w3h), H(p.w3l),
                              1, 0, 256 * N1};
         hipLaunchKernelGGL(k_head_weights, dim3(1024, 4), dim3(256), 0, st, hw);
         if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
         // conv7 as the implicit GEMM [B * 49] x [64] over K = 49 taps x 64 channels; its output rows are fc1's input rows
-        int rc = gemm<true>(H(p.a7h), H(p.a7l), H(p.d7h), H(p.d7l), conv7_b, 1, batch * O7_PIX, 64, K7, 1, nullptr, H(p.c7h), H(p.c7l), st);
-        if (rc == TRON_OK) rc = gemm<false>(H(p.c7h), H(p.c7l), H(p.w1h), H(p.w1l), fc1_b, 1, batch, 256, N1, 1, nullptr, H(p.c1h), H(p.c1l), st);
-        if (rc == TRON_OK) rc = gemm<false>(H(p.c1h), H(p.c1l), H(p.w2h), H(p.w2l), fc2_b, 1, batch, 128, 256, 1, nullptr, H(p.c2h), H(p.c2l), st);
+        int rc = gemm<G_CONV7, 13>(H(p.a7h), H(p.a7l), H(p.d7h), H(p.d7l), conv7_b, 1, batch * O7_PIX, 64, K7, 1, nullptr, H(p.c7h), H(p.c7l), st);
+        if (rc == TRON_OK) rc = gemm<G_PLAIN>(H(p.c7h), H(p.c7l), H(p.w1h), H(p.w1l), fc1_b, 1, batch, 256, N1, 1, nullptr, H(p.c1h), H(p.c1l), st);
+        if (rc == TRON_OK) rc = gemm<G_PLAIN>(H(p.c1h), H(p.c1l), H(p.w2h), H(p.w2l), fc2_b, 1, batch, 128, 256, 1, nullptr, H(p.c2h), H(p.c2l), st);
         float *c3 = reinterpret_cast<float *>(ws + p.c3);
-        if (rc == TRON_OK) rc = gemm<false>(H(p.c2h), H(p.c2l), H(p.w3h), H(p.w3l), actor1_b, 1, batch, 64, 128, 1, c3, nullptr, nullptr, st);
+        if (rc == TRON_OK) rc = gemm<G_PLAIN>(H(p.c2h), H(p.c2l), H(p.w3h), H(p.w3l), actor1_b, 1, batch, 64, 128, 1, c3, nullptr, nullptr, st);
         if (rc != TRON_OK) return rc;
         hipLaunchKernelGGL(k_q_head, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, c3, actor2_w, actor2_b, (int)batch, 64,
                            q_out, greedy_out);
@@ -796,11 +1181,11 @@ static int head_fwd(const void *trunk, bool px16, int64_t batch, int32_t side, c
                          0, px16 ? 1 : 0, 256 * N7};
     hipLaunchKernelGGL(k_head_weights, dim3(1024, 4), dim3(256), 0, st, hw);
     if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
-    int rc = gemm<false>(H(p.a7h), H(p.a7l), H(p.d7h), H(p.d7l), conv7_b, OS * OS, batch, N7, K7, 1, nullptr, H(p.c7h), H(p.c7l), st);
-    if (rc == TRON_OK) rc = gemm<false>(H(p.c7h), H(p.c7l), H(p.w1h), H(p.w1l), fc1_b, 1, batch, 256, N7, 1, nullptr, H(p.c1h), H(p.c1l), st);
-    if (rc == TRON_OK) rc = gemm<false>(H(p.c1h), H(p.c1l), H(p.w2h), H(p.w2l), fc2_b, 1, batch, 128, 256, 1, nullptr, H(p.c2h), H(p.c2l), st);
+    int rc = gemm<G_PLAIN>(H(p.a7h), H(p.a7l), H(p.d7h), H(p.d7l), conv7_b, OS * OS, batch, N7, K7, 1, nullptr, H(p.c7h), H(p.c7l), st);
+    if (rc == TRON_OK) rc = gemm<G_PLAIN>(H(p.c7h), H(p.c7l), H(p.w1h), H(p.w1l), fc1_b, 1, batch, 256, N7, 1, nullptr, H(p.c1h), H(p.c1l), st);
+    if (rc == TRON_OK) rc = gemm<G_PLAIN>(H(p.c1h), H(p.c1l), H(p.w2h), H(p.w2l), fc2_b, 1, batch, 128, 256, 1, nullptr, H(p.c2h), H(p.c2l), st);
     float *c3 = reinterpret_cast<float *>(ws + p.c3);
-    if (rc == TRON_OK) rc = gemm<false>(H(p.c2h), H(p.c2l), H(p.w3h), H(p.w3l), actor1_b, 1, batch, 64, 128, 1, c3, nullptr, nullptr, st);
+    if (rc == TRON_OK) rc = gemm<G_PLAIN>(H(p.c2h), H(p.c2l), H(p.w3h), H(p.w3l), actor1_b, 1, batch, 64, 128, 1, c3, nullptr, nullptr, st);
     if (rc != TRON_OK) return rc;
     hipLaunchKernelGGL(k_q_head, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, c3, actor2_w, actor2_b, (int)batch, 64,
                        q_out, greedy_out);
@@ -824,6 +1209,145 @@ extern "C" int tron_dqn_head_fwd_px16(const void *trunk_px16, int64_t batch, int
 {
     return head_fwd(trunk_px16, true, batch, side, conv7_w, conv7_b, fc1_w, fc1_b, fc2_w, fc2_b, actor1_w, actor1_b, actor2_w,
                     actor2_b, workspace, q_out, greedy_out, stream);
+}
+
+// ---- training at 24x24 / 32x32 boards: pool + conv7 + mish (DQNNet.py:52-54; the actor-critic nets' ACNet.py tail alike) with
+// everything on this file's kernels, forward and backward (Net/activations.py::_PoolConv7CL) --------------------------------
+namespace {
+struct P7Plan {
+    int64_t out4, gph, gpl, wh, wl, gpool, bpart, wpart, total;
+};
+P7Plan p7_plan(int64_t B, int PS)
+{
+    const int O = (PS + 1) / 2;
+    P7Plan p{};
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { const int64_t at = o; o = align256(o + bytes); return at; };
+    p.out4 = take(256);
+    p.wh = take(49ll * 4096 * 2); p.wl = take(49ll * 4096 * 2);
+    p.gph = take(B * O * O * 128); p.gpl = take(B * O * O * 128);
+    p.gpool = take(B * PS * PS * 256);
+    p.bpart = take(1024ll * 64 * 4);
+    p.wpart = take((int64_t)W7_SLICES * 49 * 4096 * 4);
+    p.total = o;
+    return p;
+}
+inline bool p7_side_ok(int32_t side) { return side == 26 || side == 34; }
+
+template <int S>
+int p7_fwd(const float *x, int64_t B, const float *w, const float *bias, void *saved, float *pre, float *y, void *workspace, hipStream_t st)
+{
+    constexpr int PS = S / 2, O = (PS + 1) / 2;
+    const P7Plan p = p7_plan(B, PS);
+    unsigned char *ws = reinterpret_cast<unsigned char *>(workspace), *sv = reinterpret_cast<unsigned char *>(saved);
+    f16 *ph = reinterpret_cast<f16 *>(sv), *pl = reinterpret_cast<f16 *>(sv + align256(B * PS * PS * 128));
+    f16 *wh = reinterpret_cast<f16 *>(ws + p.wh), *wl = reinterpret_cast<f16 *>(ws + p.wl);
+    hipLaunchKernelGGL(k_pool_split_cl<S>, dim3((unsigned)(B * PS)), dim3(256), 0, st, x, ph, pl);
+    hipLaunchKernelGGL(k_conv7w_fwd_split, dim3(784), dim3(256), 0, st, w, wh, wl);
+    if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
+    const int rc = gemm<G_CONV7, PS>(ph, pl, wh, wl, bias, 1, B * O * O, 64, 64 * 49, 0, pre, nullptr, nullptr, st);
+    if (rc != TRON_OK) return rc;
+    hipLaunchKernelGGL(k_mish_cl_to_nchw<O * O>, dim3((unsigned)(B < 4096 ? B : 4096)), dim3(256), 0, st, pre, y, (int)B);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+template <int S>
+int p7_bwd(const float *gy, const float *pre, const void *saved, const float *w, int64_t B, float *gx, float *gw, float *gb, void *workspace,
+           hipStream_t st)
+{
+    constexpr int PS = S / 2, O = (PS + 1) / 2, OPIX = O * O;
+    const P7Plan p = p7_plan(B, PS);
+    unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    const unsigned char *sv = reinterpret_cast<const unsigned char *>(saved);
+    const f16 *ph = reinterpret_cast<const f16 *>(sv), *pl = reinterpret_cast<const f16 *>(sv + align256(B * PS * PS * 128));
+    float *out4 = reinterpret_cast<float *>(ws + p.out4), *bpart = reinterpret_cast<float *>(ws + p.bpart);
+    f16 *gph = reinterpret_cast<f16 *>(ws + p.gph), *gpl = reinterpret_cast<f16 *>(ws + p.gpl);
+    // the gradient's power-of-two scale from max |gy| (|mish'| <= 1.09: one binade of headroom below f16's range is kept)
+    if (hipMemsetAsync(out4, 0, 16, st) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_LAUNCH; }
+    int rc = tron_absmax_pow2(gy, B * OPIX * 64, 15, out4, st);
+    if (rc != TRON_OK) return rc;
+    const int bblocks = (int)(B < 1024 ? B : 1024);
+    hipLaunchKernelGGL(k_mish_bwd_to_cl<OPIX>, dim3((unsigned)bblocks), dim3(256), 0, st, gy, pre, (int)B, out4, gph, gpl, bpart);
+    if (gb) hipLaunchKernelGGL(k_colsum_finish, dim3(1), dim3(1024), 0, st, bpart, bblocks, gb);
+    if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
+    if (gx) {
+        f16 *wh = reinterpret_cast<f16 *>(ws + p.wh), *wl = reinterpret_cast<f16 *>(ws + p.wl);
+        float *gpool = reinterpret_cast<float *>(ws + p.gpool);
+        hipLaunchKernelGGL(k_conv7w_dgrad_split, dim3(784), dim3(256), 0, st, w, wh, wl);
+        if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
+        const int first[4] = {0, 9, 21, 33};
+        for (int cls = 0; cls < 4 && rc == TRON_OK; ++cls) {
+            const int ny = (cls & 2) ? PS / 2 : (PS + 1) / 2, nx = (cls & 1) ? PS / 2 : (PS + 1) / 2;
+            const int taps = ((cls & 2) ? 4 : 3) * ((cls & 1) ? 4 : 3);
+            rc = gemm<G_DGRAD7, PS>(gph, gpl, wh + first[cls] * 4096, wl + first[cls] * 4096, nullptr, 1, B * ny * nx, 64, taps * 64, 0, gpool,
+                                    nullptr, nullptr, st, out4, cls);
+        }
+        if (rc != TRON_OK) return rc;
+        hipLaunchKernelGGL(k_pool_bwd_cl<S>, dim3((unsigned)(B * PS)), dim3(256), 0, st, gpool, gx);
+        if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
+    }
+    if (gw) {
+        static uint64_t prepared = 0;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
+        if (!(prepared & (1ull << (dev & 63)))) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv7_wgrad<PS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    W7<PS>::LDS) != hipSuccess)
+                (void)hipGetLastError();
+            prepared |= 1ull << (dev & 63);
+        }
+        const int nsl = (int)(B < W7_SLICES ? B : W7_SLICES);
+        float *wpart = reinterpret_cast<float *>(ws + p.wpart);
+        hipLaunchKernelGGL(k_conv7_wgrad<PS>, dim3((unsigned)(7 * nsl)), dim3(W7_THREADS), W7<PS>::LDS, st, gph, gpl, ph, pl, (int)B, nsl, wpart);
+        hipLaunchKernelGGL(k_conv7_wgrad_finish, dim3(49 * 4096 / 256), dim3(256), 0, st, wpart, nsl, out4, gw);
+        if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
+    }
+    return TRON_OK;
+}
+}  // namespace
+
+extern "C" int64_t tron_pool_conv7_saved_bytes(int64_t batch, int32_t side)
+{
+    if (batch < 1 || !p7_side_ok(side) || batch > (1ll << 20)) return 0;
+    const int PS = side / 2;
+    return 2 * align256(batch * PS * PS * 128);
+}
+
+extern "C" int64_t tron_pool_conv7_workspace(int64_t batch, int32_t side)
+{
+    if (batch < 1 || !p7_side_ok(side) || batch > (1ll << 20)) return 0;
+    return p7_plan(batch, side / 2).total;
+}
+
+extern "C" int tron_pool_conv7_fwd(const float *x, int64_t batch, int32_t side, const float *weight, const float *bias, void *saved,
+                                   float *pre, float *y, void *workspace, void *stream)
+{
+    if (!x || !weight || !bias || !saved || !pre || !y || !workspace || batch < 0) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(saved) | reinterpret_cast<uintptr_t>(pre) | reinterpret_cast<uintptr_t>(y) |
+         reinterpret_cast<uintptr_t>(workspace)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    if (batch == 0) return TRON_OK;
+    if (!p7_side_ok(side) || batch > (1ll << 20)) return TRON_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return side == 26 ? p7_fwd<26>(x, batch, weight, bias, saved, pre, y, workspace, st) : p7_fwd<34>(x, batch, weight, bias, saved, pre, y, workspace, st);
+}
+
+extern "C" int tron_pool_conv7_bwd(const float *grad_y, const float *pre, const void *saved, const float *weight, int64_t batch, int32_t side,
+                                   float *grad_x, float *grad_weight, float *grad_bias, void *workspace, void *stream)
+{
+    if (!grad_y || !pre || !saved || !weight || !workspace || batch < 0) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(saved) | reinterpret_cast<uintptr_t>(pre) |
+         reinterpret_cast<uintptr_t>(grad_x) | reinterpret_cast<uintptr_t>(workspace)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    if (!p7_side_ok(side) || batch > (1ll << 20)) return TRON_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (batch == 0) {                                                    // nothing to sum: zero parameter gradients
+        if (grad_weight && hipMemsetAsync(grad_weight, 0, 49 * 4096 * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_LAUNCH; }
+        if (grad_bias && hipMemsetAsync(grad_bias, 0, 64 * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_LAUNCH; }
+        return TRON_OK;
+    }
+    return side == 26 ? p7_bwd<26>(grad_y, pre, saved, weight, batch, grad_x, grad_weight, grad_bias, workspace, st)
+                      : p7_bwd<34>(grad_y, pre, saved, weight, batch, grad_x, grad_weight, grad_bias, workspace, st);
 }
 
 // ---- training-path pieces of the same layers (Net/activations.py::_PoolConv7): pooling forward / backward on 12x12

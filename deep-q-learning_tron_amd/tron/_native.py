@@ -14,7 +14,7 @@ MODE = {None: 0, "none": 0, "ice": 1, "temper": 2}                 # tron/game.p
 OBS_NONE, OBS_CODES_I8, OBS_PLANES3_F32, OBS_PLANES4_F32 = 0, 1, 2, 3
 OBS = {None: OBS_NONE, "none": OBS_NONE, "codes": OBS_CODES_I8, "planes3": OBS_PLANES3_F32,
        "planes4": OBS_PLANES4_F32}
-ABI_VERSION = 6                                                    # include/tron_hip.h TRON_ABI_VERSION
+ABI_VERSION = 7                                                    # include/tron_hip.h TRON_ABI_VERSION
 STEP_AUTORESET = 1
 STEP_INCREMENTAL = 2
 STEP_NONREVERSING = 4
@@ -97,6 +97,10 @@ SIGNATURES = {
     "tron_pool_s2": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "tron_pool_s2_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "tron_conv7_dense": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "tron_pool_conv7_saved_bytes": (C.c_int64, [_i64, _i32]),
+    "tron_pool_conv7_workspace": (C.c_int64, [_i64, _i32]),
+    "tron_pool_conv7_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tron_pool_conv7_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
 
 MINIMAX = {"voronoi": 0, "distwall": 1}

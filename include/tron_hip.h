@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TRON_ABI_VERSION 6
+#define TRON_ABI_VERSION 7
 
 typedef enum {
     TRON_OK = 0,
@@ -466,6 +466,23 @@ int tron_pool_s2(const float *x, float *y, int64_t planes, int32_t side, void *s
  * DQNNet.py:52 / ACNet.py's pooling on the training path).  side 12, 26 or 34 (tron_pool_s2 likewise).                */
 int tron_pool_s2_bwd(const float *grad_y, float *grad_x, int64_t planes, int32_t side, void *stream);
 int tron_conv7_dense(const float *src, float *dst, int32_t cout, int32_t cin, int32_t fold, void *stream);
+/* The same layers on the training path at 24x24 / 32x32 boards — x = pool(x); x = mish(conv7(x)); x.view(-1, 64*O*O)
+ * (Net/DQNNet.py:52-55; the actor-critic nets' tails in Net/ACNet.py alike) and what loss.backward() computes for them
+ * (DDQN.py:148) — on the split-f16 matrix cores end to end, replacing the library's NHWC convolution kernels and their layout
+ * transposes.  side 26 (13x13 pooled planes, O = 7) or 34 (17x17, O = 9); conv7 is 64 -> 64 channels, 7x7 / stride 2 / pad 3.
+ *   fwd: x f32[batch][64][side][side] -> pooled planes kept channels-last and split in `saved` (tron_pool_conv7_saved_bytes),
+ *        pre f32[batch][O*O][64] = conv7 + bias (channels-last), y f32[batch][64*O*O] = mish(pre) in NCHW-flatten order.
+ *   bwd: grad_y f32[batch][64*O*O] -> grad_x f32[batch][64][side][side] (four implicit GEMMs, one per parity class of the
+ *        pooled pixel, then the pooling's backward), grad_weight f32[64][64][7][7] (operands read transposed out of LDS, the
+ *        stride-2 im2col done by the read addresses; per-slice partial sums added in a fixed order), grad_bias f32[64];
+ *        each may be NULL.  The gradient is scaled by a power of two taken from max |grad_y| on the device.
+ * workspace: tron_pool_conv7_workspace(batch, side) bytes, 16-byte aligned like every pointer here; batch <= 2^20.        */
+int64_t tron_pool_conv7_saved_bytes(int64_t batch, int32_t side);
+int64_t tron_pool_conv7_workspace(int64_t batch, int32_t side);
+int tron_pool_conv7_fwd(const float *x, int64_t batch, int32_t side, const float *weight, const float *bias, void *saved, float *pre,
+                        float *y, void *workspace, void *stream);
+int tron_pool_conv7_bwd(const float *grad_y, const float *pre, const void *saved, const float *weight, int64_t batch, int32_t side,
+                        float *grad_x, float *grad_weight, float *grad_bias, void *workspace, void *stream);
 
 /* Wait for `stream` and report what the kernels queued on it did: launch_status-style calls above only
  * see a REJECTED launch; a fault inside a kernel surfaces at the next synchronisation.  Returns TRON_OK
