@@ -429,6 +429,90 @@ int launch(const float *in, const float *gp, const float *absmax, int n_absmax, 
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
+// conv1's weight gradient on boards whose image does not fit the strip layout (26x26, 34x34: cin = 3 or 4 planes, 32 output
+// channels — 4.8 GFLOP at 4 096 x 26x26, against 354 MB of gradient to read): plain f32 FMAs, one pass over the gradient.
+// A workgroup walks its images; the image's input planes sit in LDS with a zero halo (9 - 21 KB).  Thread (co, row group):
+// for each of its rows, the gradient row of its channel in registers (S floats) x the CIN x 3 haloed input rows around it,
+// read from LDS as broadcasts (the 32 lanes of a channel group share every address), 9 CIN accumulators per thread.  The
+// eight row groups of a channel meet in LDS; per-workgroup partial sums, k_wgrad_reduce adds them in a fixed order.
+template <int S, int CIN>
+__global__ __launch_bounds__(256) void k_wgrad_small(const float *__restrict__ in, const float *__restrict__ gp, float *__restrict__ partial,
+                                                     int batch)
+{
+    constexpr int HP = S + 2, TAPS = CIN * 9, NQ = HP / 4;               // HP % 4 == 0: a haloed row is NQ aligned 16-byte reads
+    static_assert(HP % 4 == 0 && S % 2 == 0, "row reads");
+    __shared__ __attribute__((aligned(16))) float pl[CIN * HP * HP];
+    __shared__ float red[8 * 32 * TAPS];
+    const int tid = threadIdx.x, co = tid & 31, rg = tid >> 5;
+    for (int i = tid; i < CIN * HP * HP; i += 256) pl[i] = 0.0f;
+    float acc[TAPS];
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) acc[k] = 0.0f;
+    for (int b = blockIdx.x; b < batch; b += gridDim.x) {
+        __syncthreads();                                                 // (the halo's zeros / the previous image's readers)
+        const float *img = in + (size_t)b * CIN * S * S;
+        for (int i = tid; i < CIN * S * S; i += 256) {
+            const int c = i / (S * S), r = i - c * (S * S), y = r / S, x = r - y * S;
+            pl[(c * HP + y + 1) * HP + x + 1] = img[i];
+        }
+        __syncthreads();
+        const float *g = gp + ((size_t)b * 32 + co) * S * S;
+        for (int y = rg; y < S; y += 8) {
+            float gr[S];
+#pragma unroll
+            for (int q = 0; q < S / 2; ++q) {
+                const float2 v = *reinterpret_cast<const float2 *>(g + y * S + 2 * q);
+                gr[2 * q] = v.x;
+                gr[2 * q + 1] = v.y;
+            }
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    float row[HP];                                       // haloed input row y + ky - 1: row[x + kx] is the pixel under tap kx
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(&pl[(c * HP + y + ky) * HP + 4 * q]);
+                        row[4 * q] = v[0]; row[4 * q + 1] = v[1]; row[4 * q + 2] = v[2]; row[4 * q + 3] = v[3];
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float a = acc[(c * 3 + ky) * 3 + kx];
+#pragma unroll
+                        for (int x = 0; x < S; ++x) a = __fmaf_rn(gr[x], row[x + kx], a);
+                        acc[(c * 3 + ky) * 3 + kx] = a;
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) red[(rg * 32 + co) * TAPS + k] = acc[k];
+    __syncthreads();
+    float *out = partial + (size_t)blockIdx.x * 32 * TAPS;               // [co][ci][tap]: the weight's own order
+    for (int i = tid; i < 32 * TAPS; i += 256) {
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s0 += red[(2 * r) * 32 * TAPS + i];
+            s1 += red[(2 * r + 1) * 32 * TAPS + i];
+        }
+        out[i] = s0 + s1;
+    }
+}
+
+template <int S, int CIN>
+int launch_small(const float *in, const float *gp, float *grad_w, int64_t batch, unsigned char *ws, hipStream_t st)
+{
+    const Plan p = plan(CIN, 32);
+    constexpr int W = 32 * CIN * 9;
+    float *partial = reinterpret_cast<float *>(ws + p.partial), *stage2 = reinterpret_cast<float *>(ws + p.stage2);
+    const int grid = (int)(batch < 3 * GRID_MAX ? batch : 3 * GRID_MAX);   // three resident workgroups per CU (138 - 170 VGPRs): one round.  (plan(): room for 4 GRID_MAX partial rows at cin <= 16)
+    hipLaunchKernelGGL((k_wgrad_small<S, CIN>), dim3((unsigned)grid), dim3(256), 0, st, in, gp, partial, (int)batch);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 255) / 256, STAGE2), dim3(256), 0, st, partial, grid, STAGE2, W, stage2);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 255) / 256, 1), dim3(256), 0, st, stage2, STAGE2, 1, W, grad_w);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
 }  // namespace
 
 #ifdef TRON_WG_STAMPS
@@ -458,11 +542,16 @@ extern "C" int tron_conv3x3_wgrad(const float *in, const float *grad_pre, const 
         return TRON_ERR_BAD_ARG;
     const bool small = cin == 3 || cin == 4;
     const bool rows = side == 26 && (cin == 32 || cin == 64) && (cout == 32 || cout == 64) && !(cin == 64 && cout == 32);
-    if (!(side == SIDE || rows) || !(small || cin == 32 || cin == 64) || !(cout == 32 || cout == 64) || batch > (1ll << 24))
+    const bool small_big = small && cout == 32 && (side == 26 || side == 34);   // conv1 at 24x24 / 32x32 boards: f32 FMAs
+    if (!(side == SIDE || rows || small_big) || !(small || cin == 32 || cin == 64) || !(cout == 32 || cout == 64) || batch > (1ll << 24))
         return TRON_ERR_UNSUPPORTED;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (batch == 0) return hipMemsetAsync(grad_weight, 0, (size_t)cout * cin * 9 * 4, st) == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    if (small_big) {                                                     // (no scale: the products stay in f32)
+        if (side == 26) return cin == 3 ? launch_small<26, 3>(in, grad_pre, grad_weight, batch, ws, st) : launch_small<26, 4>(in, grad_pre, grad_weight, batch, ws, st);
+        return cin == 3 ? launch_small<34, 3>(in, grad_pre, grad_weight, batch, ws, st) : launch_small<34, 4>(in, grad_pre, grad_weight, batch, ws, st);
+    }
     if (!grad_absmax) {
         const size_t n4 = (size_t)batch * cout * side * side / 4;
         const unsigned blocks = (unsigned)((n4 + 255) / 256 < ABSMAX_BLOCKS ? (n4 + 255) / 256 : ABSMAX_BLOCKS);

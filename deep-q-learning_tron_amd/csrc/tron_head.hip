@@ -867,27 +867,30 @@ __global__ __launch_bounds__(1024) void k_colsum_finish(const float *__restrict_
 
 // gx[b][c][y][x] = (1/9) sum of gpool[b][py][px][c] over the pooling windows that contain (y, x): AvgPool2d(3, 2, 1)'s backward
 // from the channels-last pooled gradient (the DGRAD7 GEMMs' output) to the NCHW planes the trunk's backward reads.  One
-// workgroup = input rows 2 py, 2 py + 1 of one image (window rows py and py + 1).
+// workgroup = 16 channels of one image: their planes are written as one contiguous run of whole cache lines.
 template <int S>
 __global__ __launch_bounds__(256) void k_pool_bwd_cl(const float *__restrict__ gpool, float *__restrict__ gx)
 {
-    constexpr int PS = S / 2, C = 64;
-    __shared__ float t[2 * (PS + 1) * 65];                               // [window row 0 / 1][px (+ a zero column)][c]
-    const int py = blockIdx.x % PS;
-    const int64_t b = blockIdx.x / PS;
-    for (int i = threadIdx.x; i < 2 * (PS + 1) * C; i += 256) {
-        const int c = i & 63, px = (i >> 6) % (PS + 1), wr = (i >> 6) / (PS + 1);
-        const bool ok = px < PS && py + wr < PS;
-        t[(wr * (PS + 1) + px) * 65 + c] = ok ? gpool[(((size_t)b * PS + py + wr) * PS + px) * C + c] : 0.0f;
+    constexpr int PS = S / 2, HW = S * S;
+    __shared__ float t[(PS * PS + 1) * 17];                              // [pooled pixel][16 channels (+1: bank spread)], + a pixel of zeros
+    const int cg = blockIdx.x & 3;
+    const int64_t b = blockIdx.x >> 2;
+    for (int i = threadIdx.x; i < PS * PS * 16; i += 256) {
+        const int c = i & 15, p = i >> 4;
+        t[p * 17 + c] = gpool[((size_t)b * PS * PS + p) * 64 + 16 * cg + c];
     }
+    if (threadIdx.x < 17) t[PS * PS * 17 + threadIdx.x] = 0.0f;
     __syncthreads();
-    for (int i = threadIdx.x; i < C * 2 * (S / 2); i += 256) {           // (channel, row 0 / 1, pair of columns)
-        const int q = i % (S / 2), yr = (i / (S / 2)) & 1, c = i / S;
-        // even row 2 py: window row py only; odd row 2 py + 1: rows py and py + 1.  Column 2 q: window column q; 2 q + 1: q and q + 1.
-        const float a0 = t[(0 * (PS + 1) + q) * 65 + c] + (yr ? t[(1 * (PS + 1) + q) * 65 + c] : 0.0f);
-        const float a1 = t[(0 * (PS + 1) + q + 1) * 65 + c] + (yr ? t[(1 * (PS + 1) + q + 1) * 65 + c] : 0.0f);
-        *reinterpret_cast<float2 *>(gx + (((size_t)b * C + c) * S + 2 * py + yr) * S + 2 * q) =
-            make_float2(a0 * (1.0f / 9.0f), (a0 + a1) * (1.0f / 9.0f));
+    float *dst = gx + ((size_t)b * 64 + 16 * cg) * HW;
+    for (int i = threadIdx.x; i < 16 * HW / 2; i += 256) {               // (channel, row, pair of columns): consecutive float2
+        const int q = i % (S / 2), r = i / (S / 2), y = r % S, c = r / S;
+        // even row y: window row y / 2 only; odd: (y - 1) / 2 and (y + 1) / 2.  Column 2 q: window column q; 2 q + 1: q and q + 1.
+        const int p0 = y >> 1, p1 = ((y & 1) && p0 + 1 < PS) ? p0 + 1 : -1;
+        const int q1 = q + 1 < PS ? q + 1 : -1;
+        const int Z = PS * PS;                                           // the pixel of zeros
+        const int i00 = p0 * PS + q, i01 = q1 >= 0 ? p0 * PS + q1 : Z, i10 = p1 >= 0 ? p1 * PS + q : Z, i11 = (p1 >= 0 && q1 >= 0) ? p1 * PS + q1 : Z;
+        const float a0 = t[i00 * 17 + c] + t[i10 * 17 + c], a1 = t[i01 * 17 + c] + t[i11 * 17 + c];
+        *reinterpret_cast<float2 *>(dst + 2 * i) = make_float2(a0 * (1.0f / 9.0f), (a0 + a1) * (1.0f / 9.0f));
     }
 }
 
@@ -1242,7 +1245,7 @@ int p7_fwd(const float *x, int64_t B, const float *w, const float *bias, void *s
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace), *sv = reinterpret_cast<unsigned char *>(saved);
     f16 *ph = reinterpret_cast<f16 *>(sv), *pl = reinterpret_cast<f16 *>(sv + align256(B * PS * PS * 128));
     f16 *wh = reinterpret_cast<f16 *>(ws + p.wh), *wl = reinterpret_cast<f16 *>(ws + p.wl);
-    hipLaunchKernelGGL(k_pool_split_cl<S>, dim3((unsigned)(B * PS)), dim3(256), 0, st, x, ph, pl);
+    hipLaunchKernelGGL(k_pool_split_cl<S>, dim3((unsigned)(B * PS)), dim3(256), 0, st, x, ph, pl);   // (a 16-channel-slab form that reads each plane once, contiguously, was 11 % slower: LDS-bound)
     hipLaunchKernelGGL(k_conv7w_fwd_split, dim3(784), dim3(256), 0, st, w, wh, wl);
     if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
     const int rc = gemm<G_CONV7, PS>(ph, pl, wh, wl, bias, 1, B * O * O, 64, 64 * 49, 0, pre, nullptr, nullptr, st);
@@ -1283,7 +1286,7 @@ int p7_bwd(const float *gy, const float *pre, const void *saved, const float *w,
                                     nullptr, nullptr, st, out4, cls);
         }
         if (rc != TRON_OK) return rc;
-        hipLaunchKernelGGL(k_pool_bwd_cl<S>, dim3((unsigned)(B * PS)), dim3(256), 0, st, gpool, gx);
+        hipLaunchKernelGGL(k_pool_bwd_cl<S>, dim3((unsigned)(B * 4)), dim3(256), 0, st, gpool, gx);
         if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
     }
     if (gw) {

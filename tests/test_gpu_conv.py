@@ -571,3 +571,32 @@ def test_gemm_f16x3_matches_float64(fused, M, N, K, ta, tb, magnitude):
     assert (got.double() - want).abs().max().item() / want.abs().max().item() < 2e-6
     assert fused.gemm_f16x3(torch.randn(8, 100, device="cuda"), torch.randn(64, 100, device="cuda")) is None      # K % 64 != 0, not transposed
     assert fused.gemm_f16x3(torch.randn(8, 64, device="cuda"), torch.randn(48, 64, device="cuda")) is None        # N % 64 != 0
+
+
+@pytest.mark.parametrize("magnitude", [1.0, 1e-6])
+@pytest.mark.parametrize("B", [1, 5, 131, 1100])
+@pytest.mark.parametrize("side,cin", [(26, 3), (26, 4), (34, 3), (34, 4)])
+def test_conv1_wgrad_at_24x24_and_32x32_boards(fused, side, cin, B, magnitude):
+    """conv1's weight gradient (3 or 4 planes -> 32) at 26x26 / 34x34 — plain f32 FMAs in tron_conv3x3_wgrad — against float64;
+    1 100: more images than workgroups.  The planes are the observation encoding's values (DQNNet.py:33 on game.py's pop_up)."""
+    torch.manual_seed(B + side + cin)
+    vals = torch.tensor([0.0, 1.0, -1.0, 10.0, -10.0, 0.25], device="cuda")
+    x = vals[torch.randint(0, 6, (B, cin, side, side), device="cuda")].contiguous()
+    gp = torch.randn(B, 32, side, side, device="cuda") * magnitude
+    assert fused.wgrad_supported(torch.empty(32, cin, 3, 3, device="cuda"), side)
+    wd = torch.zeros(32, cin, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+    F.conv2d(x.double(), wd, padding=1).backward(gp.double())
+    got = fused.conv3x3_wgrad(x, gp)
+    assert (got.double() - wd.grad).abs().max().item() / wd.grad.abs().max().item() < 3e-6
+    assert torch.equal(fused.conv3x3_wgrad(x, gp), got)                            # deterministic
+    x = torch.zeros(B, cin, side, side, device="cuda")                             # one-hot: a swapped tap or channel cannot hide
+    gp = torch.zeros(B, 32, side, side, device="cuda")
+    x[:, 0, 0, side - 1] = 1.0
+    x[:, cin - 1, side - 1, 0] = 2.0
+    x[:, 1, 13, 13] = 3.0
+    gp[:, 5, 1, side - 2] = 1.0
+    gp[:, 30, side - 2, 1] = 4.0
+    gp[:, 9, 13, 12] = 2.0
+    wd = torch.zeros(32, cin, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+    F.conv2d(x.double(), wd, padding=1).backward(gp.double())
+    assert torch.equal(fused.conv3x3_wgrad(x, gp).double(), wd.grad)              # small integers: exact
