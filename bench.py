@@ -246,10 +246,10 @@ def dqn_record(envs, width, steps, warmup, batch, repeats, world, rank):
                                  "cores as three MFMAs per f32 product (v = hi + lo 2^-11: csrc/tron_conv_f16.hip, "
                                  "tron_conv_wgrad.hip, tron_head.hip), so the ceiling is the dense f16 peak / 3 (`peak`); "
                                  "f32_matrix_peak is what exact-f32 MFMA arithmetic could reach (the loop runs above it).  "
-                                 "Whole-loop time incl. env step, replay push / sample, optimizer; the four linear layers of "
-                                 "the learner's forward / backward and conv7's dense GEMMs are f32 library GEMMs; per-kernel "
-                                 "HBM rates: profiles/r02_dqn_conv_hbm.json (the conv kernels move 2.2-3.1 TB/s: not "
-                                 "memory-bound)"}}
+                                 "Whole-loop time incl. env step, replay push / sample, optimizer; forward and input gradient of "
+                                 "the learner's four linear layers are f32 library GEMMs (their weight gradients: "
+                                 "tron_linear_wgrad; conv7: tron_gemm_f16x3 on its dense form at 12x12, tron_pool_conv7 at "
+                                 "26x26); per-kernel rows: profiles/r03_learn_*_kernel_rows.txt, r03_infer_*"}}
 
 
 def main():

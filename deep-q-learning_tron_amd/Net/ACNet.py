@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from config import MAP_WIDTH
 from Net.DQNNet import conv7_side
-from Net.activations import (mish as _mish, Conv3x3 as _Conv3x3, pool_s2 as _pool_s2, conv_bias_mish as _conv_bias_mish,
+from Net.activations import (mish as _mish, Conv3x3 as _Conv3x3, Conv7 as _Conv7, pool_s2 as _pool_s2, conv_bias_mish as _conv_bias_mish,
                              pool_conv7_cl_mish as _pool_conv7_cl_mish, pool_conv7_cl_supported as _pool_conv7_cl_supported)
 from Net.kfac import SplitBias as _SplitBias
 
@@ -66,7 +66,7 @@ class Net(nn.Module):
         self.conv5 = _Conv3x3(64, 64, 3, padding=1)
         self.conv6 = _Conv3x3(64, 64, 3, padding=1)
         self.pool = nn.AvgPool2d(kernel_size=3, padding=1, stride=2)
-        self.conv7 = nn.Conv2d(64, 64, 7, padding=3, stride=2)
+        self.conv7 = _Conv7(64, 64, 7, padding=3, stride=2)      # (an nn.Conv2d; tron_conv7_fwd / _bwd at 13x13 / 17x17 pooled planes)
         self.flat = 64 * conv7_side(self.side) ** 2
         self.fc1 = nn.Linear(self.flat, 256)
 

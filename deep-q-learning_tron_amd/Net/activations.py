@@ -466,6 +466,69 @@ class _PoolConv7CL(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _Conv7HIP(torch.autograd.Function):
+    """conv7(x) (+ bias) alone — 64 -> 64, 7x7 / stride 2 / pad 3 on 13x13 or 17x17 planes, no activation — on tron_conv7_fwd / _bwd
+    (the kernels of _PoolConv7CL with NCHW tensors on both sides), for the module the K-FAC hooks sit on (kfac.py:156-189)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from tron import _native as nat
+        L = nat.lib()
+        B, ps = x.shape[0], x.shape[-1]
+        o = (ps + 1) // 2
+        dev = x.device
+        with torch.cuda.device(dev):
+            saved = torch.empty(int(L.tron_pool_conv7_saved_bytes(B, 2 * ps)), dtype=torch.uint8, device=dev)
+            ws = torch.empty(int(L.tron_pool_conv7_workspace(B, 2 * ps)), dtype=torch.uint8, device=dev)
+            y = torch.empty(B, 64, o, o, dtype=torch.float32, device=dev)
+            nat.check(L.tron_conv7_fwd(nat.ptr(x), B, ps, nat.ptr(weight), nat.ptr(bias), nat.ptr(saved), nat.ptr(y), nat.ptr(ws),
+                                       nat.stream_ptr()), "tron_conv7_fwd")
+        ctx.save_for_backward(saved, weight)
+        ctx.geometry = (B, ps)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from tron import _native as nat
+        L = nat.lib()
+        saved, weight = ctx.saved_tensors
+        B, ps = ctx.geometry
+        g = grad_out.contiguous()
+        if not _aligned16(g):
+            g = g.clone(memory_format=torch.contiguous_format)
+        dev = g.device
+        gx = gw = gb = None
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty(B, 64, ps, ps, dtype=torch.float32, device=dev)
+            if ctx.needs_input_grad[1] and not skip_weight_gradients:
+                gw = torch.empty_like(weight)
+            if ctx.needs_input_grad[2]:
+                gb = torch.empty(64, dtype=torch.float32, device=dev)
+            ws = torch.empty(int(L.tron_pool_conv7_workspace(B, 2 * ps)), dtype=torch.uint8, device=dev)
+            nat.check(L.tron_conv7_bwd(nat.ptr(g), nat.ptr(saved), nat.ptr(weight), B, ps, nat.ptr(gx), nat.ptr(gw), nat.ptr(gb), nat.ptr(ws),
+                                       nat.stream_ptr()), "tron_conv7_bwd")
+        return gx, gw, gb
+
+
+class Conv7(torch.nn.Conv2d):
+    """nn.Conv2d(64, 64, 7, padding=3, stride=2) whose forward runs on the hand-written kernels where they cover the shape (f32 CUDA
+    planes of side 13 / 17: 24x24 and 32x32 boards) and on the library otherwise.  Same parameters and state_dict keys, still an
+    nn.Conv2d for KFACOptimizer's hooks and factor shapes."""
+
+    def forward(self, x):
+        if (_use_pool_conv7_cl and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] == x.shape[-2]
+                and x.shape[-1] in (13, 17) and 0 < x.shape[0] <= (1 << 20) and x.shape[1] == 64 and self.in_channels == 64
+                and self.out_channels == 64 and self.kernel_size == (7, 7) and self.stride == (2, 2) and self.padding == (3, 3)
+                and self.dilation == (1, 1) and self.groups == 1 and self.weight.dtype == torch.float32 and self.weight.is_contiguous()):
+            from Net import fused
+            if fused.default_math == "f16x3":
+                x = x.contiguous()
+                if _aligned16(x):
+                    return _Conv7HIP.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 class _LinearHIP(torch.autograd.Function):
     """F.linear whose weight and bias gradients come from one launch pair of csrc/tron_dqn.hip (tron_linear_wgrad: the batch
     split over workgroups) — the library's kernels for these small outputs over a batch of 4 096 run on 1 to 144 workgroups,

@@ -780,12 +780,12 @@ __global__ void k_conv7w_fwd_split(const float *__restrict__ w, f16 *__restrict_
 // y[b][co * OPIX + p] = mish(pre[b][p][co]): conv7's pre-activation rows (the CONV7 GEMM's output order) -> the flattened NCHW
 // activation fc1 reads (DQNNet.py:55: x.view(-1, 64 * 7 * 7)).  One image per workgroup pass, through LDS.
 template <int OPIX>
-__global__ __launch_bounds__(256) void k_mish_cl_to_nchw(const float *__restrict__ pre, float *__restrict__ y, int B)
+__global__ __launch_bounds__(256) void k_mish_cl_to_nchw(const float *__restrict__ pre, float *__restrict__ y, int B, int act)
 {
     __shared__ float t[OPIX * 65];
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const float *src = pre + (size_t)b * OPIX * 64;
-        for (int i = threadIdx.x; i < OPIX * 64; i += 256) t[(i >> 6) * 65 + (i & 63)] = mish1(src[i]);
+        for (int i = threadIdx.x; i < OPIX * 64; i += 256) t[(i >> 6) * 65 + (i & 63)] = act ? mish1(src[i]) : src[i];
         __syncthreads();
         float *dst = y + (size_t)b * OPIX * 64;
         for (int i = threadIdx.x; i < OPIX * 64; i += 256) {
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(256) void k_mish_bwd_to_cl(const float *__restrict_
         __syncthreads();
         const float *pr = pre + (size_t)b * OPIX * 64;
         for (int i = threadIdx.x; i < OPIX * 64; i += 256) {            // i & 63 == co for every i of this thread
-            const float g = t[(i >> 6) * 65 + co] * mish_grad1(pr[i]);
+            const float g = pre ? t[(i >> 6) * 65 + co] * mish_grad1(pr[i]) : t[(i >> 6) * 65 + co];   // (pre == NULL: no activation behind the convolution)
             sum += g;
             f16 h, l;
             split(g * sc, h, l);
@@ -891,6 +891,51 @@ __global__ __launch_bounds__(256) void k_pool_bwd_cl(const float *__restrict__ g
         const int i00 = p0 * PS + q, i01 = q1 >= 0 ? p0 * PS + q1 : Z, i10 = p1 >= 0 ? p1 * PS + q : Z, i11 = (p1 >= 0 && q1 >= 0) ? p1 * PS + q1 : Z;
         const float a0 = t[i00 * 17 + c] + t[i10 * 17 + c], a1 = t[i01 * 17 + c] + t[i11 * 17 + c];
         *reinterpret_cast<float2 *>(dst + 2 * i) = make_float2(a0 * (1.0f / 9.0f), (a0 + a1) * (1.0f / 9.0f));
+    }
+}
+
+// The convolution alone (tron_conv7_fwd / _bwd: the module the K-FAC hooks sit on takes and returns NCHW tensors): pooled planes
+// f32 [B][64][PIX] -> the channels-last split image [B][PIX][64] (pre-scaled by 2^-6), and a channels-last f32 gradient back to
+// NCHW.  One workgroup = 16 channels of one image, through LDS: contiguous on the NCHW side, 32- / 64-byte pieces on the other.
+template <int PIX>
+__global__ __launch_bounds__(256) void k_nchw_to_cl_split(const float *__restrict__ x, f16 *__restrict__ oh, f16 *__restrict__ ol)
+{
+    __shared__ float t[16 * (PIX + 1)];
+    const int cg = blockIdx.x & 3;
+    const int64_t b = blockIdx.x >> 2;
+    const float *src = x + ((size_t)b * 64 + 16 * cg) * PIX;
+    for (int i = threadIdx.x; i < 16 * PIX; i += 256) {
+        const int c = i / PIX, p = i - c * PIX;
+        t[c * (PIX + 1) + p] = src[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * PIX; i += 256) {
+        const int oct = i & 1, p = i >> 1;
+        f16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f16 hh, ll;
+            split(t[(oct * 8 + j) * (PIX + 1) + p] * ACT_SCALE, hh, ll);
+            h[j] = hh;
+            l[j] = ll;
+        }
+        const size_t o = ((size_t)b * PIX + p) * 64 + 16 * cg + 8 * oct;
+        *reinterpret_cast<f16x8 *>(oh + o) = h;
+        *reinterpret_cast<f16x8 *>(ol + o) = l;
+    }
+}
+template <int PIX>
+__global__ __launch_bounds__(256) void k_cl_to_nchw(const float *__restrict__ g, float *__restrict__ out)
+{
+    __shared__ float t[PIX * 17];
+    const int cg = blockIdx.x & 3;
+    const int64_t b = blockIdx.x >> 2;
+    for (int i = threadIdx.x; i < PIX * 16; i += 256) t[(i >> 4) * 17 + (i & 15)] = g[((size_t)b * PIX + (i >> 4)) * 64 + 16 * cg + (i & 15)];
+    __syncthreads();
+    float *dst = out + ((size_t)b * 64 + 16 * cg) * PIX;
+    for (int i = threadIdx.x; i < 16 * PIX; i += 256) {
+        const int c = i / PIX, p = i - c * PIX;
+        dst[i] = t[p * 17 + c];
     }
 }
 
@@ -1218,7 +1263,7 @@ extern "C" int tron_dqn_head_fwd_px16(const void *trunk_px16, int64_t batch, int
 // everything on this file's kernels, forward and backward (Net/activations.py::_PoolConv7CL) --------------------------------
 namespace {
 struct P7Plan {
-    int64_t out4, gph, gpl, wh, wl, gpool, bpart, wpart, total;
+    int64_t out4, gph, gpl, wh, wl, gpool, bpart, wpart, pre, total;
 };
 P7Plan p7_plan(int64_t B, int PS)
 {
@@ -1232,12 +1277,14 @@ P7Plan p7_plan(int64_t B, int PS)
     p.gpool = take(B * PS * PS * 256);
     p.bpart = take(1024ll * 64 * 4);
     p.wpart = take((int64_t)W7_SLICES * 49 * 4096 * 4);
+    p.pre = take(B * O * O * 256);                                       // (tron_conv7_fwd's channels-last output before the transpose)
     p.total = o;
     return p;
 }
 inline bool p7_side_ok(int32_t side) { return side == 26 || side == 34; }
 
-template <int S>
+// CONVONLY: x is the pooled planes f32 [B][64][PS][PS], y the convolution's output f32 [B][64][O][O] (+ bias, no activation)
+template <int S, bool CONVONLY>
 int p7_fwd(const float *x, int64_t B, const float *w, const float *bias, void *saved, float *pre, float *y, void *workspace, hipStream_t st)
 {
     constexpr int PS = S / 2, O = (PS + 1) / 2;
@@ -1245,16 +1292,21 @@ int p7_fwd(const float *x, int64_t B, const float *w, const float *bias, void *s
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace), *sv = reinterpret_cast<unsigned char *>(saved);
     f16 *ph = reinterpret_cast<f16 *>(sv), *pl = reinterpret_cast<f16 *>(sv + align256(B * PS * PS * 128));
     f16 *wh = reinterpret_cast<f16 *>(ws + p.wh), *wl = reinterpret_cast<f16 *>(ws + p.wl);
-    hipLaunchKernelGGL(k_pool_split_cl<S>, dim3((unsigned)(B * PS)), dim3(256), 0, st, x, ph, pl);   // (a 16-channel-slab form that reads each plane once, contiguously, was 11 % slower: LDS-bound)
+    if (CONVONLY) {
+        pre = reinterpret_cast<float *>(ws + p.pre);
+        hipLaunchKernelGGL(k_nchw_to_cl_split<PS * PS>, dim3((unsigned)(B * 4)), dim3(256), 0, st, x, ph, pl);
+    } else {
+        hipLaunchKernelGGL(k_pool_split_cl<S>, dim3((unsigned)(B * PS)), dim3(256), 0, st, x, ph, pl);   // (a 16-channel-slab form that reads each plane once, contiguously, was 11 % slower: LDS-bound)
+    }
     hipLaunchKernelGGL(k_conv7w_fwd_split, dim3(784), dim3(256), 0, st, w, wh, wl);
     if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
     const int rc = gemm<G_CONV7, PS>(ph, pl, wh, wl, bias, 1, B * O * O, 64, 64 * 49, 0, pre, nullptr, nullptr, st);
     if (rc != TRON_OK) return rc;
-    hipLaunchKernelGGL(k_mish_cl_to_nchw<O * O>, dim3((unsigned)(B < 4096 ? B : 4096)), dim3(256), 0, st, pre, y, (int)B);
+    hipLaunchKernelGGL(k_mish_cl_to_nchw<O * O>, dim3((unsigned)(B < 4096 ? B : 4096)), dim3(256), 0, st, pre, y, (int)B, CONVONLY ? 0 : 1);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
-template <int S>
+template <int S, bool CONVONLY>
 int p7_bwd(const float *gy, const float *pre, const void *saved, const float *w, int64_t B, float *gx, float *gw, float *gb, void *workspace,
            hipStream_t st)
 {
@@ -1286,7 +1338,8 @@ int p7_bwd(const float *gy, const float *pre, const void *saved, const float *w,
                                     nullptr, nullptr, st, out4, cls);
         }
         if (rc != TRON_OK) return rc;
-        hipLaunchKernelGGL(k_pool_bwd_cl<S>, dim3((unsigned)(B * 4)), dim3(256), 0, st, gpool, gx);
+        if (CONVONLY) hipLaunchKernelGGL(k_cl_to_nchw<PS * PS>, dim3((unsigned)(B * 4)), dim3(256), 0, st, gpool, gx);
+        else hipLaunchKernelGGL(k_pool_bwd_cl<S>, dim3((unsigned)(B * 4)), dim3(256), 0, st, gpool, gx);
         if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
     }
     if (gw) {
@@ -1332,7 +1385,8 @@ extern "C" int tron_pool_conv7_fwd(const float *x, int64_t batch, int32_t side, 
     if (batch == 0) return TRON_OK;
     if (!p7_side_ok(side) || batch > (1ll << 20)) return TRON_ERR_UNSUPPORTED;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return side == 26 ? p7_fwd<26>(x, batch, weight, bias, saved, pre, y, workspace, st) : p7_fwd<34>(x, batch, weight, bias, saved, pre, y, workspace, st);
+    return side == 26 ? p7_fwd<26, false>(x, batch, weight, bias, saved, pre, y, workspace, st)
+                      : p7_fwd<34, false>(x, batch, weight, bias, saved, pre, y, workspace, st);
 }
 
 extern "C" int tron_pool_conv7_bwd(const float *grad_y, const float *pre, const void *saved, const float *weight, int64_t batch, int32_t side,
@@ -1349,8 +1403,41 @@ extern "C" int tron_pool_conv7_bwd(const float *grad_y, const float *pre, const 
         if (grad_bias && hipMemsetAsync(grad_bias, 0, 64 * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_LAUNCH; }
         return TRON_OK;
     }
-    return side == 26 ? p7_bwd<26>(grad_y, pre, saved, weight, batch, grad_x, grad_weight, grad_bias, workspace, st)
-                      : p7_bwd<34>(grad_y, pre, saved, weight, batch, grad_x, grad_weight, grad_bias, workspace, st);
+    return side == 26 ? p7_bwd<26, false>(grad_y, pre, saved, weight, batch, grad_x, grad_weight, grad_bias, workspace, st)
+                      : p7_bwd<34, false>(grad_y, pre, saved, weight, batch, grad_x, grad_weight, grad_bias, workspace, st);
+}
+
+// conv7 alone on the same kernels — the nn.Conv2d module itself (Net/activations.py::Conv7), NCHW in and out, for callers that need the
+// layer's input and output as tensors: KFACOptimizer's hooks (kfac.py:156-189) on the actor-critic nets' conv7.
+extern "C" int tron_conv7_fwd(const float *pooled, int64_t batch, int32_t pooled_side, const float *weight, const float *bias, void *saved,
+                              float *y, void *workspace, void *stream)
+{
+    if (!pooled || !weight || !saved || !y || !workspace || batch < 0) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(pooled) | reinterpret_cast<uintptr_t>(saved) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(workspace)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    if (batch == 0) return TRON_OK;
+    if ((pooled_side != 13 && pooled_side != 17) || batch > (1ll << 20)) return TRON_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return pooled_side == 13 ? p7_fwd<26, true>(pooled, batch, weight, bias, saved, nullptr, y, workspace, st)
+                             : p7_fwd<34, true>(pooled, batch, weight, bias, saved, nullptr, y, workspace, st);
+}
+
+extern "C" int tron_conv7_bwd(const float *grad_y, const void *saved, const float *weight, int64_t batch, int32_t pooled_side,
+                              float *grad_pooled, float *grad_weight, float *grad_bias, void *workspace, void *stream)
+{
+    if (!grad_y || !saved || !weight || !workspace || batch < 0) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(saved) | reinterpret_cast<uintptr_t>(grad_pooled) |
+         reinterpret_cast<uintptr_t>(workspace)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    if ((pooled_side != 13 && pooled_side != 17) || batch > (1ll << 20)) return TRON_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (batch == 0) {
+        if (grad_weight && hipMemsetAsync(grad_weight, 0, 49 * 4096 * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_LAUNCH; }
+        if (grad_bias && hipMemsetAsync(grad_bias, 0, 64 * sizeof(float), st) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_LAUNCH; }
+        return TRON_OK;
+    }
+    return pooled_side == 13 ? p7_bwd<26, true>(grad_y, nullptr, saved, weight, batch, grad_pooled, grad_weight, grad_bias, workspace, st)
+                             : p7_bwd<34, true>(grad_y, nullptr, saved, weight, batch, grad_pooled, grad_weight, grad_bias, workspace, st);
 }
 
 // ---- training-path pieces of the same layers (Net/activations.py::_PoolConv7): pooling forward / backward on 12x12

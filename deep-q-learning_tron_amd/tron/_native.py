@@ -101,6 +101,8 @@ SIGNATURES = {
     "tron_pool_conv7_workspace": (C.c_int64, [_i64, _i32]),
     "tron_pool_conv7_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tron_pool_conv7_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "tron_conv7_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tron_conv7_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
 
 MINIMAX = {"voronoi": 0, "distwall": 1}

@@ -484,6 +484,16 @@ int tron_pool_conv7_fwd(const float *x, int64_t batch, int32_t side, const float
                         float *y, void *workspace, void *stream);
 int tron_pool_conv7_bwd(const float *grad_y, const float *pre, const void *saved, const float *weight, int64_t batch, int32_t side,
                         float *grad_x, float *grad_weight, float *grad_bias, void *workspace, void *stream);
+/* conv7 alone on the same kernels, NCHW in and out — the nn.Conv2d module itself, for callers that need the layer's input and
+ * output as tensors: KFACOptimizer's hooks on the actor-critic nets' conv7 (kfac.py:156-189; Net/ACNet.py:68).
+ *   fwd: pooled f32[batch][64][P][P] (P = pooled_side, 13 or 17) -> y f32[batch][64][O][O] = conv7(pooled) + bias (bias may be NULL:
+ *        KFACOptimizer's SplitBias moves it out of the module); `saved` as above (tron_pool_conv7_saved_bytes(batch, 2 P)).
+ *   bwd: grad_y f32[batch][64][O][O] -> grad_pooled f32[batch][64][P][P], grad_weight f32[64][64][7][7], grad_bias f32[64]; each may be NULL.
+ * workspace: tron_pool_conv7_workspace(batch, 2 P) bytes.                                                                  */
+int tron_conv7_fwd(const float *pooled, int64_t batch, int32_t pooled_side, const float *weight, const float *bias, void *saved, float *y,
+                   void *workspace, void *stream);
+int tron_conv7_bwd(const float *grad_y, const void *saved, const float *weight, int64_t batch, int32_t pooled_side, float *grad_pooled,
+                   float *grad_weight, float *grad_bias, void *workspace, void *stream);
 
 /* Wait for `stream` and report what the kernels queued on it did: launch_status-style calls above only
  * see a REJECTED launch; a fault inside a kernel surfaces at the next synchronisation.  Returns TRON_OK

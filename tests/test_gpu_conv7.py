@@ -226,3 +226,61 @@ def test_actor_critic_tail_on_and_off(nat, W, monkeypatch):
     kfac.split_biases(net)                                               # what KFACOptimizer does to the model (kfac.py:79-100)
     value, logits = net(x, prob)                                         # (the SplitBias branch: runs, same numbers)
     assert (value - results[1][0]).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("with_bias", [True, False])
+@pytest.mark.parametrize("ps,B", [(13, 1), (13, 37), (17, 2), (17, 41)])
+def test_conv7_module_matches_float64(nat, ps, B, with_bias):
+    """Net/activations.py::Conv7 — conv7 alone, NCHW in and out (tron_conv7_fwd / _bwd): the module KFACOptimizer hooks at 24x24 /
+    32x32 boards, with its bias (plain A2C fallback) and without (SplitBias moved it out) — output and all gradients vs float64."""
+    from Net.activations import Conv7, _Conv7HIP
+    torch.manual_seed(ps * 100 + B)
+    conv = Conv7(64, 64, 7, padding=3, stride=2, bias=with_bias).cuda()
+    x = (torch.randn(B, 64, ps, ps, device="cuda") * 1.5).requires_grad_(True)
+    y = conv(x)
+    assert y.grad_fn is not None and type(y.grad_fn).__name__ == _Conv7HIP.__name__ + "Backward"
+    o = (ps + 1) // 2
+    assert y.shape == (B, 64, o, o)
+    g = torch.randn_like(y) * 1e-3
+    y.backward(g)
+    xd = x.detach().double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    bd = conv.bias.detach().double().requires_grad_(True) if with_bias else None
+    yd = F.conv2d(xd, wd, bd, stride=2, padding=3)
+    yd.backward(g.double())
+    assert _rel(y.detach(), yd.detach()) < 3e-6
+    assert _rel(x.grad, xd.grad) < 5e-6
+    assert _rel(conv.weight.grad, wd.grad) < 5e-6
+    if with_bias:
+        assert _rel(conv.bias.grad, bd.grad) < 5e-6
+    y2 = conv(x.detach())                                                # no graph: same forward
+    assert torch.equal(y2, y.detach())
+    assert type(conv(x.detach()[:, :, :12, :12].contiguous()).grad_fn).__name__ != "_Conv7HIPBackward"   # other sides: the library
+
+
+def test_kfac_statistics_through_conv7_module(nat, monkeypatch):
+    """K-FAC's factors for conv7 (kfac.py:41-76: input patches' Gram, output gradient's Gram) come from the module's hooks: with the
+    module on tron_conv7 and on the library, the same factors and the same parameter gradients."""
+    from Net import activations, kfac
+    from Net.ACNet import TestNet
+    from tron.vec import pop_up_planes
+    torch.manual_seed(11)
+    W, B = 24, 8
+    S = W + 2
+    vals = torch.tensor([1, -1, -2, -3, 10, -10], dtype=torch.int8, device="cuda")
+    x = pop_up_planes(vals[torch.randint(0, 6, (B, S, S), device="cuda")])
+    prob = torch.rand(B, device="cuda")
+    base = TestNet(W).cuda().eval()
+    out = []
+    for on in (True, False):
+        monkeypatch.setattr(activations, "_use_pool_conv7_cl", on)
+        net = copy.deepcopy(base)
+        opt = kfac.KFACOptimizer(net)
+        opt.acc_stats = True
+        value, logits = net(x, prob)
+        (value.square().mean() + logits.square().mean()).backward()
+        opt.acc_stats = False
+        m = [mod for mod in opt.modules if isinstance(mod, torch.nn.Conv2d) and mod.kernel_size == (7, 7)][0]
+        out.append((opt.m_aa[m].clone(), opt.m_gg[m].clone(), m.weight.grad.clone()))
+    for a, b in zip(out[0], out[1]):
+        assert (a - b).abs().max().item() / (b.abs().max().item() + 1e-30) < 1e-4
