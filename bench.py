@@ -313,7 +313,7 @@ def main():
         ACKTR.train(n_envs=envs, width=width, model="mul", reward="3", iterations=1, acktr=True, log_every=0)   # warm-up (MIOpen find)
         o = ACKTR.train(n_envs=envs, width=width, model="mul", reward="3", iterations=args.acktr_iterations, acktr=True, log_every=0)
         if rank == 0:
-            from Net import fused, kfac
+            from Net import activations, fused, kfac
             net = o["brain"].actor_critic
             conv = net.conv2.module if hasattr(net.conv2, "module") else net.conv2
             side = width + 2
@@ -321,7 +321,9 @@ def main():
                 "trunk_convolutions": ("csrc/tron_conv_f16.hip (forward, input gradient)" if fused.supported(conv, side) else "MIOpen")
                                       + ("; weight gradient csrc/tron_conv_wgrad*.hip" if fused.wgrad_supported(conv.weight, side)
                                          else "; weight gradient MIOpen"),
-                "conv7": "MIOpen", "kfac_factors": "csrc/tron_kfac.hip Gram kernels" if kfac.use_gram else "extract_patches + library GEMM",
+                "conv7": ("csrc/tron_head.hip (tron_conv7_fwd / _bwd)" if (side // 2 in (13, 17) and activations._use_pool_conv7_cl
+                                                                              and fused.default_math == "f16x3") else "MIOpen"),
+                "kfac_factors": "csrc/tron_kfac.hip Gram kernels" if kfac.use_gram else "extract_patches + library GEMM",
                 "bias_residual_activation": "one pass behind each hooked convolution (tron_bias_mish_fwd / _bwd)",
                 "fisher_pass": "statistics only" if o["brain"].fisher_stats_only else "full backward",
                 "eigendecompositions": "torch.linalg.eigh (rocSOLVER)"}
