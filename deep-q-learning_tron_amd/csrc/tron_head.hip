@@ -896,33 +896,35 @@ __global__ __launch_bounds__(256) void k_pool_bwd_cl(const float *__restrict__ g
 
 // The convolution alone (tron_conv7_fwd / _bwd: the module the K-FAC hooks sit on takes and returns NCHW tensors): pooled planes
 // f32 [B][64][PIX] -> the channels-last split image [B][PIX][64] (pre-scaled by 2^-6), and a channels-last f32 gradient back to
-// NCHW.  One workgroup = 16 channels of one image, through LDS: contiguous on the NCHW side, 32- / 64-byte pieces on the other.
+// NCHW, through LDS.
 template <int PIX>
 __global__ __launch_bounds__(256) void k_nchw_to_cl_split(const float *__restrict__ x, f16 *__restrict__ oh, f16 *__restrict__ ol)
 {
-    __shared__ float t[16 * (PIX + 1)];
-    const int cg = blockIdx.x & 3;
-    const int64_t b = blockIdx.x >> 2;
-    const float *src = x + ((size_t)b * 64 + 16 * cg) * PIX;
-    for (int i = threadIdx.x; i < 16 * PIX; i += 256) {
-        const int c = i / PIX, p = i - c * PIX;
-        t[c * (PIX + 1) + p] = src[i];
+    // one workgroup = 32 pixels x all 64 channels: 128-byte reads per channel, one contiguous 4 KB run of whole pixels per half
+    // (a 16-channel slab per workgroup wrote every 128-byte pixel in four pieces at four different times: 0.9 TB/s)
+    constexpr int NBLK = (PIX + 31) / 32;
+    __shared__ float t[64 * 33];
+    const int p0 = ((int)blockIdx.x % NBLK) * 32;
+    const int64_t b = blockIdx.x / NBLK;
+    const float *src = x + (size_t)b * 64 * PIX;
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+        const int c = i >> 5, p = i & 31;
+        t[c * 33 + p] = p0 + p < PIX ? src[c * PIX + p0 + p] : 0.0f;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * PIX; i += 256) {
-        const int oct = i & 1, p = i >> 1;
-        f16x8 h, l;
+    const int oct = threadIdx.x & 7, p = threadIdx.x >> 3;
+    if (p0 + p >= PIX) return;
+    f16x8 h, l;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            f16 hh, ll;
-            split(t[(oct * 8 + j) * (PIX + 1) + p] * ACT_SCALE, hh, ll);
-            h[j] = hh;
-            l[j] = ll;
-        }
-        const size_t o = ((size_t)b * PIX + p) * 64 + 16 * cg + 8 * oct;
-        *reinterpret_cast<f16x8 *>(oh + o) = h;
-        *reinterpret_cast<f16x8 *>(ol + o) = l;
+    for (int j = 0; j < 8; ++j) {
+        f16 hh, ll;
+        split(t[(oct * 8 + j) * 33 + p] * ACT_SCALE, hh, ll);
+        h[j] = hh;
+        l[j] = ll;
     }
+    const size_t o = ((size_t)b * PIX + p0 + p) * 64 + 8 * oct;
+    *reinterpret_cast<f16x8 *>(oh + o) = h;
+    *reinterpret_cast<f16x8 *>(ol + o) = l;
 }
 template <int PIX>
 __global__ __launch_bounds__(256) void k_cl_to_nchw(const float *__restrict__ g, float *__restrict__ out)
@@ -1294,7 +1296,7 @@ int p7_fwd(const float *x, int64_t B, const float *w, const float *bias, void *s
     f16 *wh = reinterpret_cast<f16 *>(ws + p.wh), *wl = reinterpret_cast<f16 *>(ws + p.wl);
     if (CONVONLY) {
         pre = reinterpret_cast<float *>(ws + p.pre);
-        hipLaunchKernelGGL(k_nchw_to_cl_split<PS * PS>, dim3((unsigned)(B * 4)), dim3(256), 0, st, x, ph, pl);
+        hipLaunchKernelGGL(k_nchw_to_cl_split<PS * PS>, dim3((unsigned)(B * ((PS * PS + 31) / 32))), dim3(256), 0, st, x, ph, pl);
     } else {
         hipLaunchKernelGGL(k_pool_split_cl<S>, dim3((unsigned)(B * PS)), dim3(256), 0, st, x, ph, pl);   // (a 16-channel-slab form that reads each plane once, contiguously, was 11 % slower: LDS-bound)
     }
