@@ -171,7 +171,7 @@ class _Conv3x3HIP(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not (skip_weight_gradients and weight.shape[1] >= 16):
             if fused.wgrad_supported(weight, x.shape[-1]):
                 gw = fused.conv3x3_wgrad(x, g, absmax)
-            else:                                             # (34x34: the weight gradient stays on the library)
+            else:                                             # (shapes the weight-gradient kernels do not cover)
                 gw = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [False, True, False])[1]
         if ctx.needs_input_grad[2]:

@@ -307,10 +307,10 @@ def conv3x3_dgrad_mish(gp, weight, absmax, pre_below, extra=None):
 
 
 def wgrad_supported(weight, side):
-    """tron_conv3x3_wgrad's shapes: every layer of the trunk at 12x12; conv2..conv6 at 26x26 (24x24 boards: the
-    row-streaming kernel); conv1 (3 or 4 planes -> 32) at 26x26 and 34x34 (plain f32 FMAs)."""
+    """tron_conv3x3_wgrad's shapes: every layer of the trunk at 12x12; conv2..conv6 at 26x26 and 34x34 (24x24 / 32x32 boards: the
+    row-streaming kernel, a 34-pixel row as two column halves); conv1 (3 or 4 planes -> 32) there as plain f32 FMAs."""
     co, ci = weight.shape[0], weight.shape[1]
-    shape_ok = ((side == 12 and ci in (3, 4, 32, 64)) or (side == 26 and (ci, co) in ((32, 32), (32, 64), (64, 64)))
+    shape_ok = ((side == 12 and ci in (3, 4, 32, 64)) or (side in (26, 34) and (ci, co) in ((32, 32), (32, 64), (64, 64)))
                 or (side in (26, 34) and ci in (3, 4) and co == 32))
     return (shape_ok and co in (32, 64) and tuple(weight.shape[2:]) == (3, 3) and weight.is_cuda
             and weight.dtype == torch.float32)

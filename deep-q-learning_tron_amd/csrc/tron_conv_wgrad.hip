@@ -541,7 +541,7 @@ extern "C" int tron_conv3x3_wgrad(const float *in, const float *grad_pre, const 
          reinterpret_cast<uintptr_t>(grad_weight)) & 15u)
         return TRON_ERR_BAD_ARG;
     const bool small = cin == 3 || cin == 4;
-    const bool rows = side == 26 && (cin == 32 || cin == 64) && (cout == 32 || cout == 64) && !(cin == 64 && cout == 32);
+    const bool rows = (side == 26 || side == 34) && (cin == 32 || cin == 64) && (cout == 32 || cout == 64) && !(cin == 64 && cout == 32);
     const bool small_big = small && cout == 32 && (side == 26 || side == 34);   // conv1 at 24x24 / 32x32 boards: f32 FMAs
     if (!(side == SIDE || rows || small_big) || !(small || cin == 32 || cin == 64) || !(cout == 32 || cout == 64) || batch > (1ll << 24))
         return TRON_ERR_UNSUPPORTED;
@@ -559,7 +559,7 @@ extern "C" int tron_conv3x3_wgrad(const float *in, const float *grad_pre, const 
         grad_absmax = reinterpret_cast<const float *>(ws);
         n_absmax = (int32_t)blocks;
     }
-    if (rows) {                                                          // 24x24 boards: rows streamed through LDS
+    if (rows) {                                                          // 24x24 / 32x32 boards: rows streamed through LDS
         const Plan p = plan(cin, cout);
         const int W = cout * cin * 9;
         float *partial = reinterpret_cast<float *>(ws + p.partial), *stage2 = reinterpret_cast<float *>(ws + p.stage2);

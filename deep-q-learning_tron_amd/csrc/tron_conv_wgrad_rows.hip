@@ -37,16 +37,22 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int ROWEL = 48, ROWB = ROWEL * 2, PADL = 8;                   // an LDS row: 8 zeros, 32 pixels (>= S real), 8 zeros
 constexpr float IN_SCALE = 1.0f / 64.0f, LO_SCALE = 2048.0f;
 
-template <int S_, int CIN_, int COW_>
+template <int S_, int CIN_, int COW_, int HALVES_ = 1>
 struct RCfg {
     static constexpr int S = S_, CIN = CIN_, COW = COW_;                 // COW: output channels per workgroup
+    // HALVES = 2 (34x34: a row does not fit one 32-deep slab): every image is walked twice, once per column half.  Half h takes
+    // the gradient's columns h HW .. h HW + HW - 1 against the input's columns from one to the left of them to one to the right —
+    // both read from column h (HW - 1) on, so that slab position = column - h (HW - 1): the gradient sits at positions h .. h + HW - 1,
+    // the input at 0 .. HW, everything else of the slab is zero.  Same kernel otherwise; 2 (S + 2) steps per image.
+    static constexpr int HALVES = HALVES_, HW = S / HALVES;              // gradient columns per half
+    static constexpr int NPOS = HALVES == 1 ? S : HW + 1;                // slab positions in use (input columns per half)
     static constexpr int NCI = CIN / 16, NCO = COW / 16, WAVES = NCI * NCO, THREADS = 64 * WAVES;
     static constexpr int P = S + 2;                                      // steps per image: input rows -1 .. S
     static constexpr int HS = S / 2;                                     // float pairs per row
     static constexpr int IN_SLOT = CIN * ROWB, IN_HALF = 4 * IN_SLOT;    // ring of four rows
     static constexpr int G_SLOT = COW * ROWB, G_HALF = 3 * 2 * G_SLOT;   // [copy kx][ring of two rows]
     static constexpr int LDS = 2 * IN_HALF + 2 * G_HALF;
-    static_assert(S % 2 == 0 && S <= 32 && (WAVES == 4 || WAVES == 8), "one 32-deep slab per row; 4 or 8 waves");
+    static_assert(S % 2 == 0 && NPOS <= 32 && (HALVES == 1 || HW % 2 == 1) && (WAVES == 4 || WAVES == 8), "one 32-deep slab per (half) row; 4 or 8 waves");
     static_assert(LDS <= 160 * 1024, "LDS");
 };
 
@@ -88,6 +94,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void k_wgrad_rows(const float *__res
     const int nhalves = cout / COW, co0 = ((int)blockIdx.x % nhalves) * COW, wg = (int)blockIdx.x / nhalves;
     const int wgs = (int)gridDim.x / nhalves;
     const int nb = wg < batch ? (batch - wg + wgs - 1) / wgs : 0;       // this workgroup's images: wg, wg + wgs, ...
+    const int nbv = nb * C::HALVES;                                      // ... as (image, column half) pairs
     const int it = wave % C::NCI, ct = wave / C::NCI;                    // this wave's input / output channel tile
 
     for (int i = tid * 16; i < C::LDS; i += THREADS * 16) *reinterpret_cast<f32x4 *>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -102,11 +109,13 @@ __global__ __launch_bounds__(C::THREADS, 2) void k_wgrad_rows(const float *__res
     // pixels of one channel's row (two 8-byte loads; 8-byte LDS stores), a wave-pass is 9 rows x 7 items and is either all
     // input rows or all gradient rows (wave-uniform: the other kind's instructions are skipped, not masked), and the
     // shifted copies are cut from the neighbouring lanes' registers (DPP wave shifts + v_alignbit), not stored piecewise.
-    constexpr int Q = (S + 3) / 4, RPW = 64 / Q;                         // items per row, rows per wave-pass
+    constexpr int Q = (C::NPOS + 3) / 4, RPW = 64 / Q;                   // items per row, rows per wave-pass
+    constexpr int HALVES = C::HALVES, HW = C::HW;
     constexpr int NPI = (CIN + RPW - 1) / RPW, NPG = (COW + RPW - 1) / RPW, NROUND = (NPI + NPG + C::WAVES - 1) / C::WAVES;
     const int rip = lane / Q, q = lane - rip * Q;                        // row within the pass, item within the row
     int st_src[NROUND], st_dst[NROUND];                                  // source offset within the image / LDS offset; -1: nothing
-    float st_m2[NROUND], st_m3[NROUND];                                  // 0 where pixels 4q+2, 4q+3 lie beyond the row
+    // which of an item's four positions 4 q + j carry data: the input's [0, NPOS), the gradient's [h, h + HW) for half h of two,
+    // [0, S) for a whole row (the rest of the slab stays zero); the second 8-byte load is skipped where both its pixels are out
 #pragma unroll
     for (int r = 0; r < NROUND; ++r) {
         const int pidx = wave + r * C::WAVES;
@@ -115,32 +124,37 @@ __global__ __launch_bounds__(C::THREADS, 2) void k_wgrad_rows(const float *__res
         const bool ok = rip < RPW && row < (is_in ? CIN : COW) && pidx < NPI + NPG;
         st_src[r] = ok ? row * S * S + 4 * q : -1;
         st_dst[r] = row * ROWB + (PADL + 4 * q) * 2;
-        st_m2[r] = 4 * q + 2 < S ? 1.0f : 0.0f;
-        st_m3[r] = 4 * q + 3 < S ? 1.0f : 0.0f;
     }
+    auto pos_lo = [&](bool is_in, int half) { return (!is_in && HALVES == 2) ? half : 0; };
+    auto pos_hi = [&](bool is_in, int half) { return HALVES == 1 ? S : (is_in ? HW + 1 : half + HW); };
     float2 pf[NROUND][2];
     // what step u stages: input entry u (image u / P, row u % P - 1) and the gradient row of slab u - 2
+    // (eb, gb count (image, half) pairs: image = eb / HALVES, half = eb % HALVES)
     auto load = [&](int eb, int er, int gb, int gy) {
-        const bool in_ok = eb < nb && er >= 0 && er < S, g_ok = gb >= 0 && gb < nb && gy >= 0 && gy < S;
-        const float *in_row = in + ((size_t)(wg + (in_ok ? eb : 0) * wgs) * CIN * S + (in_ok ? er : 0)) * S;
-        const float *g_row = gp + (((size_t)(wg + (g_ok ? gb : 0) * wgs) * cout + co0) * S + (g_ok ? gy : 0)) * S;
+        const bool in_ok = eb < nbv && er >= 0 && er < S, g_ok = gb >= 0 && gb < nbv && gy >= 0 && gy < S;
+        const int ie = in_ok ? eb / HALVES : 0, ih = in_ok ? eb % HALVES : 0, ge = g_ok ? gb / HALVES : 0, gh = g_ok ? gb % HALVES : 0;
+        const float *in_row = in + ((size_t)(wg + ie * wgs) * CIN * S + (in_ok ? er : 0)) * S + ih * (HW - 1);
+        const float *g_row = gp + (((size_t)(wg + ge * wgs) * cout + co0) * S + (g_ok ? gy : 0)) * S + gh * (HW - 1);
 #pragma unroll
         for (int r = 0; r < NROUND; ++r) {
             const int pidx = wave + r * C::WAVES;
             if (pidx >= NPI + NPG) continue;                             // (wave-uniform)
-            const float *src = (pidx < NPI ? in_row : g_row) + (st_src[r] >= 0 ? st_src[r] : 0);
+            const bool is_in = pidx < NPI;
+            const float *src = (is_in ? in_row : g_row) + (st_src[r] >= 0 ? st_src[r] : 0);
             pf[r][0] = *reinterpret_cast<const float2 *>(src);
-            pf[r][1] = *reinterpret_cast<const float2 *>(st_m2[r] != 0.0f ? src + 2 : src);   // (never past the tensor)
+            pf[r][1] = *reinterpret_cast<const float2 *>(4 * q + 2 < pos_hi(is_in, is_in ? ih : gh) ? src + 2 : src);   // (never past the row / the tensor)
         }
     };
-    auto store = [&](int slot_in, int slot_g, bool in_ok, bool g_ok) {
+    auto store = [&](int slot_in, int slot_g, bool in_ok, bool g_ok, int in_half, int g_half) {
 #pragma unroll
         for (int r = 0; r < NROUND; ++r) {
             const int pidx = wave + r * C::WAVES;
             if (pidx >= NPI + NPG) continue;
             const bool is_in = pidx < NPI;                               // (wave-uniform)
             const float sc = st_src[r] < 0 ? 0.0f : is_in ? (in_ok ? IN_SCALE : 0.0f) : (g_ok ? gscale : 0.0f);
-            const float v0 = pf[r][0].x * sc, v1 = pf[r][0].y * sc, v2 = pf[r][1].x * (sc * st_m2[r]), v3 = pf[r][1].y * (sc * st_m3[r]);
+            const int lo = pos_lo(is_in, is_in ? in_half : g_half), span = pos_hi(is_in, is_in ? in_half : g_half) - lo;
+            auto at = [&](int j, float v) { return (unsigned)(4 * q + j - lo) < (unsigned)span ? v * sc : 0.0f; };
+            const float v0 = at(0, pf[r][0].x), v1 = at(1, pf[r][0].y), v2 = at(2, pf[r][1].x), v3 = at(3, pf[r][1].y);
             const f16 h0 = (f16)v0, h1 = (f16)v1, h2 = (f16)v2, h3 = (f16)v3;
             const f16 l0 = (f16)((v0 - (float)h0) * LO_SCALE), l1 = (f16)((v1 - (float)h1) * LO_SCALE);
             const f16 l2 = (f16)((v2 - (float)h2) * LO_SCALE), l3 = (f16)((v3 - (float)h3) * LO_SCALE);
@@ -182,14 +196,15 @@ __global__ __launch_bounds__(C::THREADS, 2) void k_wgrad_rows(const float *__res
 
     // (image, index) of the entry staged at step u, and of steps u - 2 (gradient row) and u - 3 (the slab multiplied)
     int eb = 0, ei = 0;
-    const int total = nb * P + 3;
+    const int total = nbv * P + 3;
     load(0, -1, -1, 0);
     for (int u = 0; u < total; ++u) {
         const int u2 = u - 2, u3 = u - 3;
         const int gb = u2 >= 0 ? u2 / P : -1, gy = u2 >= 0 ? u2 - gb * P : 0;
         const int vb = u3 >= 0 ? u3 / P : -1, vy = u3 >= 0 ? u3 - vb * P : 0;
         // 1. this step's rows (loaded during the previous step) into their ring slots
-        if (TRON_WR_ABLATE != 1) store(u & 3, u & 1, eb < nb && ei >= 1 && ei <= S, gb >= 0 && gb < nb && gy < S);
+        if (TRON_WR_ABLATE != 1)
+            store(u & 3, u & 1, eb < nbv && ei >= 1 && ei <= S, gb >= 0 && gb < nbv && gy < S, eb % HALVES, gb >= 0 ? gb % HALVES : 0);
         // 2. the next step's rows: in flight under this step's MFMAs
         {
             int nb_e = eb, ni = ei + 1;
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void k_wgrad_rows(const float *__res
             ei = ni;
         }
         // 3. the slab staged three steps ago: g row vy of image vb (ring slot of step u - 1) x input entries u-3, u-2, u-1
-        if (vb >= 0 && vb < nb && vy < S && TRON_WR_ABLATE != 2) {
+        if (vb >= 0 && vb < nbv && vy < S && TRON_WR_ABLATE != 2) {
             const int gs = (u - 1) & 1;
             f16x8 ah[3], al[3], bh[3], bl[3];
 #pragma unroll
@@ -270,6 +285,12 @@ int launch_rows(const float *in, const float *gp, const float *absmax, int n_abs
 int tron_wgrad_rows(const float *in, const float *gp, const float *absmax, int n_absmax, float *partial, int64_t batch, int cin,
                     int cout, int side, int grid_max, int *nparts, hipStream_t st)
 {
+    if (side == 34) {                                                    // 32x32 boards: two column halves per row
+        if (cin == 64 && cout == 64) return launch_rows<RCfg<34, 64, 32, 2>>(in, gp, absmax, n_absmax, partial, batch, cout, grid_max, nparts, st);
+        if (cin == 32 && cout == 64) return launch_rows<RCfg<34, 32, 64, 2>>(in, gp, absmax, n_absmax, partial, batch, cout, grid_max, nparts, st);
+        if (cin == 32 && cout == 32) return launch_rows<RCfg<34, 32, 32, 2>>(in, gp, absmax, n_absmax, partial, batch, cout, grid_max, nparts, st);
+        return TRON_ERR_UNSUPPORTED;
+    }
     if (side != 26) return TRON_ERR_UNSUPPORTED;
     if (cin == 64 && cout == 64) return launch_rows<RCfg<26, 64, 32>>(in, gp, absmax, n_absmax, partial, batch, cout, grid_max, nparts, st);
     if (cin == 32 && cout == 64) return launch_rows<RCfg<26, 32, 64>>(in, gp, absmax, n_absmax, partial, batch, cout, grid_max, nparts, st);

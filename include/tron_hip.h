@@ -401,8 +401,8 @@ int tron_px16_to_f32(const void *in_px16, float *out, int64_t batch, int32_t cha
  * tron_bias_mish_bwd writes).  Split-f16 matrix-core arithmetic (TRON_CONV_F16X3's), f32 accumulation, sums in a fixed
  * order (deterministic).  grad_absmax: n_absmax per-block maxima of |grad_pre| on the device (tron_bias_mish_bwd leaves
  * them in its scratch) used to scale the gradient into f16's normal range, or NULL: a pre-pass finds the maximum.
- * Supported: side 12 with cin 3, 4, 32 or 64 and cout 32 or 64; side 26 (24x24 boards) with (cin, cout) in {(32,32), (32,64),
- * (64,64)}; side 26 or 34 with cin 3 or 4 and cout 32 (conv1 there: plain f32 FMAs, grad_absmax unused); anything else
+ * Supported: side 12 with cin 3, 4, 32 or 64 and cout 32 or 64; side 26 or 34 (24x24 / 32x32 boards) with (cin, cout) in {(32,32),
+ * (32,64), (64,64)}; side 26 or 34 with cin 3 or 4 and cout 32 (conv1 there: plain f32 FMAs, grad_absmax unused); anything else
  * TRON_ERR_UNSUPPORTED.  workspace: at least
  * tron_conv3x3_wgrad_workspace(cin, cout) bytes; all buffers 16-byte aligned.                                    */
 int tron_conv3x3_wgrad(const float *in, const float *grad_pre, const float *grad_absmax, int32_t n_absmax,

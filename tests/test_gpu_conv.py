@@ -314,7 +314,7 @@ def test_conv3x3_wgrad_zero_gradient_and_bad_args(fused):
     gw = torch.empty(32, 32, 3, 3, device="cuda")
     ws = torch.empty(int(L.tron_conv3x3_wgrad_workspace(32, 32)), dtype=torch.uint8, device="cuda")
     a = (x.data_ptr(), gp.data_ptr(), None, 0, gw.data_ptr(), 5)
-    assert L.tron_conv3x3_wgrad(*a, 32, 32, 34, ws.data_ptr(), None) == nat.ERR_UNSUPPORTED
+    assert L.tron_conv3x3_wgrad(*a, 32, 32, 30, ws.data_ptr(), None) == nat.ERR_UNSUPPORTED
     assert L.tron_conv3x3_wgrad(*a, 64, 32, 26, ws.data_ptr(), None) == nat.ERR_UNSUPPORTED
     assert L.tron_conv3x3_wgrad(*a, 48, 32, 12, ws.data_ptr(), None) == nat.ERR_UNSUPPORTED
     assert L.tron_conv3x3_wgrad(*a, 32, 32, 12, None, None) == nat.ERR_BAD_ARG
@@ -459,14 +459,16 @@ def test_conv1_input_gradient_falls_back_to_the_library(fused, cin):
 @pytest.mark.parametrize("magnitude", [1.0, 1e-6])
 @pytest.mark.parametrize("B", [1, 2, 5, 131, 300])
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64)])
-def test_conv3x3_wgrad_26_matches_float64(fused, cin, cout, B, magnitude):
-    """tron_conv3x3_wgrad at 26x26 (24x24 boards: csrc/tron_conv_wgrad_rows.hip, image rows streamed through LDS) against
-    the float64 weight gradient of F.conv2d; ragged batches (fewer images than workgroups, several per workgroup)."""
-    torch.manual_seed(B * 17 + cin + cout)
-    x = torch.randn(B, cin, 26, 26, device="cuda")
-    gp = torch.randn(B, cout, 26, 26, device="cuda") * magnitude
+@pytest.mark.parametrize("S", [26, 34])
+def test_conv3x3_wgrad_26_matches_float64(fused, S, cin, cout, B, magnitude):
+    """tron_conv3x3_wgrad at 26x26 and 34x34 (24x24 / 32x32 boards: csrc/tron_conv_wgrad_rows.hip, image rows streamed through LDS,
+    a 34-pixel row as two column halves) against the float64 weight gradient of F.conv2d; ragged batches (fewer images than
+    workgroups, several per workgroup)."""
+    torch.manual_seed(B * 17 + cin + cout + S)
+    x = torch.randn(B, cin, S, S, device="cuda")
+    gp = torch.randn(B, cout, S, S, device="cuda") * magnitude
     gp[0, 0, 0, 0] = 0.0
-    assert fused.wgrad_supported(torch.empty(cout, cin, 3, 3, device="cuda"), 26)
+    assert fused.wgrad_supported(torch.empty(cout, cin, 3, 3, device="cuda"), S)
     wd = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
     F.conv2d(x.double(), wd, padding=1).backward(gp.double())
     ref = wd.grad
@@ -477,14 +479,19 @@ def test_conv3x3_wgrad_26_matches_float64(fused, cin, cout, B, magnitude):
         assert err < 2e-6, (err, absmax is None)
     assert torch.equal(fused.conv3x3_wgrad(x, gp, blocks), got)                    # deterministic
     # one-hot / asymmetric data: a swapped tap or channel cannot hide
-    x = torch.zeros(B, cin, 26, 26, device="cuda")
-    gp = torch.zeros(B, cout, 26, 26, device="cuda")
-    x[:, 3, 0, 25] = 1.0
-    x[:, cin - 1, 25, 0] = 2.0
+    x = torch.zeros(B, cin, S, S, device="cuda")
+    gp = torch.zeros(B, cout, S, S, device="cuda")
+    x[:, 3, 0, S - 1] = 1.0
+    x[:, cin - 1, S - 1, 0] = 2.0
     x[:, 7, 13, 13] = 3.0
-    gp[:, 5, 1, 24] = 1.0
-    gp[:, cout - 2, 24, 1] = 4.0
+    x[:, 11, 20, S // 2] = 5.0                                                     # (34: both sides of the seam between the column halves)
+    x[:, 12, 21, S // 2 - 1] = 6.0
+    gp[:, 5, 1, S - 2] = 1.0
+    gp[:, cout - 2, S - 2, 1] = 4.0
     gp[:, 9, 13, 12] = 2.0
+    gp[:, 3, 20, S // 2 - 1] = 7.0
+    gp[:, 4, 21, S // 2] = 8.0
+    gp[:, 6, 20, S // 2] = 1.0
     wd = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
     F.conv2d(x.double(), wd, padding=1).backward(gp.double())
     assert torch.equal(fused.conv3x3_wgrad(x, gp).double(), wd.grad)              # small integers: exact
