@@ -290,3 +290,23 @@ def test_load_player_dqn_from_kfac_layout_runs(tmp_path):
     got = play.load_player(str(path), "dqn", 10, device="cpu")
     x = torch.randn(3, 3, 12, 12)
     assert torch.allclose(got(x), net.eval()(x))
+
+
+def test_conv_modules_are_plain_conv2d_off_the_gpu():
+    """Net/activations.py::Conv3x3 / Conv7 are nn.Conv2d subclasses whose HIP paths apply to f32 CUDA tensors of the covered sides
+    only: on the CPU (and for any other shape) they are the library convolution, with the reference's state_dict keys
+    (Net/ACNet.py:59-70) — what keeps `.bak` checkpoints interchangeable."""
+    import torch
+    from Net.ACNet import TestNet
+    from Net.activations import Conv3x3, Conv7
+    torch.manual_seed(0)
+    net = TestNet(24)
+    assert isinstance(net.conv7, Conv7) and isinstance(net.conv7, torch.nn.Conv2d) and isinstance(net.conv2, Conv3x3)
+    keys = set(net.state_dict().keys())
+    assert {"conv7.weight", "conv7.bias", "conv2.weight", "conv2.bias"} <= keys and not any("module" in k for k in keys)
+    x = torch.randn(3, 64, 13, 13)
+    want = torch.nn.functional.conv2d(x, net.conv7.weight, net.conv7.bias, stride=2, padding=3)
+    assert torch.equal(net.conv7(x), want)
+    plain = torch.nn.Conv2d(64, 64, 7, padding=3, stride=2)
+    plain.load_state_dict(net.conv7.state_dict())                       # same parameter names and shapes
+    assert torch.equal(plain(x), want)
