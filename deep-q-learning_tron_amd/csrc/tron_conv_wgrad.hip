@@ -357,21 +357,27 @@ __global__ __launch_bounds__(THREADS, 1) void k_wgrad(const float *__restrict__ 
     }
 }
 
-// sums of the per-workgroup partial gradients in a fixed order: stage 1 adds STAGE2 interleaved subsets, stage 2 those
-__global__ void k_wgrad_reduce(const float *__restrict__ partial, int nparts, int stride, int W, float *__restrict__ out)
+// sums of the per-workgroup partial gradients in a fixed order, one launch: a workgroup = 32 outputs x the STAGE2 = 8 interleaved
+// subsets of the partials (subset y = partials y, y + 8, ...); thread (output, subset) adds its subset on eight independent chains
+// (a single chain is nparts / 8 dependent load -> add steps: 33 us for conv1's 1 024 partials), joined in a fixed order; the eight
+// subset sums meet in LDS and are joined in the same fixed order.  (Two launches before: subsets, then their sum.)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, int nparts, int W, float *__restrict__ out)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W) return;
-    // eight independent chains (a single one is nparts / stride dependent load -> add steps: 33 us for conv1's 1 024 partials),
-    // joined in a fixed order
+    __shared__ float sub[STAGE2][32];
+    const int il = threadIdx.x & 31, y = threadIdx.x >> 5, i = blockIdx.x * 32 + il;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int p = blockIdx.y;
-    for (; p + 7 * stride < nparts; p += 8 * stride) {
+    if (i < W) {
+        int p = y;
+        for (; p + 7 * STAGE2 < nparts; p += 8 * STAGE2) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] += partial[(size_t)(p + k * stride) * W + i];
+            for (int k = 0; k < 8; ++k) s[k] += partial[(size_t)(p + k * STAGE2) * W + i];
+        }
+        for (int k = 0; p < nparts; p += STAGE2, ++k) s[k] += partial[(size_t)p * W + i];
     }
-    for (int k = 0; p < nparts; p += stride, ++k) s[k] += partial[(size_t)p * W + i];
-    out[(size_t)blockIdx.y * W + i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    sub[y][il] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (y == 0 && i < W)
+        out[i] = ((sub[0][il] + sub[1][il]) + (sub[2][il] + sub[3][il])) + ((sub[4][il] + sub[5][il]) + (sub[6][il] + sub[7][il]));
 }
 
 __global__ __launch_bounds__(256) void k_absmax(const float *__restrict__ x, size_t n4, float *__restrict__ out)
@@ -420,12 +426,11 @@ int launch(const float *in, const float *gp, const float *absmax, int n_absmax, 
     const Plan p = plan(cin, cout);
     const int nrounds = (int)((batch + IMGS - 1) / IMGS);
     const int wgs = nrounds < GRID_MAX / nhalves ? nrounds : GRID_MAX / nhalves;   // workgroups per output half
-    float *partial = reinterpret_cast<float *>(ws + p.partial), *stage2 = reinterpret_cast<float *>(ws + p.stage2);
+    float *partial = reinterpret_cast<float *>(ws + p.partial);
     hipLaunchKernelGGL(kern, dim3(wgs * nhalves), dim3(THREADS), C::LDS_ALL, st, in, gp, absmax, n_absmax, partial, (int)batch, cin,
                        cout, nrounds);
     const int nparts = wgs * C::KSPLIT;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 255) / 256, STAGE2), dim3(256), 0, st, partial, nparts, STAGE2, W, stage2);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 255) / 256, 1), dim3(256), 0, st, stage2, STAGE2, 1, W, grad_w);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 31) / 32), dim3(256), 0, st, partial, nparts, W, grad_w);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
@@ -505,11 +510,10 @@ int launch_small(const float *in, const float *gp, float *grad_w, int64_t batch,
 {
     const Plan p = plan(CIN, 32);
     constexpr int W = 32 * CIN * 9;
-    float *partial = reinterpret_cast<float *>(ws + p.partial), *stage2 = reinterpret_cast<float *>(ws + p.stage2);
+    float *partial = reinterpret_cast<float *>(ws + p.partial);
     const int grid = (int)(batch < 3 * GRID_MAX ? batch : 3 * GRID_MAX);   // three resident workgroups per CU (138 - 170 VGPRs): one round.  (plan(): room for 4 GRID_MAX partial rows at cin <= 16)
     hipLaunchKernelGGL((k_wgrad_small<S, CIN>), dim3((unsigned)grid), dim3(256), 0, st, in, gp, partial, (int)batch);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 255) / 256, STAGE2), dim3(256), 0, st, partial, grid, STAGE2, W, stage2);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 255) / 256, 1), dim3(256), 0, st, stage2, STAGE2, 1, W, grad_w);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 31) / 32), dim3(256), 0, st, partial, grid, W, grad_w);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
@@ -562,12 +566,11 @@ extern "C" int tron_conv3x3_wgrad(const float *in, const float *grad_pre, const 
     if (rows) {                                                          // 24x24 / 32x32 boards: rows streamed through LDS
         const Plan p = plan(cin, cout);
         const int W = cout * cin * 9;
-        float *partial = reinterpret_cast<float *>(ws + p.partial), *stage2 = reinterpret_cast<float *>(ws + p.stage2);
+        float *partial = reinterpret_cast<float *>(ws + p.partial);
         int nparts = 0;
         const int rc = tron_wgrad_rows(in, grad_pre, grad_absmax, n_absmax, partial, batch, cin, cout, side, GRID_MAX, &nparts, st);
         if (rc != TRON_OK) return rc;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 255) / 256, STAGE2), dim3(256), 0, st, partial, nparts, STAGE2, W, stage2);
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 255) / 256, 1), dim3(256), 0, st, stage2, STAGE2, 1, W, grad_weight);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((W + 31) / 32), dim3(256), 0, st, partial, nparts, W, grad_weight);
         return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
     }
     if (small) return launch<1, 2>(in, grad_pre, grad_absmax, n_absmax, grad_weight, batch, cin, cout, ws, st);
