@@ -15,6 +15,15 @@
 //     k_q_head          actor2 (64 -> 4) in f32 + argmax
 // GEMM tile: 128 x 64 per 8-wave workgroup (wave = 32 x 32 = 2 x 2 MFMA tiles), K in chunks of 64 staged by 16-byte
 // copies into single-buffered LDS (60 KB: two workgroups share a CU and cover each other's barriers).
+//
+// The same layers on the TRAINING path (loss.backward() through them, DDQN.py:148):
+//     12x12:           tron_pool12 / tron_conv7_dense around tron_gemm_f16x3 (conv7's dense form: three plain GEMMs)
+//     26x26 / 34x34:   tron_pool_conv7_fwd / _bwd — the pooled planes kept channels-last and split; forward = the CONV7 implicit
+//                      GEMM; input gradient = four DGRAD7 implicit GEMMs (one per parity class of the pooled pixel: a stride-2
+//                      convolution's taps split by parity) + k_pool_bwd_cl; weight gradient = k_conv7_wgrad (both operands are
+//                      channels-last, i.e. the product runs over their SLOW index: ds_read_b64_tr_b16 reads them transposed out
+//                      of LDS, the reads' row addresses do the stride-2 im2col, LDS-DMA stages an image under the previous one's
+//                      MFMAs); tron_conv7_fwd / _bwd — conv7 alone, NCHW in and out, for the module K-FAC hooks.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
