@@ -287,3 +287,38 @@ def test_acktr_update_fixture_on_gpu(fused, tag, mode):
                 ref = g[f"{tag}_{key}_{mn}"]
                 assert np.allclose(got, ref, rtol=1e-4, atol=1e-7 + 1e-4 * np.abs(ref).max()), (mn, key)
         assert brain.optimizer.steps == 2
+
+
+def test_config5_micro_batch_gradients_at_34x34(fused):
+    """ACKTR's micro-batch at BASELINE config 5 (8 192 samples of 34x34; ACKTR.py:88-159 through Net/ACNet.py:59-76): the 64 -> 64
+    weight gradient on the row-streaming kernel's two-halves form (32 images per workgroup) and conv7 as the module the K-FAC hooks
+    see (tron_conv7_fwd / _bwd on 17x17 pooled planes: 228 images per workgroup slice of its weight-gradient kernel) — against
+    float64, the batch walked in chunks of 512."""
+    from Net.activations import Conv7
+    torch.manual_seed(34)
+    B = 8192
+    x = torch.randn(B, 64, 34, 34, device="cuda")
+    gp = torch.randn(B, 64, 34, 34, device="cuda") / B
+    got = fused.conv3x3_wgrad(x, gp)
+    want = torch.zeros(64, 64, 3, 3, dtype=torch.float64, device="cuda")
+    for i in range(0, B, 512):
+        wd = torch.zeros(64, 64, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+        F.conv2d(x[i:i + 512].double(), wd, padding=1).backward(gp[i:i + 512].double())
+        want += wd.grad
+    assert (got.double() - want).abs().max().item() / want.abs().max().item() < 3e-6
+    del x, gp
+    conv = Conv7(64, 64, 7, padding=3, stride=2, bias=False).cuda()
+    p = (torch.randn(B, 64, 17, 17, device="cuda")).requires_grad_(True)
+    y = conv(p)
+    g = torch.randn_like(y) / B
+    y.backward(g)
+    gw = torch.zeros(64, 64, 7, 7, dtype=torch.float64, device="cuda")
+    for i in range(0, B, 512):
+        pd = p.detach()[i:i + 512].double().requires_grad_(True)
+        wd = conv.weight.detach().double().requires_grad_(True)
+        yd = F.conv2d(pd, wd, stride=2, padding=3)
+        yd.backward(g[i:i + 512].double())
+        assert (y.detach()[i:i + 512].double() - yd.detach()).abs().max().item() / yd.abs().max().item() < 3e-6
+        assert (p.grad[i:i + 512].double() - pd.grad).abs().max().item() / pd.grad.abs().max().item() < 5e-6
+        gw += wd.grad
+    assert (conv.weight.grad.double() - gw).abs().max().item() / gw.abs().max().item() < 5e-6
