@@ -547,6 +547,14 @@ __global__ __launch_bounds__(BLOCK) void k_tile(Params P, int E, uint32_t cpe, u
     tile_step<FMT, DO_STEP, ALIGNED>(P, E, cpe, cpe_magic, actions, uniforms, flags, obs, out, (int)blockIdx.x + tile0, smem);
 }
 
+typedef __attribute__((address_space(4))) const unsigned char kernarg_t;    // the kernel-argument segment (constant address space: scalar loads)
+__device__ __forceinline__ void load_params(Params &p, kernarg_t *q)       // Params is every rollout kernel's first argument
+{
+    // one block copy straight from the constant address space (wide scalar loads).  Measured alternatives, same box: word by
+    // word, or through a generic pointer, the rollout is 8 % SLOWER than with the parameters simply kept live.
+    __builtin_memcpy(&p, q, sizeof(Params));
+}
+
 // persistent rollout on the board-owning layout (every mode / format / side): see k_obs_roll
 template <int FMT, bool ALIGNED>
 __global__ __launch_bounds__(BLOCK) void k_tile_roll(Params P, int E, uint32_t cpe, uint32_t cpe_magic, uint32_t flags,
@@ -560,6 +568,8 @@ __global__ __launch_bounds__(BLOCK) void k_tile_roll(Params P, int E, uint32_t c
         lo.totals = acc;
         __syncthreads();
     }
+    // (Params stays live across the loop here: re-read per step as in k_obs_roll, this kernel goes from 97-106 to 135-141 VGPRs —
+    // three waves per SIMD instead of four — and temper mode from 2.58 to 2.23 G env-steps/s)
     for (int s = 0; s < k_steps; ++s)
         for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
             tile_step<FMT, true, ALIGNED>(P, E, cpe, cpe_magic, nullptr, nullptr, flags, obs, lo, t, smem);
@@ -853,9 +863,18 @@ __global__ __launch_bounds__(BLOCK) void k_obs_roll(Params P, int E, uint32_t cp
     // read from memory once, every step still writes both observation planes (which also are the state in memory)
     const bool resident = (flags & TRON_ROLLOUT_RESIDENT) != 0u && (int)gridDim.x == ntiles;
     flags &= ~TRON_ROLLOUT_RESIDENT;
+    // The step's parameters are re-read from the kernel-argument segment at every step (scalar loads through a pointer the
+    // compiler cannot see through): kept live across the loop, the 26 words of Params pushed the kernel to 63 SGPR spills —
+    // 122 v_readlane per step; re-read, 33 / 24 (and 108 VGPRs instead of 93: four waves per SIMD instead of five), and the
+    // rollout is 3.5 % faster at 64 steps per launch, 0.5 - 1.5 % at 20 (same box, A/B, scripts/env_kernarg_ab.sh).
+    kernarg_t *kp = (kernarg_t *)__builtin_amdgcn_kernarg_segment_ptr();       // (Params is the first argument)
     for (int s = 0; s < k_steps; ++s)
         for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
-            obs_tile<true>(P, E, cpe, cpe_magic, nullptr, flags, lo, t, smem, resident && s > 0, resident);
+            kernarg_t *q = kp;
+            asm volatile("" : "+s"(q));
+            Params Pl;
+            load_params(Pl, q);
+            obs_tile<true>(Pl, E, cpe, cpe_magic, nullptr, flags, lo, t, smem, resident && s > 0, resident);
             __syncthreads();        // the tile's LDS is reused; this step's state words are visible to the next
         }
     if (out.totals && threadIdx.x < 4 && acc[threadIdx.x]) atomicAdd(&out.totals[threadIdx.x], acc[threadIdx.x]);
