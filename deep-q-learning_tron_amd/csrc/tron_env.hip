@@ -1650,7 +1650,7 @@ namespace {
 // full: at 65 536 envs 32-env tiles are 2 048 workgroups = 1.6 rounds (the tail runs 3 per CU, latency-bound), 26-env
 // tiles are 2 521 = 1.97 rounds — 21.4 instead of 21.9 us per step (gpurun sweep, round 2).  Picks the E in
 // [3/4 E0, E0] with the fullest last round (E0 = the per-step kernels' tile); small batches that fit in one round
-// keep E0.
+// keep E0.  (With this file's current k_obs_roll — occupancy 4 — 32-env tiles are exactly two rounds and win the sweep.)
 int roll_tile_envs(const tron_env *h)
 {
     const int E0 = h->E;
