@@ -52,26 +52,40 @@ def alg_bytes_per_env_step(width):
     return 3 * g + 32
 
 
-def pmc_traffic(envs, width, obs, mode, kernel_tag, steps_per_launch, variant="larger-fetch"):
-    """HBM bytes per STEP of the step kernel from the committed rocprofv3 PMC passes
-    (profiles/r*_summary*.json, made by scripts/pmc_summary.py: FETCH_SIZE x2 per the gfx950
-    correction + WRITE_SIZE, KiB -> bytes).  Only returned for the exact workload AND steps-per-launch
-    the passes were taken on: a persistent launch of a different length has a different L2 / Infinity
-    Cache carry-over between its steps.  The profiled program launches the rollout kernel in two variants
-    (boards re-read each step / resident in LDS); pmc_summary.py splits them by fetch volume."""
+def env_kernel_source_sha():
+    """sha256 (first 16 hex digits) of the env kernels' sources: a committed PMC record names the sources it was taken on,
+    so a record of an older kernel is never quoted for the current one."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("tron_env.hip", "tron_device.hpp"):
+        h.update(open(os.path.join(PKG, "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(envs, width, obs, mode, variant, steps_per_launch):
+    """HBM bytes per STEP of the persistent rollout kernel from the committed rocprofv3 PMC passes
+    (profiles/r*_rollout_pmc.json, made by scripts/rollout_pmc.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE /
+    --kernel-trace runs of `bench.py --only-rollout`: every dispatch of the timed class is the same launch; FETCH_SIZE x2 per
+    the gfx950 correction, KiB -> bytes).  Returned only for the exact workload, variant ("plain" / "resident") and
+    steps-per-launch the passes were taken on (a persistent launch of another length has another L2 / Infinity Cache
+    carry-over between its steps) AND only when the record names the CURRENT kernel sources."""
     import glob
-    if (envs, width, obs, mode) != (N_ENVS, WIDTH, "codes", "none"):
-        return None, None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary*.json")), reverse=True):
+    import re
+    paths = glob.glob(os.path.join(ROOT, "profiles", "r*_rollout_pmc*.json"))
+    paths.sort(key=lambda q: int(re.match(r"r(\d+)_", os.path.basename(q)).group(1)), reverse=True)
+    sha = env_kernel_source_sha()
+    stale = None
+    for path in paths:
         summ = json.load(open(path))
-        if int(summ.get("steps_per_launch", 1)) != int(steps_per_launch):
-            continue
-        names = [n for n in summ["kernels"] if kernel_tag in n]
-        pick = [n for n in names if variant in n] or [n for n in names if "[" not in n]
-        if pick:
-            k = summ["kernels"][pick[0]]
-            return k["hbm_bytes_per_launch"] / summ.get("steps_per_launch", 1), os.path.relpath(path, ROOT)
-    return None, None
+        for rec in summ.get("records", []):
+            if (rec["envs"], rec["width"], rec["obs"], rec["mode"], rec["variant"], int(rec["steps_per_launch"])) != \
+                    (envs, width, obs, mode, variant, int(steps_per_launch)):
+                continue
+            if summ.get("env_kernel_source_sha16") != sha:
+                stale = stale or f"{os.path.relpath(path, ROOT)} is of other kernel sources ({summ.get('env_kernel_source_sha16')} != {sha}): not quoted"
+                continue
+            return rec["hbm_bytes_per_launch"] / rec["steps_per_launch"], os.path.relpath(path, ROOT)
+    return None, stale
 
 
 def host_cores():
@@ -252,6 +266,49 @@ def dqn_record(envs, width, steps, warmup, batch, repeats, world, rank):
                                  "26x26); per-kernel rows: profiles/r03_learn_*_kernel_rows.txt, r03_infer_*"}}
 
 
+class _RandomModel:
+    """The stub policy of BASELINE.md §2's main_loop row: model.act(...) -> a uniform action, no network."""
+
+    def __init__(self, seed=0x5EED):
+        import random
+        self.rng = random.Random(seed)
+
+    def act(self, x, env=None):
+        return self.rng.randrange(4)
+
+
+def config1_record(games, width=10):
+    """BASELINE configs[0] / SURVEY 8(d) c1: single games of the scalar facade — tron.util.make_game + Game.main_loop(model,
+    pop=pop_up), two random-action players — every step a one-env launch of the HIP step kernel plus the facade's host
+    round trips (state pull, map snapshot, pop_up per player).  Plumbing, not throughput: reported so that the N = 1 case
+    has a measured line next to the reference's recorded 1.1 k env-steps/s."""
+    import torch
+    from tron import util
+    model = _RandomModel()
+    for _ in range(3):                                                     # warm-up: library load, first launches
+        util.make_game(True, True, width=width).main_loop(model, pop=util.pop_up)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = wins1 = wins2 = 0
+    for _ in range(games):
+        g = util.make_game(True, True, width=width)
+        g.main_loop(model, pop=util.pop_up)
+        steps += len(g.history) - 1
+        wins1 += g.winner == 1
+        wins2 += g.winner == 2
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": "env-steps/sec, scalar Game facade (BASELINE configs[0]: single 10x10 game, 2 random-action players, main_loop)",
+            "value": steps / dt, "unit": "env-steps/s", "n_gpus": 1, "games": games, "env_steps": steps, "seconds": dt,
+            "mean_episode_steps": steps / games, "wins_p1_p2_draw": [int(wins1), int(wins2), int(games - wins1 - wins2)],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+            "reference_python_recorded": {"value": 1.1e3, "source": "BASELINE.md §2, Game.main_loop(stub random-action model, pop=pop_up), 10x10"},
+            "config": {"workload": f"{games} sequential {width}x{width} games of tron.game.Game (one env per launch, host-side "
+                                   f"history / Map mirrors as the reference keeps them), stub random-action model, pop=pop_up",
+                       "parallelism": "none (N = 1 plumbing case)"},
+            "note": "latency-bound by construction: each step is one tiny kernel launch plus ~6 device-to-host copies of a few hundred bytes"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,6 +335,16 @@ def main():
     ap.add_argument("--acktr", action="store_true", help="print the ACKTR record instead (BASELINE configs[4]: 16 384 envs 32x32)")
     ap.add_argument("--acktr-iterations", type=int, default=2)
     ap.add_argument("--dqn3-steps", type=int, default=8, help="config-3 DQN record (65 536 envs x 24x24): env steps per timed region")
+    ap.add_argument("--only-rollout", action="store_true",
+                    help="profiling runs: the warm-up and the timed persistent-rollout launches only (no per-step, two-stream "
+                         "or resident passes, no temper / DQN / CPU records), so that every dispatch of the step kernel in a "
+                         "rocprofv3 pass is the same launch")
+    ap.add_argument("--rollout-variant", default="plain", choices=["plain", "resident"],
+                    help="what the timed region launches: the persistent rollout re-reading the boards every step (headline) or "
+                         "keeping them resident in LDS (own byte model); 'resident' is for --only-rollout profiling runs")
+    ap.add_argument("--config1", action="store_true",
+                    help="BASELINE configs[0]: single 10x10 games of the scalar Game facade, two random-action players, "
+                         "Game.main_loop(model, pop=pop_up) — the plumbing case (SURVEY 8(d) c1); prints its own line")
     ap.add_argument("--dqn-envs", type=int, default=4096)
     ap.add_argument("--dqn-width", type=int, default=10)
     args = ap.parse_args()
@@ -304,6 +371,13 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.config1:
+        if rank == 0:
+            print(json.dumps(config1_record(max(20, min(args.steps, 2000)))), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     if args.acktr:
         # BASELINE configs[4]: the ACKTR.py path at 32x32 boards, 16 384 envs, K-FAC natural-gradient step on PyTorch-ROCm
@@ -379,7 +453,9 @@ def main():
                 for _ in range(k):
                     step()
         else:
-            def run(k, per_step=False, two=False, resident=False):
+            main_resident = args.rollout_variant == "resident"
+
+            def run(k, per_step=False, two=False, resident=main_resident):
                 env.rollout_random(k, nonreversing=nonrev, per_step_launches=per_step, two_streams=two, resident=resident)
         run(args.warmup)
         for _ in range(max(1, args.repeats)):
@@ -393,7 +469,7 @@ def main():
             walls.append(max_over_ranks(time.perf_counter() - t0, world))
             dev_ms.append(ev0.elapsed_time(ev1))
         # the same K steps as one launch per step (what a caller that supplies actions every step gets)
-        if not args.incremental and not os.environ.get("TRON_ROLL_PER_STEP"):
+        if not args.incremental and not args.only_rollout and not os.environ.get("TRON_ROLL_PER_STEP"):
             run(min(args.warmup, 16), True)
             for _ in range(max(1, args.repeats)):
                 ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -432,20 +508,52 @@ def main():
     step_ms = ev_ms / args.steps
     kern_ms = ev_ms / n_launches                   # avg launch of the step kernel
 
+    # a sliding mode beside the headline ("temper" as a secondary row): the same K steps on k_tile_roll
+    temper = None
+    if args.mode == "none" and args.obs == "codes" and not args.incremental and not args.only_rollout and not nonrev:
+        tenv = VecTron(args.envs, args.width, mode="temper", seed=0x5EED, rank=rank, obs_format="codes")
+        tenv.reset()
+        t_ms = []
+        with torch.cuda.stream(side):
+            side.wait_stream(torch.cuda.current_stream())
+            tenv.rollout_random(args.warmup)
+            for _ in range(max(1, min(args.repeats, 3))):
+                ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                barrier()
+                ev2.record()
+                tenv.rollout_random(args.steps)
+                ev3.record()
+                barrier()
+                t_ms.append(max_over_ranks(ev2.elapsed_time(ev3), world) / args.steps)
+        tenv.close()
+        del tenv
+        tm = statistics.median(t_ms)
+        t_ach = alg_bytes_per_env_step(args.width) * args.envs / (tm * 1e-3) / 1e9
+        temper = {"metric": "env-steps/sec, mode='temper' (slides: game.py:96-108,163-178; in-kernel Philox uniforms)",
+                  "value": args.envs * world / (tm * 1e-3), "ms_per_step": tm, "ms_per_step_min_max": [min(t_ms), max(t_ms)],
+                  "roofline": {"bound": "hbm", "achieved": t_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": t_ach / HBM_PEAK_GBS,
+                               "frac_of_achievable": t_ach / HBM_COPY_GBS, "alg_bytes_per_env_step": alg_bytes_per_env_step(args.width),
+                               "kernel": "k_tile_roll (persistent rollout, board-owning layout)"}}
+
     dqn = dqn3 = None
-    if not args.no_dqn and not args.incremental:
+    if not args.no_dqn and not args.incremental and not args.only_rollout:
         env.close()
         del env
         env = None
-        try:
-            dqn = dqn_record(args.dqn_envs, args.dqn_width, args.dqn_steps, 6, args.batch, 3, world, rank)
-        except Exception as e:                     # the headline must survive a trainer-side failure
-            dqn = {"error": f"{type(e).__name__}: {e}"}
-        try:                                       # BASELINE configs[2]: 65 536 envs x 24x24, 1M-slot replay
-            torch.cuda.empty_cache()
-            dqn3 = dqn_record(N_ENVS, WIDTH, args.dqn3_steps, 2, args.batch, 3, world, rank)
-        except Exception as e:
-            dqn3 = {"error": f"{type(e).__name__}: {e}"}
+        # A single process lets the headline survive a trainer-side failure (the record then carries the error).  With one
+        # rank per GPU that is not an option: the rank that raised has left the per-learn-step all-reduce and its peers
+        # would block there — the job ends non-zero instead (DDQN.abort_job; never a line that looks like a result).
+        def guarded(*a):
+            try:
+                return dqn_record(*a)
+            except Exception as e:
+                if world > 1:
+                    import DDQN
+                    DDQN.abort_job(e)
+                return {"error": f"{type(e).__name__}: {e}"}
+        dqn = guarded(args.dqn_envs, args.dqn_width, args.dqn_steps, 6, args.batch, 3, world, rank)
+        torch.cuda.empty_cache()                   # BASELINE configs[2]: 65 536 envs x 24x24, 1M-slot replay
+        dqn3 = guarded(N_ENVS, WIDTH, args.dqn3_steps, 2, args.batch, 3, world, rank)
         torch.cuda.empty_cache()
 
     if rank == 0:
@@ -461,9 +569,8 @@ def main():
             g = (args.width + 2) ** 2
             b_alg = 80 + int(0.36 * 2 * g)
         achieved = b_alg * args.envs / (step_ms * 1e-3) / 1e9
-        kernel_tag = "k_obs_roll" if obs_is_state else "k_tile_roll"
-        hbm_bytes, hbm_src = (pmc_traffic(args.envs, args.width, args.obs, args.mode, kernel_tag, args.steps / n_launches)
-                              if persistent else (None, None))
+        hbm_bytes, hbm_src = (pmc_traffic(args.envs, args.width, args.obs, args.mode, args.rollout_variant, args.steps / n_launches)
+                              if persistent and obs_is_state else (None, None))
         out = {
             "metric": "env-steps/sec" + (" (incremental observation update)" if args.incremental else "") +
                       (" (non-reversing uniform actions)" if nonrev else ""),
@@ -490,11 +597,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "achievable_peak": HBM_COPY_GBS, "frac_of_achievable": achieved / HBM_COPY_GBS,
                          "traffic": None if hbm_bytes is None else hbm_bytes / (step_ms * 1e-3) / 1e9,
-                         "traffic_bytes_per_step": hbm_bytes, "traffic_source": hbm_src,
+                         "traffic_bytes_per_step": hbm_bytes, "traffic_source": hbm_src if hbm_bytes is not None else None,
                          "traffic_note": ("PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs) of this "
-                                          "workload at this steps-per-launch, committed under profiles/"
+                                          "workload at this steps-per-launch on these kernel sources, committed under profiles/"
                                           if hbm_bytes is not None else
-                                          "no committed PMC pass for this workload / steps-per-launch"),
+                                          (hbm_src or "no committed PMC pass for this workload / steps-per-launch")),
                          "kernel": ("k_inc (in-place update: touched cells + restarted boards only)" if args.incremental
                                     else "k_obs / k_tile (one launch per step)" if not persistent
                                     else "k_obs_roll (persistent rollout of the observation-is-state step, int8 codes)"
@@ -539,14 +646,16 @@ def main():
                              "achieved": rs_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rs_ach / HBM_PEAK_GBS,
                              "achievable_peak": 6100.0, "frac_of_achievable": rs_ach / 6100.0,
                              "achievable_note": "the guide's plain-store rate 6.0-6.2 TB/s",
-                             "traffic_bytes_per_step": pmc_traffic(args.envs, args.width, args.obs, args.mode, "k_obs_roll",
-                                                                   min(args.steps, chunk), "smaller-fetch")[0],
+                             "traffic_bytes_per_step": pmc_traffic(args.envs, args.width, args.obs, args.mode, "resident",
+                                                                   min(args.steps, chunk))[0],
                              "kernel": "k_obs_roll with TRON_ROLLOUT_RESIDENT"}}
+        if temper is not None:
+            out["temper"] = temper
         if dqn is not None:
             out["dqn"] = dqn
         if dqn3 is not None:
             out["dqn_config3"] = dqn3
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.only_rollout:
             out["cpu_baseline"] = cpu_baseline(args.width)
         print(json.dumps(out), flush=True)
 
@@ -555,4 +664,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:                     # one rank per GPU: a rank that fails ends the job, non-zero (DDQN.abort_job)
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not (isinstance(e, SystemExit) and not e.code):
+            import DDQN
+            DDQN.abort_job(e)
+        raise

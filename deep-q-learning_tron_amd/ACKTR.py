@@ -70,7 +70,8 @@ class Brain(object):
         self.value_loss_coef = config.value_loss_coef if v is None else float(v)
         # the sampled-Fisher backward pass computes statistics only (see update()); TRON_ACKTR_FISHER_FULL=1: as two full passes
         self.fisher_stats_only = os.environ.get("TRON_ACKTR_FISHER_FULL", "0") == "0"
-        self._cheap = None
+        from Net import activations
+        self._grad_scope = activations.GradScope()      # this Brain's graphs: the statistics-only switch reaches no other backward
         if acktr:
             self.optimizer = KFACOptimizer(self.actor_critic)
         else:
@@ -82,16 +83,14 @@ class Brain(object):
         Linear layers with >= 1024 inputs): biases, the first convolution, the small Linear layers.  Asking autograd for
         these reaches every module of the net (each module's output gradient is needed on the way down), which is all
         the statistics pass needs."""
-        if self._cheap is None:
-            import torch.nn as nn
-            heavy = set()
-            for m in self.actor_critic.modules():
-                if isinstance(m, nn.Conv2d) and m.in_channels >= 16:
-                    heavy.add(id(m.weight))
-                elif isinstance(m, nn.Linear) and m.in_features >= 1024:
-                    heavy.add(id(m.weight))
-            self._cheap = [p for p in self.actor_critic.parameters() if id(p) not in heavy and p.requires_grad]
-        return self._cheap
+        import torch.nn as nn
+        heavy = set()                                   # (rebuilt per call — a few dozen modules: split_bias or a model swap may have replaced parameters)
+        for m in self.actor_critic.modules():
+            if isinstance(m, nn.Conv2d) and m.in_channels >= 16:
+                heavy.add(id(m.weight))
+            elif isinstance(m, nn.Linear) and m.in_features >= 1024:
+                heavy.add(id(m.weight))
+        return [p for p in self.actor_critic.parameters() if id(p) not in heavy and p.requires_grad]
 
     def update(self, rollouts, micro_batch=None):
         """One update from a full rollout (ACKTR.py:88-159).  With `micro_batch`, the T*N samples are
@@ -120,11 +119,13 @@ class Brain(object):
             w = (hi - lo) / B
             o = obs[lo:hi].to(self.device).detach()
             a = acts[lo:hi].to(self.device).detach()
-            if probs is None:
-                values, action_log_probs, entropy = self.actor_critic.evaluate_actions(o, a)
-            else:
-                values, action_log_probs, entropy = self.actor_critic.evaluate_actions(
-                    o, a, probs[lo:hi].to(self.device).detach())
+            from Net import activations
+            with activations.grad_scope(self._grad_scope):       # the nodes of this forward belong to this Brain's scope
+                if probs is None:
+                    values, action_log_probs, entropy = self.actor_critic.evaluate_actions(o, a)
+                else:
+                    values, action_log_probs, entropy = self.actor_critic.evaluate_actions(
+                        o, a, probs[lo:hi].to(self.device).detach())
             advantages = rets[lo:hi].to(self.device).detach() - values
             value_loss = advantages.pow(2).mean()
             action_gain = (action_log_probs * advantages.detach()).mean()
@@ -141,12 +142,11 @@ class Brain(object):
                     # weight gradients are a by-product — and the expensive half of a backward pass.  Ask autograd only
                     # for the cheap parameters (every module's hook still fires: its input gradient is on the way to
                     # them), drop what that leaves in .grad, and let the loss pass below carry the Fisher loss as well.
-                    from Net import activations
-                    activations.skip_weight_gradients = True        # (the hand-written convolution nodes: see there)
+                    self._grad_scope.skip_weight_gradients = True     # (the hand-written convolution nodes of THIS graph: Net/activations.py)
                     try:
                         (fisher_loss * w).backward(retain_graph=True, inputs=self._cheap_parameters())
                     finally:
-                        activations.skip_weight_gradients = False
+                        self._grad_scope.skip_weight_gradients = False
                     self.actor_critic.zero_grad()
                 else:
                     (fisher_loss * w).backward(retain_graph=True)

@@ -169,7 +169,13 @@ class Agent():
         fused = self.device.type == "cuda" and os.environ.get("TRON_ADAM_FUSED", "1") != "0"
         self.optimizer = optim.Adam(self.qnetwork_local.parameters(), fused=True) if fused else optim.Adam(self.qnetwork_local.parameters())
         self.epsilon = 0
-        self._eps_seed, self._eps_rank = (0x5EED if seed is None else int(seed)), int(rank)      # act_batch's exploration draws
+        # act_batch's exploration draws: Philox keyed (seed, rank) at counter (observation, call).  The reference's
+        # random.random() (DDQN.py:105) is unseeded, so without a seed the key comes from the OS; the call counter is part of
+        # the full checkpoint (a resumed run continues the draw sequence instead of replaying it).
+        self._eps_seed = int.from_bytes(os.urandom(4), "little") if seed is None else int(seed)
+        self._eps_rank, self._eps_calls = int(rank), 0
+        self._pending = self._pending_on_side = False                            # learn(defer=True) ... finish_learn()
+        self._side = None
         self.totalloss = 0
         self.batch_size = batch_size
         self.memory = (ReplayBuffer(4, buffer_size, batch_size, width, in_channels, seed=seed, rank=rank)
@@ -211,7 +217,7 @@ class Agent():
             # one launch (csrc/tron_dqn.hip): Philox draws keyed by (seed, rank) at counter (observation, call); epsilon stays on the device
             from tron import _native as nat
             out = torch.empty_like(greedy)
-            self._eps_calls = getattr(self, "_eps_calls", 0) + 1
+            self._eps_calls += 1
             with torch.cuda.device(greedy.device):
                 nat.check(nat.lib().tron_eps_greedy(nat.ptr(greedy), greedy.numel(), nat.ptr(epsilon.reshape(1)), self._eps_seed & 0xFFFFFFFF,
                                                     self._eps_rank, self._eps_calls, nat.ptr(out), nat.stream_ptr()), "tron_eps_greedy")
@@ -247,14 +253,15 @@ class Agent():
         return flat
 
     def finish_learn(self):
-        """The second half of a learn(..., defer=True): wait for the gradient all-reduce that went out on the side
-        stream, then optimizer step and soft update.  No-op when nothing is pending."""
+        """The second half of a learn(..., defer=True): wait for the gradient all-reduce (on the side stream, when it went
+        out there), then optimizer step and soft update.  No-op when nothing is pending."""
         if not getattr(self, "_pending", False):
             return
-        torch.cuda.current_stream(self.device).wait_stream(self._side)
+        if getattr(self, "_pending_on_side", False):
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
         self.optimizer.step()
         self.soft_update(self.qnetwork_local, self.qnetwork_target, TAU)
-        self._pending = False
+        self._pending = self._pending_on_side = False
 
     def learn(self, experiences, gamma, defer=False):           # DDQN.py:115-151
         """experiences: ReplayBuffer.sample() (f32 planes, as the reference hands them over) or .sample_codes() (int8
@@ -264,7 +271,9 @@ class Agent():
         defer=True the call returns once that collective is queued and `finish_learn()` applies the update — the
         trainer calls it after it has queued the next policy forward, so the collective's latency (xGMI ring: tens of
         microseconds for 2-5 MB) hides under that forward; the policy then acts on weights one learn step old, on every
-        rank alike.  Single process, or defer=False: the reference's order, update applied before returning."""
+        rank alike.  defer=False (what a single process runs): the reference's order, update applied before returning.
+        (defer=True is honoured in a single process and on host tensors too — the gradients are then simply kept until
+        finish_learn() — which is how the CPU tests pin the deferred order against a plain run.)"""
         self.finish_learn()
         states, actions, rewards, next_state, dones = experiences
         criterion = torch.nn.MSELoss()
@@ -302,14 +311,12 @@ class Agent():
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
                 all_reduce_mean_(flat)
-            self._pending = True
-            if defer:
-                return loss.detach()
+            self._pending_on_side = True
+        else:
+            average_gradients(self.qnetwork_local)     # host tensors / gathered gradients: synchronous; no-op in a single process
+        self._pending = True
+        if not defer:
             self.finish_learn()
-            return loss.detach()
-        average_gradients(self.qnetwork_local)
-        self.optimizer.step()
-        self.soft_update(self.qnetwork_local, self.qnetwork_target, TAU)
         return loss.detach()
 
     def soft_update(self, local_model, target_model, tau):                       # DDQN.py:153-165
@@ -325,22 +332,81 @@ class Agent():
                     target_param.data.copy_(tau * local_param.data + (1 - tau) * target_param.data)
 
 
-def save_checkpoint(path, brain, epsilon=0.0, counters=None):
-    """Everything needed to resume except the replay contents: both nets, Adam state, epsilon and
-    counters.  (The reference saves only the target net's state_dict, DDQN.py:326, so a resumed run
-    restarts epsilon at 1; `torch.save(brain.qnetwork_target.state_dict(), ...)` still gives that file.)"""
-    torch.save({"local": brain.qnetwork_local.state_dict(), "target": brain.qnetwork_target.state_dict(),
-                "optimizer": brain.optimizer.state_dict(), "epsilon": float(epsilon),
-                "t_step": brain.t_step, "counters": dict(counters or {})}, path)
+def save_checkpoint(path, brain, epsilon=0.0, counters=None, replay="cursor"):
+    """Everything needed to resume: both nets, Adam state, epsilon, counters, the exploration draw counter and the replay
+    ring — replay="cursor": write head, fill level and sampler call counter (SURVEY 8(f)4's "replay head"); "contents":
+    the filled slots too (2 * cells + 6 bytes each: 1.35 GB for 1 M slots at 24x24 boards); None: nothing.  Tensors and
+    plain numbers only: the file loads with weights_only=True.  (The reference saves only the target net's state_dict,
+    DDQN.py:326, so a resumed run restarts epsilon at 1 with an empty deque; `torch.save(brain.qnetwork_target.state_dict(), ...)`
+    still gives that file.)"""
+    ck = {"local": brain.qnetwork_local.state_dict(), "target": brain.qnetwork_target.state_dict(),
+          "optimizer": brain.optimizer.state_dict(), "epsilon": float(epsilon), "t_step": brain.t_step,
+          "eps_calls": int(brain._eps_calls), "eps_seed": int(brain._eps_seed), "counters": dict(counters or {})}
+    ring = getattr(getattr(brain, "memory", None), "memory", None)
+    if replay is not None and ring is not None and hasattr(ring, "state_dict"):
+        ck["replay"] = ring.state_dict(contents=(replay == "contents"))
+    torch.save(ck, path)
 
 
 def load_checkpoint(path, brain):
-    ck = torch.load(path, map_location=brain.device, weights_only=True)
+    """Inverse of save_checkpoint.  A replay section with contents refills the ring; a cursor-only one is applied when the
+    ring already holds that many transitions and skipped otherwise (a fresh ring restarts empty, as the reference's does)."""
+    ck = torch.load(path, map_location="cpu", weights_only=True)
     brain.qnetwork_local.load_state_dict(ck["local"])
     brain.qnetwork_target.load_state_dict(ck["target"])
     brain.optimizer.load_state_dict(ck["optimizer"])
     brain.t_step = ck["t_step"]
+    brain._eps_calls = int(ck.get("eps_calls", 0))
+    if "eps_seed" in ck:
+        brain._eps_seed = int(ck["eps_seed"])
+    ring = getattr(getattr(brain, "memory", None), "memory", None)
+    if "replay" in ck and ring is not None and hasattr(ring, "load_state_dict"):
+        sd = ck["replay"]
+        if "states" in sd or int(sd["size"]) <= len(ring):
+            ring.load_state_dict(sd)
     return ck["epsilon"], ck["counters"]
+
+
+def abort_job(exc=None, code=1):
+    """One rank per GPU: end THIS process non-zero, now.  A rank that raised has left the per-learn-step all-reduce; its
+    peers would block in RCCL until a watchdog fires (and a caller that swallowed the exception would report success).
+    The traceback is printed, the process group is aborted where the backend can (NCCL / RCCL communicators: a blocked peer
+    then fails instead of waiting) and the process exits with `code` without running atexit handlers that could block in
+    the same collective — never a re-exec.  The launcher (`torch.distributed.run`) sees the failed worker and stops the
+    others; peers on gloo see the closed connection and raise.  Reference shape: independent workers, ACKTR.py:183,285-289."""
+    import sys
+    import threading
+    import traceback
+    if exc is not None:
+        traceback.print_exception(type(exc), exc, exc.__traceback__, file=sys.stderr)
+    print(f"[tron] rank {os.environ.get('RANK', '0')}: aborting the job (exit code {code})", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    threading.Timer(5.0, lambda: os._exit(code)).start()       # if the abort below blocks, leave anyway
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            abort = getattr(dist.distributed_c10d, "_abort_process_group", None)
+            if abort is not None and dist.get_backend() == "nccl":
+                abort()
+    except Exception:
+        pass
+    os._exit(code)
+
+
+def fails_the_job(fn):
+    """Decorator for a rank's main loop: with world > 1 any exception (or KeyboardInterrupt) becomes abort_job(); a single
+    process re-raises as usual."""
+    import functools
+
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        try:
+            return fn(*args, **kwargs)
+        except BaseException as e:        # noqa: BLE001 - the point is that nothing survives silently
+            if _world() > 1 and not isinstance(e, SystemExit):
+                abort_job(e)
+            raise
+    return guarded
 
 
 def _decays_left(epsilon):
@@ -353,6 +419,7 @@ def _decays_left(epsilon):
     return k
 
 
+@fails_the_job
 def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BATCH_SIZE, capacity=1 << 20,
           in_channels=3, seed=0x5EED, log_every=50, save_path=None, log_dir=None, resume=None,
           terminal_next_state=True, brain=None):
@@ -368,12 +435,22 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
     terminal_next_state=True stores what the reference stores for a finished game (DDQN.py:265-308: the
     terminal board as next_state) by stepping without autoreset and restarting the finished envs with a
     masked reset; False uses the env's autoreset (ACKTR.py:307-310 convention: next_state of a terminal
-    transition is the new game's first observation — irrelevant to the (1 - done) target, one launch fewer)."""
+    transition is the new game's first observation — irrelevant to the (1 - done) target, one launch fewer).
+
+    Update order.  A single process applies every learn step before the next policy forward (the reference's order,
+    DDQN.py:73-88).  With one rank per GPU (world > 1) the gradient all-reduce goes out on a side stream and the update is
+    applied AFTER the next policy forward has been queued (learn(defer=True) ... act_batch ... finish_learn): the policy of
+    env step t + 1 acts on the weights of learn step k - 1, on every rank alike — a deterministic one-step staleness that
+    hides the collective's latency; tests/test_dist_cpu.py holds a two-rank run to a single process applying that order.
+
+    Failure.  With world > 1 an exception on any rank ends THIS process non-zero at once (abort_job): the launcher then
+    takes the job down instead of the peers blocking in the next all-reduce."""
     import time
     import torch.distributed as dist
     from tron.vec import VecTron, pop_up_planes
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
+    defer = world > 1
     if brain is None:
         torch.manual_seed(seed)                    # same initial weights on every rank ...
         brain = Agent(width, in_channels, buffer_size=capacity, batch_size=batch_size, seed=seed, rank=rank,
@@ -428,7 +505,7 @@ def train(n_envs=4096, width=MAP_WIDTH, steps=200, learn_every=2, batch_size=BAT
             games_d += done.sum()
         if it % learn_every == learn_every - 1 and len(brain.memory) > batch_size:    # len(): a host counter
             brain.steps += 1
-            brain.learn(brain.memory.sample_codes(), GAMMA, defer=True)   # the batch as int8 codes: conv1 and the target chain read them
+            brain.learn(brain.memory.sample_codes(), GAMMA, defer=defer)  # the batch as int8 codes: conv1 and the target chain read them
             learn_steps += 1
         # DDQN.py:313-315, once per finished 20-game cycle
         if sched is not None:

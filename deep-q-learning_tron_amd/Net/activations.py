@@ -131,10 +131,50 @@ class _Conv1CodesHIP(torch.autograd.Function):
         return None, gw, (gb if ctx.needs_input_grad[2] else None), None
 
 
-# Set (by ACKTR.Brain.update) around a backward pass that exists only for K-FAC's gradient statistics: a custom Function's
-# ctx.needs_input_grad is fixed at forward time, so `backward(inputs=...)` alone cannot tell it that nobody wants the weight
-# gradient of this pass; the library operators learn it from the engine.
-skip_weight_gradients = False
+# A backward pass that exists only for K-FAC's gradient statistics (ACKTR.Brain.update) does not want the hand-written
+# convolution nodes' weight gradients, and a custom Function cannot learn that from the engine: ctx.needs_input_grad is fixed
+# at forward time, so `backward(inputs=...)` alone does not reach it (the library operators do learn it).  The switch is
+# scoped to the GRAPH, not to the process: a Brain owns a GradScope, its forward passes run inside `with grad_scope(scope)`
+# (forward runs on the calling thread: a thread-local), every node built there keeps a reference to the scope, and the
+# Brain flips `scope.skip_weight_gradients` around its statistics pass.  A backward of any other graph — the other player's
+# Brain, another thread — holds another scope (or none) and is unaffected.  (Backward itself runs on autograd's device
+# thread, which is why the node carries the scope instead of looking one up.)
+import threading as _threading
+
+
+class GradScope:
+    __slots__ = ("skip_weight_gradients",)
+
+    def __init__(self):
+        self.skip_weight_gradients = False
+
+
+_forward_scope = _threading.local()
+
+
+class grad_scope:
+    """Context manager: nodes created inside belong to `scope`."""
+
+    def __init__(self, scope):
+        self.scope = scope
+
+    def __enter__(self):
+        self.prev = getattr(_forward_scope, "scope", None)
+        _forward_scope.scope = self.scope
+        return self.scope
+
+    def __exit__(self, *exc):
+        _forward_scope.scope = self.prev
+        return False
+
+
+def _current_scope():
+    return getattr(_forward_scope, "scope", None)
+
+
+def _skips_weight_gradient(ctx):
+    scope = getattr(ctx, "grad_scope", None)
+    return scope is not None and scope.skip_weight_gradients
 
 
 class _Conv3x3HIP(torch.autograd.Function):
@@ -147,6 +187,7 @@ class _Conv3x3HIP(torch.autograd.Function):
         from Net import fused
         out = fused.conv3x3_raw(x, weight, bias, None, act=False)
         ctx.save_for_backward(x, weight)
+        ctx.grad_scope = _current_scope()
         return out
 
     @staticmethod
@@ -168,7 +209,7 @@ class _Conv3x3HIP(torch.autograd.Function):
             else:
                 gx = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
-        if ctx.needs_input_grad[1] and not (skip_weight_gradients and weight.shape[1] >= 16):
+        if ctx.needs_input_grad[1] and not (_skips_weight_gradient(ctx) and weight.shape[1] >= 16):
             if fused.wgrad_supported(weight, x.shape[-1]):
                 gw = fused.conv3x3_wgrad(x, g, absmax)
             else:                                             # (shapes the weight-gradient kernels do not cover)
@@ -440,6 +481,7 @@ class _PoolConv7CL(torch.autograd.Function):
                                             nat.ptr(ws), nat.stream_ptr()), "tron_pool_conv7_fwd")
         ctx.save_for_backward(saved, pre, weight)
         ctx.geometry = (B, side)
+        ctx.grad_scope = _current_scope()
         return y
 
     @staticmethod
@@ -456,7 +498,7 @@ class _PoolConv7CL(torch.autograd.Function):
         with torch.cuda.device(dev):
             if ctx.needs_input_grad[0]:
                 gx = torch.empty(B, 64, side, side, dtype=torch.float32, device=dev)
-            if ctx.needs_input_grad[1] and not skip_weight_gradients:
+            if ctx.needs_input_grad[1] and not _skips_weight_gradient(ctx):
                 gw = torch.empty_like(weight)
             if ctx.needs_input_grad[2]:
                 gb = torch.empty(64, dtype=torch.float32, device=dev)
@@ -485,6 +527,7 @@ class _Conv7HIP(torch.autograd.Function):
                                        nat.stream_ptr()), "tron_conv7_fwd")
         ctx.save_for_backward(saved, weight)
         ctx.geometry = (B, ps)
+        ctx.grad_scope = _current_scope()
         return y
 
     @staticmethod
@@ -501,7 +544,7 @@ class _Conv7HIP(torch.autograd.Function):
         with torch.cuda.device(dev):
             if ctx.needs_input_grad[0]:
                 gx = torch.empty(B, 64, ps, ps, dtype=torch.float32, device=dev)
-            if ctx.needs_input_grad[1] and not skip_weight_gradients:
+            if ctx.needs_input_grad[1] and not _skips_weight_gradient(ctx):
                 gw = torch.empty_like(weight)
             if ctx.needs_input_grad[2]:
                 gb = torch.empty(64, dtype=torch.float32, device=dev)

@@ -264,12 +264,14 @@ template <class C>
 int launch_rows(const float *in, const float *gp, const float *absmax, int n_absmax, float *partial, int64_t batch, int cout,
                 int grid_max, int *nparts, hipStream_t st)
 {
-    static bool prepared = false;
+    static uint64_t prepared = 0;                                       // one bit per device: the attribute is per device
     auto kern = k_wgrad_rows<C>;
-    if (!prepared) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
+    if (!(prepared & (1ull << (dev & 63)))) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
             (void)hipGetLastError();
-        prepared = true;
+        prepared |= 1ull << (dev & 63);
     }
     const int nhalves = cout / C::COW;
     const int wgs = (int)(batch < grid_max / nhalves ? batch : grid_max / nhalves);

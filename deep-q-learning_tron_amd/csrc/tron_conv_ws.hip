@@ -580,15 +580,18 @@ int launch_ws(const void *in, const void *wfrag, const float *bias, const void *
     int grid = device_cus() / G::NB * G::NB;
     if (nitems < grid) grid = (int)nitems;
     constexpr size_t LDS_ALL = G::LDS_BYTES;
-    static bool prepared[4] = {false, false, false, false};
+    static uint64_t prepared[4] = {0, 0, 0, 0};                         // per variant, one bit per device (the attribute is per device)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
+    const uint64_t dev_bit = 1ull << (dev & 63);
 #define TRON_WS_LAUNCH(RES_, F32_)                                                                                    \
     do {                                                                                                              \
         auto kern = k_conv_ws<G, RES_, F32_>;                                                                         \
-        if (!prepared[RES_ * 2 + F32_]) {                                                                             \
+        if (!(prepared[RES_ * 2 + F32_] & dev_bit)) {                                                                 \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)LDS_ALL) != hipSuccess)                                                      \
                 (void)hipGetLastError();                                                                              \
-            prepared[RES_ * 2 + F32_] = true;                                                                         \
+            prepared[RES_ * 2 + F32_] |= dev_bit;                                                                     \
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::THREADS), LDS_ALL, st,                                    \
                            reinterpret_cast<const unsigned char *>(in), reinterpret_cast<const f16x8 *>(wfrag), bias, \

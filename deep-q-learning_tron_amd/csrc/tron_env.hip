@@ -42,6 +42,7 @@
 #include <math.h>
 #include <string.h>
 #include <new>
+#include <type_traits>
 
 using namespace tron;
 
@@ -879,6 +880,15 @@ __global__ __launch_bounds__(BLOCK) void k_obs_roll(Params P, int E, uint32_t cp
         }
     if (out.totals && threadIdx.x < 4 && acc[threadIdx.x]) atomicAdd(&out.totals[threadIdx.x], acc[threadIdx.x]);
 }
+
+// load_params reads sizeof(Params) bytes from offset 0 of the kernel-argument segment: that is Params only while it is the
+// kernel's FIRST parameter (arguments are laid out in declaration order from offset 0) and a plain block of bytes.
+template <class F> struct first_kernel_arg;
+template <class R, class A0, class... A> struct first_kernel_arg<R (*)(A0, A...)> { typedef A0 type; };
+static_assert(std::is_same<first_kernel_arg<decltype(&k_obs_roll)>::type, Params>::value,
+              "k_obs_roll re-reads Params from kernarg offset 0: Params must stay its first parameter");
+static_assert(std::is_trivially_copyable<Params>::value && alignof(Params) <= 8 && sizeof(Params) % 4 == 0,
+              "Params is block-copied from the kernel-argument segment with scalar loads");
 
 // ------------------------------------------------------------ incremental step --
 // Observation-is-state, TRON_STEP_INCREMENTAL: the attached planes already hold the previous

@@ -614,6 +614,19 @@ int gram_pass(const f16 *xh, const f16 *xl, const GramPlan &p, int d, int64_t ro
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
+// k_gram_nchw (a 1x1 "patch matrix" read straight from the NCHW tensor) writes one C x C block of partial sums per split.
+// The split count and the bytes it needs are decided HERE for both the size query and the call: a Gram plan over batch * per
+// rows is smaller than the blocks when an image has few positions (conv7's 4x4 / 6x6 outputs), so the query takes the maximum.
+inline bool nchw_gram_geometry(int32_t channels, int32_t kh, int32_t kw, int32_t pad, int32_t stride, int64_t per)
+{
+    return kh == 1 && kw == 1 && pad == 0 && stride == 1 && (channels == 32 || channels == 64) && per % 4 == 0;
+}
+inline int nchw_gram_splits(int64_t batch) { return (int)(batch < 2048 ? batch : 2048); }
+inline int64_t nchw_gram_bytes(int64_t batch, int32_t channels)
+{
+    return (int64_t)nchw_gram_splits(batch) * channels * channels * (int64_t)sizeof(float) + 512;
+}
+
 }  // namespace
 
 extern "C" int64_t tron_kfac_patch_gram_workspace(int64_t batch, int32_t channels, int32_t height, int32_t width, int32_t kh,
@@ -622,7 +635,13 @@ extern "C" int64_t tron_kfac_patch_gram_workspace(int64_t batch, int32_t channel
     if (batch < 1 || channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad < 0 || stride < 1) return 0;
     const int OH = (height + 2 * pad - kh) / stride + 1, OW = (width + 2 * pad - kw) / stride + 1;
     if (OH < 1 || OW < 1 || (int64_t)channels * kh * kw > 8192) return 0;
-    return gram_plan(batch * OH * OW, (int64_t)OH * OW, channels * kh * kw).total;
+    const int64_t per = (int64_t)OH * OW;
+    int64_t need = gram_plan(batch * per, per, channels * kh * kw).total;
+    if (nchw_gram_geometry(channels, kh, kw, pad, stride, per)) {
+        const int64_t direct = nchw_gram_bytes(batch, channels);
+        if (direct > need) need = direct;
+    }
+    return need;
 }
 
 extern "C" int tron_kfac_patch_gram(const float *x, int64_t batch, int32_t channels, int32_t height, int32_t width, int32_t kh,
@@ -639,11 +658,10 @@ extern "C" int tron_kfac_patch_gram(const float *x, int64_t batch, int32_t chann
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (batch == 0) return hipMemsetAsync(gram, 0, (size_t)d * d * sizeof(float), st) == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
     const int64_t per = (int64_t)OH * OW;
-    if (kh == 1 && kw == 1 && pad == 0 && stride == 1 && (channels == 32 || channels == 64) && per % 4 == 0 &&
-        (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+    if (nchw_gram_geometry(channels, kh, kw, pad, stride, per) && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
         // a gradient factor (or any 1x1 "patch matrix"): straight from the NCHW tensor, k_gram_nchw
-        const int nsplit = (int)(batch < 2048 ? batch : 2048);
-        float *partial = reinterpret_cast<float *>(workspace);           // nsplit * C * C floats (<= 32 MB: within every plan's total)
+        const int nsplit = nchw_gram_splits(batch);
+        float *partial = reinterpret_cast<float *>(workspace);           // nsplit * C * C floats = nchw_gram_bytes(): what _workspace() reserved
         if (channels == 64)
             hipLaunchKernelGGL(k_gram_nchw<64>, dim3(nsplit), dim3(256), 0, st, x, batch, (int)per, in_scale, nsplit, partial);
         else

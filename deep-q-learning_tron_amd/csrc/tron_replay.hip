@@ -336,6 +336,62 @@ int tron_replay_sample_codes(tron_replay_handle r, int32_t batch, int8_t *states
     return launch_status();
 }
 
+int tron_replay_get_cursor(tron_replay_handle r, int64_t *head, int64_t *size, uint32_t *sample_calls)
+{
+    if (!r) return TRON_ERR_BAD_ARG;
+    if (head) *head = r->head;
+    if (size) *size = r->size;
+    if (sample_calls) *sample_calls = r->calls;
+    return TRON_OK;
+}
+
+int tron_replay_set_cursor(tron_replay_handle r, int64_t head, int64_t size, uint32_t sample_calls)
+{
+    if (!r || head < 0 || head >= r->capacity || size < 0 || size > r->capacity) return TRON_ERR_BAD_ARG;
+    if (size < r->capacity && head != size) return TRON_ERR_BAD_ARG;     // a ring that has not wrapped yet fills from slot 0
+    r->head = head;
+    r->size = size;
+    r->calls = sample_calls;
+    return TRON_OK;
+}
+
+static int replay_copy(tron_replay_handle r, int64_t first, int64_t n, void *const user[5], bool to_ring, void *stream)
+{
+    if (bad(r)) return r ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
+    if (first < 0 || n < 0 || first + n > r->capacity) return TRON_ERR_BAD_ARG;
+    if (n == 0) return TRON_OK;
+    char *ring[5] = {reinterpret_cast<char *>(r->states) + (size_t)first * r->cells,
+                     reinterpret_cast<char *>(r->next_states) + (size_t)first * r->cells,
+                     reinterpret_cast<char *>(r->actions) + first, reinterpret_cast<char *>(r->rewards) + 4 * first,
+                     reinterpret_cast<char *>(r->dones) + first};
+    const size_t bytes[5] = {(size_t)n * r->cells, (size_t)n * r->cells, (size_t)n, 4 * (size_t)n, (size_t)n};
+    for (int k = 0; k < 5; ++k) {
+        if (!user[k]) continue;
+        void *dst = to_ring ? (void *)ring[k] : user[k];
+        const void *src = to_ring ? (const void *)user[k] : (const void *)ring[k];
+        if (hipMemcpyAsync(dst, src, bytes[k], hipMemcpyDeviceToDevice, S_(stream)) != hipSuccess) {
+            (void)hipGetLastError();
+            return TRON_ERR_LAUNCH;
+        }
+    }
+    return TRON_OK;
+}
+
+int tron_replay_export(tron_replay_handle r, int64_t first, int64_t n, int8_t *states, int8_t *next_states, int8_t *actions,
+                       float *rewards, int8_t *dones, void *stream)
+{
+    void *const user[5] = {states, next_states, actions, rewards, dones};
+    return replay_copy(r, first, n, user, false, stream);
+}
+
+int tron_replay_import(tron_replay_handle r, int64_t first, int64_t n, const int8_t *states, const int8_t *next_states,
+                       const int8_t *actions, const float *rewards, const int8_t *dones, void *stream)
+{
+    void *const user[5] = {const_cast<int8_t *>(states), const_cast<int8_t *>(next_states), const_cast<int8_t *>(actions),
+                           const_cast<float *>(rewards), const_cast<int8_t *>(dones)};
+    return replay_copy(r, first, n, user, true, stream);
+}
+
 int tron_replay_indices(tron_replay_handle r, int32_t batch, int64_t *indices_out, void *stream)
 {
     if (bad(r)) return r ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;

@@ -14,7 +14,7 @@ MODE = {None: 0, "none": 0, "ice": 1, "temper": 2}                 # tron/game.p
 OBS_NONE, OBS_CODES_I8, OBS_PLANES3_F32, OBS_PLANES4_F32 = 0, 1, 2, 3
 OBS = {None: OBS_NONE, "none": OBS_NONE, "codes": OBS_CODES_I8, "planes3": OBS_PLANES3_F32,
        "planes4": OBS_PLANES4_F32}
-ABI_VERSION = 7                                                    # include/tron_hip.h TRON_ABI_VERSION
+ABI_VERSION = 8                                                    # include/tron_hip.h TRON_ABI_VERSION
 STEP_AUTORESET = 1
 STEP_INCREMENTAL = 2
 STEP_NONREVERSING = 4
@@ -66,6 +66,10 @@ SIGNATURES = {
     "tron_replay_sample": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tron_replay_sample_codes": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tron_replay_size": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "tron_replay_get_cursor": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_u32)]),
+    "tron_replay_set_cursor": (C.c_int, [_vp, _i64, _i64, _u32]),
+    "tron_replay_export": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tron_replay_import": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tron_gemm_f16x3": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "tron_gemm_f16x3_workspace": (C.c_int64, [_i64, _i32, _i64]),
     "tron_absmax_pow2": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),

@@ -366,6 +366,49 @@ class DeviceReplay:
                                                          nat.ptr(d), nat.stream_ptr()), "tron_replay_sample_codes")
         return st, a, r, s2, d
 
+    def cursor(self):
+        """(write head, filled slots, sample() calls so far): tron_replay_get_cursor."""
+        head, size, calls = C.c_int64(), C.c_int64(), C.c_uint32()
+        nat.check(self._lib.tron_replay_get_cursor(self._h, C.byref(head), C.byref(size), C.byref(calls)), "tron_replay_get_cursor")
+        return head.value, size.value, calls.value
+
+    def state_dict(self, contents=True):
+        """The ring for a checkpoint ("replay head"): the cursor always; with contents=True also the filled
+        slots of all five arrays as HOST tensors (2 * cells + 6 bytes per slot: 1.35 GB for 1 M slots at 24x24 boards) —
+        slots [0, size), in ring order, so that load_state_dict puts every transition back where it was."""
+        head, size, calls = self.cursor()
+        out = {"capacity": self.capacity, "cells": self.cells, "head": head, "size": size, "sample_calls": calls}
+        if contents and size > 0:
+            dev = self.device
+            s = torch.empty(size, self.cells, dtype=torch.int8, device=dev)
+            s2 = torch.empty_like(s)
+            a = torch.empty(size, dtype=torch.int8, device=dev)
+            r = torch.empty(size, dtype=torch.float32, device=dev)
+            d = torch.empty(size, dtype=torch.int8, device=dev)
+            with torch.cuda.device(dev):
+                nat.check(self._lib.tron_replay_export(self._h, 0, size, nat.ptr(s), nat.ptr(s2), nat.ptr(a), nat.ptr(r), nat.ptr(d),
+                                                       nat.stream_ptr()), "tron_replay_export")
+            out.update(states=s.cpu(), next_states=s2.cpu(), actions=a.cpu(), rewards=r.cpu(), dones=d.cpu())
+        return out
+
+    def load_state_dict(self, sd):
+        """Inverse of state_dict(): the cursor, and the contents when the checkpoint holds them (a cursor-only checkpoint
+        into a ring that has fewer slots filled than it claims is refused: sampling would read slots nobody wrote)."""
+        if int(sd["capacity"]) != self.capacity or int(sd["cells"]) != self.cells:
+            raise ValueError(f"checkpointed ring is {sd['capacity']} x {sd['cells']}, this one {self.capacity} x {self.cells}")
+        size = int(sd["size"])
+        if "states" in sd:
+            dev = self.device
+            t = [sd[k].to(dev).contiguous() for k in ("states", "next_states", "actions", "rewards", "dones")]
+            if t[0].shape != (size, self.cells) or t[0].dtype != torch.int8 or t[3].dtype != torch.float32:
+                raise ValueError("checkpointed ring contents do not match its cursor")
+            with torch.cuda.device(dev):
+                nat.check(self._lib.tron_replay_import(self._h, 0, size, *[nat.ptr(x) for x in t], nat.stream_ptr()), "tron_replay_import")
+                torch.cuda.current_stream().synchronize()              # (t is freed on return)
+        elif size > len(self):
+            raise ValueError("cursor-only replay checkpoint: the ring holds fewer transitions than the cursor says")
+        nat.check(self._lib.tron_replay_set_cursor(self._h, int(sd["head"]), size, int(sd["sample_calls"])), "tron_replay_set_cursor")
+
     def last_indices(self, batch):
         out = torch.empty(batch, dtype=torch.int64, device=self.device)
         with torch.cuda.device(self.device):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TRON_ABI_VERSION 7
+#define TRON_ABI_VERSION 8
 
 typedef enum {
     TRON_OK = 0,
@@ -219,6 +219,17 @@ int tron_replay_sample(tron_replay_handle r, int32_t batch, int32_t channels, fl
 int tron_replay_sample_codes(tron_replay_handle r, int32_t batch, int8_t *states, int64_t *actions, float *rewards,
                              int8_t *next_states, float *dones, void *stream);
 int tron_replay_size(tron_replay_handle r, int64_t *size, int64_t *capacity);
+/* Checkpointing the ring (SURVEY 8(f)4 "replay head"; the reference keeps its deque in host memory and never saves it,
+ * DDQN.py:326).  The cursor is the write head, the fill level and the sampler's call counter (the Philox counter of the next
+ * draw): restoring it makes a resumed run push to the same slots and draw the same batches.  export / import copy the slots
+ * [first, first + n) (no wrap: first + n <= capacity) of all five arrays between the ring and caller-owned DEVICE buffers:
+ * states / next_states int8[n][cells], actions int8[n], rewards f32[n], dones int8[n]; any of them may be NULL (skipped). */
+int tron_replay_get_cursor(tron_replay_handle r, int64_t *head, int64_t *size, uint32_t *sample_calls);
+int tron_replay_set_cursor(tron_replay_handle r, int64_t head, int64_t size, uint32_t sample_calls);
+int tron_replay_export(tron_replay_handle r, int64_t first, int64_t n, int8_t *states, int8_t *next_states,
+                       int8_t *actions, float *rewards, int8_t *dones, void *stream);
+int tron_replay_import(tron_replay_handle r, int64_t first, int64_t n, const int8_t *states, const int8_t *next_states,
+                       const int8_t *actions, const float *rewards, const int8_t *dones, void *stream);
 
 /* C f32[M][N] = A B^T + bias[n] on the split-f16 matrix cores (operands split in two halves, three MFMAs per slab, f32
  * accumulation: relative error ~1e-6), f32 in and out — the dense products of the training-path head (conv7 in its dense

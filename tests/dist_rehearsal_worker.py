@@ -46,13 +46,35 @@ def main(out_dir):
 
     out = DDQN.train(n_envs=N, width=W, steps=12, learn_every=2, batch_size=64, capacity=1 << 14, log_every=0, seed=seed)
     brain = out["brain"]
+    # the side-stream branch of learn(defer=True) (world > 1: the all-reduce on its own stream, the update applied
+    # by finish_learn) against learn(defer=False) on the same batches — same parameters, on every rank.
+    import copy
+    brain.finish_learn()
+    mem, brain.memory, brain._side = brain.memory, None, None            # (the ring's handle and the stream are not copyable; both agents share the ring)
+    twin = copy.deepcopy(brain)
+    brain.memory = mem
+    twin.optimizer = torch.optim.Adam(twin.qnetwork_local.parameters(), fused=bool(brain.optimizer.defaults.get("fused")))
+    twin.optimizer.load_state_dict(brain.optimizer.state_dict())
+    twin.memory = brain.memory
+    twin._side = None
+    for net in (brain.qnetwork_local, twin.qnetwork_local):
+        net.dropout.p = 0.0
+    deferred_equal = True
+    for k in range(3):
+        batch = brain.memory.sample_codes()
+        l1 = brain.learn(batch, DDQN.GAMMA, defer=True)
+        assert brain._pending and brain._pending_on_side                  # the branch under test
+        brain.finish_learn()
+        l2 = twin.learn(batch, DDQN.GAMMA, defer=False)
+        deferred_equal &= bool(torch.equal(l1, l2))
+    deferred_equal &= all(bool(torch.equal(p, q)) for p, q in zip(brain.qnetwork_local.parameters(), twin.qnetwork_local.parameters()))
     flat = torch.cat([p.detach().reshape(-1) for p in brain.qnetwork_local.parameters()]).cpu().numpy()
     tflat = torch.cat([p.detach().reshape(-1) for p in brain.qnetwork_target.parameters()]).cpu().numpy()
     # each rank's replay shard holds its own transitions
     brain.memory.sample()
     idx = brain.memory.memory.last_indices(64).cpu().numpy()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), obs=obs_np, oracle_equal=same, local=flat, target=tflat,
-             learn_steps=out["learn_steps"], games=out["games"], env_steps=out["env_steps"], world=world, idx=idx)
+             learn_steps=out["learn_steps"], deferred_equal=deferred_equal, games=out["games"], env_steps=out["env_steps"], world=world, idx=idx)
     dist.barrier()
     dist.destroy_process_group()
 

