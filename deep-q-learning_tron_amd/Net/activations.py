@@ -312,6 +312,82 @@ class _TrunkHIP(torch.autograd.Function):
         return tuple(grads)
 
 
+class _TrunkPX(torch.autograd.Function):
+    """conv1 .. conv6 (DQNNet.py:33-50) from the env's int8 codes as ONE autograd node on the weight-stationary design
+    (csrc/tron_conv_ws_train.hip): the forward is the gradient-free chain's kernel keeping every pre-activation as a PX16 image,
+    the backward runs each input gradient as that same kernel on the rotated weights — residual gradient, mish' of the layer
+    below, its bias sums and the next scale in the epilogue — and each weight gradient straight from the two PX16 images
+    (transposed LDS reads).  No f32 NCHW tensor exists between conv1's output and conv6's output; the head reads conv6's f32
+    output, conv1's weight gradient (3 or 4 planes -> 32: plain f32 FMAs) reads an f32 gradient the last input-gradient launch
+    also writes."""
+
+    @staticmethod
+    def forward(ctx, codes, plane4, *wb):
+        from Net import fused
+        w, b = wb[0::2], wb[1::2]
+        frag = fused._split_jobs(list(w[1:]), "tron_conv3x3_ws_split_weights", False)
+        a1, z1 = fused.conv1_px16_train(codes, w[0], b[0], plane4)
+        a2, z2 = fused.conv_ws_train(a1, 32, frag[0], b[1])
+        a3, z3 = fused.conv_ws_train(a2, 32, frag[1], b[2], residual=a1)
+        a4, z4 = fused.conv_ws_train(a3, 64, frag[2], b[3])
+        a5, z5 = fused.conv_ws_train(a4, 64, frag[3], b[4])
+        out, z6 = fused.conv_ws_train(a5, 64, frag[4], b[5], residual=a4, want_f32=True)
+        ctx.save_for_backward(codes, a1.buf, a2.buf, a3.buf, a4.buf, a5.buf, z1.buf, z2.buf, z3.buf, z4.buf, z5.buf, z6.buf, *w)
+        ctx.plane4 = plane4
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from Net import fused
+        codes, a1, a2, a3, a4, a5, z1, z2, z3, z4, z5, z6, *w = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if not _aligned16(g):
+            g = g.clone(memory_format=torch.contiguous_format)
+        B, S = g.shape[0], g.shape[-1]
+        need = ctx.needs_input_grad                                 # (codes, plane4, w1, b1, ..., w6, b6)
+        px = lambda buf, c: fused._px((B, c, S, S), buf)
+        rot, wn = fused._split_jobs(list(w[1:]), "tron_conv3x3_ws_split_weights_bwd", True)      # conv2 .. conv6, one launch
+        gb, gw = [None] * 6, [None] * 6
+        gp6, gb[5] = fused.grad_px_from_f32(g, px(z6, 64))
+        del g
+        gw[5] = fused.conv3x3_wgrad_px(px(a5, 64), gp6) if need[12] else None
+        gp5, _, gb[4] = fused.conv_ws_dgrad(gp6, 64, rot[4], wn[4:5], px(z5, 64))
+        gw[4] = fused.conv3x3_wgrad_px(px(a4, 64), gp5) if need[10] else None
+        gp4, _, gb[3] = fused.conv_ws_dgrad(gp5, 64, rot[3], wn[3:4], px(z4, 64), extra=gp6)      # a4 also feeds conv6's residual
+        del gp5, gp6
+        gw[3] = fused.conv3x3_wgrad_px(px(a3, 32), gp4) if need[8] else None
+        gp3, _, gb[2] = fused.conv_ws_dgrad(gp4, 32, rot[2], wn[2:3], px(z3, 32))
+        del gp4
+        gw[2] = fused.conv3x3_wgrad_px(px(a2, 32), gp3) if need[6] else None
+        gp2, _, gb[1] = fused.conv_ws_dgrad(gp3, 32, rot[1], wn[1:2], px(z2, 32))
+        gw[1] = fused.conv3x3_wgrad_px(px(a1, 32), gp2) if need[4] else None
+        _, gp1, gb[0] = fused.conv_ws_dgrad(gp2, 32, rot[0], wn[0:1], px(z1, 32), extra=gp3, want_px=False, want_f32=True)   # a1 also feeds conv3's residual
+        del gp2, gp3
+        if need[2]:
+            from tron.vec import pop_up_planes
+            planes = pop_up_planes(codes)
+            if w[0].shape[1] == 4:
+                planes = torch.cat([planes, torch.full_like(planes[:, :1], ctx.plane4)], 1)
+            if fused.wgrad_supported(w[0], S):
+                gw[0] = fused.conv3x3_wgrad(planes, gp1)
+            else:
+                gw[0] = torch.ops.aten.convolution_backward(gp1, planes, w[0], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                            [False, True, False])[1]
+        grads = [None, None]
+        for k in range(6):
+            grads += [gw[k], gb[k] if need[3 + 2 * k] else None]
+        return tuple(grads)
+
+
+def trunk_px_supported(net, x):
+    """Can `_TrunkPX` run conv1..conv6 of `net` on x?  int8 codes [B, S, S] at 12x12 / 26x26, the DQN trunk's channel plan."""
+    from Net import fused
+    return (fused.use_trunk_px and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.int8 and x.dim() == 3 and x.numel() > 0
+            and fused.default_math == "f16x3" and fused.ws_supported(net, x.shape[-1]) and x.shape[-2] == x.shape[-1]
+            and [(c.in_channels, c.out_channels) for c in (net.conv2, net.conv3, net.conv4, net.conv5, net.conv6)]
+            == [(32, 32), (32, 32), (32, 64), (64, 64), (64, 64)])
+
+
 def trunk_supported(net, x):
     """Can `_TrunkHIP` run conv1..conv6 of `net` on x (f32 planes [B, C, S, S] or int8 codes [B, S, S])?"""
     from Net import fused
@@ -336,6 +412,8 @@ def trunk_mish(net, x, plane4=0.0):
     wb = []
     for c in (net.conv1, net.conv2, net.conv3, net.conv4, net.conv5, net.conv6):
         wb += [c.weight, c.bias]
+    if trunk_px_supported(net, x):
+        return _TrunkPX.apply(x.contiguous(), float(plane4), *wb)
     return _TrunkHIP.apply(x.contiguous(), float(plane4), *wb)
 
 

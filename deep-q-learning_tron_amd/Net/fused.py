@@ -255,6 +255,150 @@ def trunk_px(net, codes, plane4=0.0, want="f32"):
     return conv_ws(e, net.conv6, w[4], residual=d, want_px=False, want_f32=True)
 
 
+# ---- the learner's trunk on the weight-stationary design (csrc/tron_conv_ws_train.hip): forward keeps a_k and z_k as PX16 images,
+# ---- gradients travel as PX16 "gradient images" (value * a power-of-two scale kept in a device record) -------------------
+use_trunk_px = _os.environ.get("TRON_TRUNK_PX", "1") != "0"
+
+
+class GradPX:
+    """A gradient tensor [batch, channels, side, side] as a PX16 image of g * s, with its device record info = {s, 1 / s,
+    max |g|, -} (include/tron_hip.h): s is a power of two chosen before the producing kernel runs."""
+
+    def __init__(self, batch, channels, side, device):
+        self.shape = (batch, channels, side, side)
+        self.buf = torch.empty(batch * channels * side * side * 4, dtype=torch.uint8, device=device)
+        self.info = torch.zeros(4, dtype=torch.float32, device=device)
+
+    def float(self):
+        px = PX16.__new__(PX16)
+        px.shape, px.buf = self.shape, self.buf
+        return px.float() * self.info[1]
+
+
+def _px(shape, buf):
+    px = PX16.__new__(PX16)
+    px.shape, px.buf = tuple(shape), buf
+    return px
+
+
+def _split_jobs(weights, fn_name, transposed):
+    """Fragment images of several weight tensors [cout, cin, 3, 3] in ONE launch; transposed: the input gradient's
+    (rotated, transposed) fragments, plus the bound factors wnorm [n]."""
+    import ctypes as C
+    L = nat.lib()
+    n = len(weights)
+    dev = weights[0].device
+    shapes = [(w.shape[1], w.shape[0]) for w in weights]                                  # (cin, cout) of the forward layers
+    sizes = [(int(L.tron_conv3x3_ws_workspace(*((co, ci) if transposed else (ci, co)))) + 255) // 256 * 256 for ci, co in shapes]
+    buf = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+    views, off = [], 0
+    for sz in sizes:
+        views.append(buf[off:off + sz])
+        off += sz
+    ws = [w.detach() if w.is_contiguous() else w.detach().contiguous() for w in weights]
+    wp = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
+    vp = (C.c_void_p * n)(*[v.data_ptr() for v in views])
+    ci = (C.c_int32 * n)(*[c for c, _ in shapes])
+    co = (C.c_int32 * n)(*[c for _, c in shapes])
+    with torch.cuda.device(dev):
+        if transposed:
+            wn = torch.empty(n, dtype=torch.float32, device=dev)
+            nat.check(L.tron_conv3x3_ws_split_weights_bwd(wp, ci, co, vp, nat.ptr(wn), n, nat.stream_ptr()), fn_name)
+            return views, wn
+        nat.check(L.tron_conv3x3_ws_split_weights(wp, ci, co, vp, n, nat.stream_ptr()), fn_name)
+    return views
+
+
+def conv1_px16_train(codes, weight, bias, plane4=0.0):
+    """mish(conv1(pop_up(codes)) + bias) and its pre-activation, both PX16 [B, 32, S, S] (tron_conv1_px16_train)."""
+    c = codes.contiguous()
+    B, S = c.shape[0], c.shape[-1]
+    a, z = PX16(B, weight.shape[0], S, c.device), PX16(B, weight.shape[0], S, c.device)
+    w = weight.detach()
+    with torch.cuda.device(c.device):
+        nat.check(nat.lib().tron_conv1_px16_train(nat.ptr(c), nat.ptr(w if w.is_contiguous() else w.contiguous()), nat.ptr(bias.detach()),
+                                                  weight.shape[1], float(plane4), B, S, nat.ptr(a.buf), nat.ptr(z.buf), nat.stream_ptr()),
+                  "tron_conv1_px16_train")
+    return a, z
+
+
+def conv_ws_train(x, cout, wfrag, bias, residual=None, want_f32=False):
+    """mish(conv3x3(x) + bias + residual) with the pre-activation kept: x PX16 -> (PX16 output — or, want_f32, the f32 NCHW
+    output the head reads —, PX16 pre-activation)   (tron_conv3x3_ws_train_fwd)."""
+    B, cin, S, _ = x.shape
+    dev = x.buf.device
+    z = PX16(B, cout, S, dev)
+    out = None if want_f32 else PX16(B, cout, S, dev)
+    o32 = torch.empty(B, cout, S, S, dtype=torch.float32, device=dev) if want_f32 else None
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().tron_conv3x3_ws_train_fwd(nat.ptr(x.buf), nat.ptr(wfrag), nat.ptr(bias.detach()),
+                                                      nat.ptr(None if residual is None else residual.buf), nat.ptr(None if out is None else out.buf),
+                                                      nat.ptr(o32), nat.ptr(z.buf), B, cin, cout, S, nat.stream_ptr()), "tron_conv3x3_ws_train_fwd")
+    return (o32 if want_f32 else out), z
+
+
+def grad_px_from_f32(g, z):
+    """The gradient chain's entry: (g * mish'(z)) as a gradient image + the column sums (the layer's bias gradient);
+    g f32 [B, C, S, S], z the layer's PX16 pre-activation."""
+    L = nat.lib()
+    B, C, S, _ = g.shape
+    dev = g.device
+    sc = torch.zeros(4, dtype=torch.float32, device=dev)
+    out = GradPX(B, C, S, dev)
+    gb = torch.empty(C, dtype=torch.float32, device=dev)
+    ws = torch.empty(int(L.tron_px16_grad_workspace(B, C)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(L.tron_absmax_pow2(nat.ptr(g), g.numel(), 14, nat.ptr(sc), nat.stream_ptr()), "tron_absmax_pow2")
+        nat.check(L.tron_px16_grad_from_f32(nat.ptr(g), nat.ptr(z.buf), nat.ptr(sc), B, C, S, nat.ptr(out.buf), nat.ptr(out.info), nat.ptr(gb),
+                                            nat.ptr(ws), nat.stream_ptr()), "tron_px16_grad_from_f32")
+    return out, gb
+
+
+def conv_ws_dgrad(gp, cin, wfrag_rot, wnorm, z_below, extra=None, want_px=True, want_f32=False):
+    """(conv^T(gp, W) + extra) * mish'(z_below): gp a GradPX with the forward layer's cout channels -> (GradPX with cin channels
+    or None, f32 NCHW or None, bias gradient of the layer below [cin])   (tron_conv3x3_ws_dgrad)."""
+    L = nat.lib()
+    B, cout, S, _ = gp.shape
+    dev = gp.buf.device
+    out = GradPX(B, cin, S, dev)
+    if not want_px:
+        out.buf = None
+    o32 = torch.empty(B, cin, S, S, dtype=torch.float32, device=dev) if want_f32 else None
+    gb = torch.empty(cin, dtype=torch.float32, device=dev)
+    nbytes = int(L.tron_conv3x3_ws_dgrad_workspace(cin, cout))
+    if nbytes <= 0:
+        raise nat.TronNativeError(f"tron_conv3x3_ws_dgrad: no kernel for cin={cin} cout={cout}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(L.tron_conv3x3_ws_dgrad(nat.ptr(gp.buf), nat.ptr(gp.info), nat.ptr(wfrag_rot), nat.ptr(wnorm),
+                                          nat.ptr(None if extra is None else extra.buf), nat.ptr(None if extra is None else extra.info),
+                                          nat.ptr(z_below.buf), nat.ptr(out.buf), nat.ptr(o32), nat.ptr(out.info), nat.ptr(gb), B, cin, cout, S,
+                                          nat.ptr(ws), nat.stream_ptr()), "tron_conv3x3_ws_dgrad")
+    return (out if want_px else None), o32, gb
+
+
+def wgrad_px_supported(cin, cout, side):
+    return side in (12, 26) and (cin, cout) in _WS_SHAPES
+
+
+def conv3x3_wgrad_px(a, gp):
+    """Weight gradient of conv3x3 from the layer's input a (PX16) and the gradient image at its output -> f32 [cout, cin, 3, 3]
+    (tron_conv3x3_wgrad_px16)."""
+    L = nat.lib()
+    B, cin, S, _ = a.shape
+    cout = gp.shape[1]
+    dev = a.buf.device
+    nbytes = int(L.tron_conv3x3_wgrad_px16_workspace(B, cin, cout, S))
+    if nbytes <= 0:
+        raise nat.TronNativeError(f"tron_conv3x3_wgrad_px16: no kernel for cin={cin} cout={cout} side={S}")
+    gw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=dev)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(L.tron_conv3x3_wgrad_px16(nat.ptr(a.buf), nat.ptr(gp.buf), nat.ptr(gp.info), nat.ptr(gw), B, cin, cout, S, nat.ptr(ws),
+                                            nat.stream_ptr()), "tron_conv3x3_wgrad_px16")
+    return gw
+
+
 def conv3x3_dgrad(gp, weight, absmax=None):
     """Input gradient of conv3x3(x, weight, padding=1): gp f32 [B, Cout, S, S] (the gradient at the convolution's output),
     weight the FORWARD layer's [Cout, Cin, 3, 3] -> f32 [B, Cin, S, S] (tron_conv3x3_dgrad).  absmax: per-block maxima of

@@ -1,0 +1,580 @@
+// tron_conv_ws_train.hip — the LEARNER's side of the weight-stationary design (DDQN.py:115-151 on DQNNet.py:33-50): the trunk's
+// forward, input gradients and weight gradients with every tensor between two layers a PX16 image — no f32 NCHW activation,
+// pre-activation or gradient tensor exists between conv1 and conv6.
+//
+//   forward    k_conv_ws<WS_TRAIN> (tron_conv_ws_kernel.hpp): the gradient-free chain's kernel, which also keeps each layer's
+//              pre-activation z as a PX16 image (what mish'(z) is computed from on the way back);
+//   gradient images: a gradient tensor g is stored as PX16 of g * s, s a power of two kept beside the image in a 4-float
+//              record {s, 1 / s, max |g|, -} on the device.  Gradients are 1e-6-sized after a mean-reduced loss: s brings them
+//              into f16's range.  s must be known BEFORE the kernel that writes the image runs, so it is chosen from a bound:
+//              max |conv^T(g) + r| <= max |g| * (largest absolute row sum of the rotated weights) + max |r|, times mish' <= 1.1;
+//              s = the power of two that maps that bound to at most 2^15 — no overflow, and the true maximum (typically 10-30x
+//              below the bound) sits ~2^10 above f16's normal minimum: hi + lo keep 22 bits wherever it matters;
+//   k_gout_px  the chain's entry: g (f32 NCHW, from the head's backward) * mish'(z6) -> gradient image + bias sums + max;
+//   input gradient   k_conv_ws<WS_BWD>: the same loop on the rotated, transposed weights, epilogue = (+ residual gradient) *
+//              mish'(z below), column sums (the layer below's bias gradient), max, PX16 store at the next scale;
+//   weight gradient  k_wgrad_px: dW[co][ci][tap] = sum over pixels of g[co][p] * a[ci][p + tap] straight from the two
+//              pixel-major images: K = pixels, both MFMA operands read TRANSPOSED out of LDS (ds_read_b64_tr_b16: a lane
+//              supplies the address of one pixel row and receives one channel column, so the nine taps are address offsets
+//              into a zero-haloed window and no operand is ever converted, shifted in registers or im2col-ed).
+#include "tron_conv_ws_kernel.hpp"
+
+namespace {
+
+// ---- scales ------------------------------------------------------------------------------------------------------------
+// largest absolute row sum of the rotated weights of a layer: max over the backward convolution's output channel (= the
+// forward layer's input channel ci) of sum_{co, tap} |W[co][ci][tap]|
+__global__ __launch_bounds__(64) void k_ws_wnorm(WsJobs jobs, float *__restrict__ wnorm)
+{
+    const int k = blockIdx.x, cinF = jobs.cout[k], coutF = jobs.cin[k];  // (rot jobs carry the backward convolution's cout / cin)
+    const float *__restrict__ w = jobs.w[k];
+    float m = 0.0f;
+    for (int ci = threadIdx.x; ci < cinF; ci += 64) {
+        float s = 0.0f;
+        for (int co = 0; co < coutF; ++co)
+            for (int t = 0; t < 9; ++t) s += __builtin_fabsf(w[((size_t)co * cinF + ci) * 9 + t]);
+        m = __builtin_fmaxf(m, s);
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, d, 64));
+    if (threadIdx.x == 0) wnorm[k] = m;
+}
+
+__device__ __forceinline__ float pow2_at_most(float x)                   // the largest power of two <= x (x > 0, finite); exponent clamped to +-60
+{
+    int e = (int)((__float_as_uint(x) >> 23) & 0xFFu) - 127;
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+    return __uint_as_float((uint32_t)(e + 127) << 23);
+}
+
+// scal = {1 / s_in, 1 / s_res, s_out, -} for one k_conv_ws<WS_BWD> launch; out_info = {s_out, 1 / s_out, (max: k_wsb_finish), -}
+__global__ void k_wsb_scale(const float *__restrict__ in_info, const float *__restrict__ res_info, const float *__restrict__ wnorm,
+                            float *__restrict__ scal, float *__restrict__ out_info)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float bound = (in_info[2] * wnorm[0] + (res_info ? res_info[2] : 0.0f)) * 1.1f;
+    const float s = bound > 0.0f && bound < 3.0e38f ? pow2_at_most(32768.0f / bound) : 1.0f;
+    scal[0] = in_info[1];
+    scal[1] = res_info ? res_info[1] : 1.0f;
+    scal[2] = s;
+    scal[3] = 0.0f;
+    out_info[0] = s;
+    out_info[1] = 1.0f / s;
+}
+
+// stats[2][groups][C] of a k_conv_ws<WS_BWD> (or k_gout_px) launch -> bias_grad[c] = the column sums, added in a fixed order,
+// and info[2] = the largest magnitude written; one workgroup, one thread per channel
+__global__ __launch_bounds__(64) void k_wsb_finish(const float *__restrict__ stats, int groups, int C, float *__restrict__ bias_grad,
+                                                   float *__restrict__ info)
+{
+    const int c = threadIdx.x;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, m = 0.0f;
+    if (c < C) {
+        int gidx = 0;
+        for (; gidx + 3 < groups; gidx += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += stats[(size_t)(gidx + k) * C + c];
+        }
+        for (int k = 0; gidx < groups; ++gidx, ++k) acc[k] += stats[(size_t)gidx * C + c];
+        for (int q = 0; q < groups; ++q) m = __builtin_fmaxf(m, stats[((size_t)groups + q) * C + c]);
+        if (bias_grad) bias_grad[c] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, d, 64));
+    if (threadIdx.x == 0) info[2] = m;
+}
+
+// ---- the chain's entry: gp = g * mish'(z) as a gradient image ----------------------------------------------------------
+// g: f32 [B][C][SS] (the gradient at the trunk's output, from the head's backward), z: PX16 pre-activation of the last layer.
+// blockIdx = (image group, channel octet); a thread walks pixels of its group's images: 8 channels x one pixel at a time
+// (coalesced along the pixels of each channel row), keeps the 8 column sums and the maximum, and the block leaves them in
+// stats[2][groups][C] (k_wsb_finish).  info_in = tron_absmax_pow2's {s, max |g|, ...}: s brings max |g| below 2^14, and
+// |mish'| <= 1.1 keeps the product below 2^15.
+__global__ __launch_bounds__(256) void k_gout_px(const float *__restrict__ gout, const unsigned char *__restrict__ z, int64_t B, int C,
+                                                 int SS, const float *__restrict__ scale4, unsigned char *__restrict__ out,
+                                                 float *__restrict__ stats, float *__restrict__ info)
+{
+    __shared__ float red[256 * 9];
+    const int oct = blockIdx.y, groups = gridDim.x, grp = blockIdx.x;
+    const float s = scale4[0];
+    if (grp == 0 && oct == 0 && threadIdx.x == 0) { info[0] = s; info[1] = 1.0f / s; }
+    const int64_t per = (B + groups - 1) / groups, i0 = grp * per, i1 = i0 + per < B ? i0 + per : B;
+    const size_t half = (size_t)(C / 8) * SS * 16;
+    float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mx = 0.0f;
+    const int64_t total = (i1 > i0 ? i1 - i0 : 0) * SS;
+    for (int64_t i = threadIdx.x; i < total; i += 256) {
+        const int64_t img = i0 + i / SS;
+        const int p = (int)(i % SS);
+        const unsigned char *zp = z + (size_t)img * 2 * half + ((size_t)oct * SS + p) * 16;
+        const f16x8 zh = *reinterpret_cast<const f16x8 *>(zp), zl = *reinterpret_cast<const f16x8 *>(zp + half);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float zz = ((float)zh[j] + (float)zl[j] * LO_UNSCALE) * ACT_UNSCALE;
+            const float gg = gout[((size_t)img * C + oct * 8 + j) * SS + p];
+            const uint32_t eb = __float_as_uint(__builtin_amdgcn_exp2f(zz * 1.44269504088896341f));
+            const float e = __uint_as_float(eb < 0x5D5E0B6Bu ? eb : 0x5D5E0B6Bu);
+            const float n = e * (e + 2.0f), r = __builtin_amdgcn_rcpf(n + 2.0f), t = n * r;
+            const float m = t + zz * ((r + r) * (t + 1.0f)) * (e * __builtin_amdgcn_rcpf(e + 1.0f));
+            v[j] = gg * m;
+            sum[j] += v[j];
+            mx = __builtin_fmaxf(mx, __builtin_fabsf(v[j]));
+            v[j] *= s * ACT_SCALE;
+        }
+        f16x8 hh, ll;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hh[j] = (f16)v[j];
+            ll[j] = (f16)((v[j] - (float)hh[j]) * LO_SCALE);
+        }
+        unsigned char *op = out + (size_t)img * 2 * half + ((size_t)oct * SS + p) * 16;
+        *reinterpret_cast<f16x8 *>(op) = hh;
+        *reinterpret_cast<f16x8 *>(op + half) = ll;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[j * 256 + threadIdx.x] = sum[j];
+    red[8 * 256 + threadIdx.x] = mx;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[j * 256 + threadIdx.x] += red[j * 256 + threadIdx.x + d];
+            red[8 * 256 + threadIdx.x] = __builtin_fmaxf(red[8 * 256 + threadIdx.x], red[8 * 256 + threadIdx.x + d]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 8) {
+        stats[(size_t)grp * C + oct * 8 + threadIdx.x] = red[threadIdx.x * 256];
+        stats[((size_t)groups + grp) * C + oct * 8 + threadIdx.x] = red[8 * 256];
+    }
+}
+
+// ---- the weight gradient from two PX16 images ----------------------------------------------------------------------------
+// GEMM view: M = output channels (A = the gradient image), N = input channels (B = the activation image, shifted per tap),
+// K = pixels.  Geometry of one instantiation:
+//   S     image side;  NI images stacked per "stack" (12x12: 2, so that 8-row bands are whole 32-pixel slabs: 96 = 3 x 32);
+//   R     rows of the stack per band; a band's gradient pixels are contiguous in memory, its activation window brings one
+//         halo row above and below (and the all-zero separator row between two stacked images);
+//   COT / CIT  the channels of each operand one workgroup holds (a 64-channel layer at 26x26 is split over two workgroup
+//         kinds by input channels: 64 + 64 channels of both operands, double-buffered, do not fit 160 KB);
+//   a wave owns a (32 co) x (16 ci) block and all nine taps — 2 x 9 x 2 accumulator tiles = 144 registers — and the slabs
+//   s = kgroup, kgroup + KG, ... of every item; waves = blocks x KG = 8.
+// A workgroup serves ONE band index (its DMA source table, built once, is the band's), bands get workgroups in proportion to
+// their slabs.  An item = (stack, band): both operands go global -> LDS by LDS-DMA through a per-unit source table (a unit
+// whose destination is halo, separator, padding pixel or plane padding copies from a zero page), double-buffered one item
+// ahead, one barrier per item, the next item's pieces riding between the taps' MFMAs.
+template <int S_, int NI_, int R_, int COT_, int CIT_, int KG_>
+struct WCfg {
+    static constexpr int S = S_, NI = NI_, R = R_, COT = COT_, CIT = CIT_, KG = KG_;
+    static constexpr int SS = S * S, ROWS = NI * S, NB = (ROWS + R - 1) / R;
+    static constexpr int GPX = R * S, NSLAB = (GPX + 31) / 32, GP = NSLAB * 32;
+    static constexpr int WR = R + 2 + (NI - 1), WC = S + 2;
+    static constexpr int odd128(int x) { return ((x + 127) / 256) * 256 + 128; }     // smallest y >= x with y = 128 (mod 256)
+    static constexpr int G_PLANE = odd128(GP * 16), A_PLANE = odd128(WR * WC * 16);
+    static constexpr int G_HALF = (COT / 8) * G_PLANE, A_HALF = (CIT / 8) * A_PLANE;
+    static constexpr int A_OFF = 2 * G_HALF;
+    static constexpr int ITEM = (2 * G_HALF + 2 * A_HALF + 1023) / 1024 * 1024;
+    static constexpr int NPIECE = ITEM / 1024, PPW = (NPIECE + 7) / 8;
+    static constexpr int TAB_OFF = 2 * ITEM, TAB_BYTES = 8 * PPW * 128;
+    static constexpr int LDS = TAB_OFF + TAB_BYTES + 1024;               // + the sink of a piece past the item's end
+    static constexpr int NBLK = (COT / 32) * (CIT / 16);
+    static_assert(NBLK * KG == 8, "eight waves");
+    static_assert(LDS <= 160 * 1024, "LDS");
+    static_assert(2 * NI * 8 * SS < 0xFFFF, "source offsets in 16 bits");
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x8 lds_tr8(const unsigned char *p0, const unsigned char *p1)   // two ds_read_b64_tr_b16 (EXEC all ones)
+{
+    typedef __attribute__((address_space(3))) s16x4 lds_v;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v *)p0), b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v *)p1);
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(f16x8, v);
+}
+
+// row index (with halo and separator rows counted) of stack row t: image i = t / S occupies e = i (S + 1) + 1 ... i (S + 1) + S
+template <class C> __device__ __forceinline__ int stack_e(int t) { return t + t / C::S + 1; }
+
+struct WBands { int n[8]; };                                             // workgroups per band
+
+template <class C>
+__global__ __launch_bounds__(512, 2) void k_wgrad_px(const unsigned char *__restrict__ gimg, const unsigned char *__restrict__ aimg,
+                                                     int B, int CO, int CI, int kinds, WBands bands, float *__restrict__ partial)
+{
+    constexpr int S = C::S, SS = C::SS;
+    extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, g = lane >> 4;
+    // workgroup kinds = the (co, ci) channel tiles of a layer one workgroup does not hold whole.  The kinds of one item sit 8
+    // blocks apart — the same XCD under round-robin placement — so the operand they share is read from memory once (speed only).
+    const int kind = ((int)blockIdx.x >> 3) % kinds, wg = (((int)blockIdx.x >> 3) / kinds) * 8 + ((int)blockIdx.x & 7);
+    const int nci = CI / C::CIT, co0 = (kind / nci) * C::COT, ci0 = (kind % nci) * C::CIT;
+    // this workgroup's band, its index among the band's workgroups and their number
+    int band = 0, wb = wg, nwb = bands.n[0];
+    while (wb >= nwb && band + 1 < C::NB) { wb -= nwb; ++band; nwb = bands.n[band]; }
+    if (wb >= nwb) return;                                               // (the grid is rounded up to whole groups of 8 x kinds)
+    const int r0 = band * C::R, nrows = (C::ROWS - r0 < C::R) ? C::ROWS - r0 : C::R, npx = nrows * S;
+    const int nslab = (npx + 31) >> 5;
+    const int e0 = stack_e<C>(r0) - 1, e_last = stack_e<C>(r0 + nrows - 1) + 1;   // the window's first and last row (halo rows included)
+    const int blk = wave % C::NBLK, kgroup = wave / C::NBLK;
+    const int cot2 = blk / (C::CIT / 16), cit = blk % (C::CIT / 16);
+
+    for (int i = tid * 16; i < C::TAB_OFF; i += 512 * 16) *reinterpret_cast<uint4 *>(lds + i) = make_uint4(0u, 0u, 0u, 0u);
+
+    // the DMA source table: unit u (16 bytes) of the item buffer <- unit tab[u] of the stack's gradient / activation images,
+    // or 0xFFFF: zeros.  Piece j of this wave = piece wave + 8 j of the item.
+    uint16_t *tab = reinterpret_cast<uint16_t *>(lds + C::TAB_OFF) + wave * C::PPW * 64;
+    const size_t g_img_units = (size_t)2 * (CO / 8) * SS, a_img_units = (size_t)2 * (CI / 8) * SS;   // 16-byte units of one image
+    for (int j = 0; j < C::PPW; ++j) {
+        const int d = (wave + 8 * j) * 1024 + lane * 16;
+        int off = -1;
+        if (d < C::A_OFF) {                                              // gradient: [hi | lo][octet][pixel of the band]
+            const int h = d / C::G_HALF, d1 = d - h * C::G_HALF, o = d1 / C::G_PLANE, px = (d1 - o * C::G_PLANE) >> 4;
+            if (px < npx) {
+                const int t = r0 + px / S, img = t / S, y = t - img * S, x = px - (px / S) * S;
+                off = (int)(img * g_img_units) + (h * (CO / 8) + co0 / 8 + o) * SS + y * S + x;
+            }
+        } else if (d < C::A_OFF + 2 * C::A_HALF) {                       // activation window: [hi | lo][octet][row][column with halo]
+            const int da = d - C::A_OFF, h = da / C::A_HALF, d1 = da - h * C::A_HALF, o = d1 / C::A_PLANE, u = (d1 - o * C::A_PLANE) >> 4;
+            const int wr = u / C::WC, wc = u - wr * C::WC, e = e0 + wr;
+            const int img = e / (S + 1), y = e - img * (S + 1) - 1;      // y = -1: a halo / separator row
+            if (e <= e_last && wc >= 1 && wc <= S && y >= 0 && img < C::NI)
+                off = (int)(img * a_img_units) + (h * (CI / 8) + ci0 / 8 + o) * SS + y * S + (wc - 1);
+        }
+        tab[j * 64 + lane] = (uint16_t)(off < 0 ? 0xFFFF : off);
+    }
+
+    const int nstack = (B + C::NI - 1) / C::NI;
+    auto dma_piece = [&](int stack, int buf, int j) {                    // (a stack past the last one: zeros — selects, no branch around the copy)
+        const int q = wave + 8 * j;
+        const uint32_t o16 = tab[j * 64 + lane];
+        const bool is_g = q * 1024 + lane * 16 < C::A_OFF;
+        // the second image of the last stack may not exist: its units read zeros
+        const size_t per = is_g ? g_img_units : a_img_units;
+        const bool ok = stack < nstack && o16 != 0xFFFFu && (C::NI == 1 || (int64_t)stack * C::NI + (o16 >= per ? 1 : 0) < B);
+        const unsigned char *base = is_g ? gimg + (size_t)stack * C::NI * g_img_units * 16 : aimg + (size_t)stack * C::NI * a_img_units * 16;
+        const unsigned char *src = ok ? base + (size_t)o16 * 16 : reinterpret_cast<const unsigned char *>(g_ws_zero) + lane * 16;
+        unsigned char *dst = q < C::NPIECE ? lds + buf * C::ITEM + q * 1024 : lds + C::TAB_OFF + C::TAB_BYTES;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+
+    // LDS byte offsets (within an item buffer) of the pixel rows this lane supplies to the transposed reads.  The k a lane
+    // holds in element e of a slab's fragment is 16 (e >> 2) + 4 g + (e & 3) (any assignment works if both operands share it):
+    // read j of a slab covers pixels 32 s + 16 j + 4 g + (li >> 2), this lane supplies the 8 bytes (li & 3) of that pixel's row.
+    // Gradient planes are dense: slab s = + 512 s.  Activation rows have halo columns: one base per (slab, read).
+    const int q4 = li >> 2, p4 = li & 3;
+    int g_addr[2], a_addr[C::NSLAB][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        g_addr[j] = (4 * cot2 + (p4 >> 1)) * C::G_PLANE + (16 * j + 4 * g + q4) * 16 + (p4 & 1) * 8;       // co tile t: + 2 t G_PLANE
+#pragma unroll
+        for (int s = 0; s < C::NSLAB; ++s) {
+            int px = 32 * s + 16 * j + 4 * g + q4;
+            px = px < npx ? px : 0;                                      // (padding pixels: the gradient is zero there, any finite operand will do)
+            const int t = r0 + px / S, x = px - (px / S) * S;
+            a_addr[s][j] = C::A_OFF + (2 * cit + (p4 >> 1)) * C::A_PLANE + ((stack_e<C>(t) - e0) * C::WC + x + 1) * 16 + (p4 & 1) * 8;
+        }
+    }
+
+    f32x4 acc0[9][2], acc1[9][2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc0[k][t] = acc1[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();                                                     // zeros and tables are in before any copy lands
+    int stack = wb;
+    if (stack < nstack)
+        for (int j = 0; j < C::PPW; ++j) dma_piece(stack, 0, j);
+    for (int cur = 0; stack < nstack; stack += nwb, cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // this item is in; everybody is done with the other buffer
+        const int nxt = stack + nwb;
+        const unsigned char *I = lds + cur * C::ITEM;
+        int pj = 0;                                                      // the next item's pieces ride between the taps: piece 9 si + tap at (slab si, tap)
+#pragma unroll
+        for (int si = 0; si < (C::NSLAB + C::KG - 1) / C::KG; ++si) {
+            const int s = kgroup + si * C::KG;
+            if (s < nslab) {
+                f16x8 gh[2], gl[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    gh[t] = lds_tr8(I + g_addr[0] + s * 512 + 2 * t * C::G_PLANE, I + g_addr[1] + s * 512 + 2 * t * C::G_PLANE);
+                    gl[t] = lds_tr8(I + C::G_HALF + g_addr[0] + s * 512 + 2 * t * C::G_PLANE, I + C::G_HALF + g_addr[1] + s * 512 + 2 * t * C::G_PLANE);
+                }
+                int a0 = a_addr[0][0], a1 = a_addr[0][1];
+#pragma unroll
+                for (int q = 1; q < C::NSLAB; ++q)
+                    if (s == q) { a0 = a_addr[q][0]; a1 = a_addr[q][1]; }
+                f16x8 ah = lds_tr8(I + a0 - (C::WC + 1) * 16, I + a1 - (C::WC + 1) * 16);
+                f16x8 al = lds_tr8(I + C::A_HALF + a0 - (C::WC + 1) * 16, I + C::A_HALF + a1 - (C::WC + 1) * 16);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const f16x8 bh = ah, bl = al;
+                    if (tap < 8) {
+                        const int sh = ((tap + 1) / 3 - 1) * C::WC * 16 + ((tap + 1) % 3 - 1) * 16;
+                        ah = lds_tr8(I + a0 + sh, I + a1 + sh);
+                        al = lds_tr8(I + C::A_HALF + a0 + sh, I + C::A_HALF + a1 + sh);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc1[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[t], bl, acc1[tap][t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc0[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[t], bh, acc0[tap][t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc1[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl[t], bh, acc1[tap][t], 0, 0, 0);
+                    if (si * 9 + tap < C::PPW) { dma_piece(nxt, cur ^ 1, si * 9 + tap); pj = si * 9 + tap + 1; }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        for (; pj < C::PPW; ++pj) dma_piece(nxt, cur ^ 1, pj);           // (waves with few or no slabs of this band)
+    }
+
+    // D row = 4 g + r (output channel within the tile), column = li (input channel): partial[part][tap][co][ci], part = (workgroup, kgroup)
+    float *out = partial + ((size_t)wg * C::KG + kgroup) * 9 * CO * CI;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 v = acc0[tap][t] + acc1[tap][t] * LO_UNSCALE;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[((size_t)tap * CO + co0 + 32 * cot2 + 16 * t + 4 * g + r) * CI + ci0 + 16 * cit + li] = v[r];
+        }
+}
+
+// dW[co][ci][tap] = (2^12 / s) * sum over the parts of partial[part][tap][co][ci] (both operands carry 2^-6, the gradient its
+// scale s on top), eight independent chains joined in a fixed order
+__global__ __launch_bounds__(256) void k_wgrad_px_finish(const float *__restrict__ partial, int nparts, int CO, int CI,
+                                                         const float *__restrict__ ginfo, float *__restrict__ gw)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, total = 9 * CO * CI;
+    if (i >= total) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int p = 0;
+    for (; p + 7 < nparts; p += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += partial[(size_t)(p + k) * total + i];
+    }
+    for (int k = 0; p < nparts; ++p, ++k) acc[k] += partial[(size_t)p * total + i];
+    const float v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    const int tap = i / (CO * CI), r = i - tap * CO * CI, co = r / CI, ci = r - co * CI;
+    gw[((size_t)co * CI + ci) * 9 + tap] = v * (4096.0f * ginfo[1]);
+}
+
+template <class C>
+int launch_wgrad_px(const void *gimg, const void *aimg, const float *ginfo, int64_t B, int CO, int CI, float *partial, float *gw,
+                    hipStream_t st, int64_t *ws_need)
+{
+    static_assert(C::NB <= 8, "bands");
+    const int kinds = (CO / C::COT) * (CI / C::CIT);                     // workgroup kinds: channel tiles of both operands
+    const int cus = device_cus();
+    // workgroups per band in proportion to the band's slabs; every kind gets the same split
+    int per_kind = cus / kinds;
+    if (per_kind < C::NB) per_kind = C::NB;
+    int slabs[8], tot = 0, nwg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < C::NB; ++b) {
+        const int r0 = b * C::R, nr = C::ROWS - r0 < C::R ? C::ROWS - r0 : C::R;
+        slabs[b] = (nr * C::S + 31) / 32;
+        tot += slabs[b];
+    }
+    const int64_t nstack = (B + C::NI - 1) / C::NI;
+    int used = 0;
+    for (int b = 0; b < C::NB; ++b) {
+        int n = per_kind * slabs[b] / tot;
+        n = n < 1 ? 1 : n;
+        if (n > nstack) n = (int)nstack;
+        nwg[b] = n;
+        used += n;
+    }
+    const int64_t parts = (int64_t)used * C::KG;                         // per kind: disjoint (co, ci) tiles, so the kinds share the parts
+    if (ws_need) { *ws_need = parts * 9 * CO * CI * (int64_t)sizeof(float); return TRON_OK; }
+    static uint64_t prepared = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
+    if (!(prepared & (1ull << (dev & 63)))) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad_px<C>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
+            (void)hipGetLastError();
+        prepared |= 1ull << (dev & 63);
+    }
+    WBands bands;
+    for (int b = 0; b < 8; ++b) bands.n[b] = nwg[b];
+    const int grid = (used + 7) / 8 * 8 * kinds;                        // (wg = 8 (block / (8 kinds)) + block % 8: whole groups of 8 per kind)
+    hipLaunchKernelGGL(k_wgrad_px<C>, dim3((unsigned)grid), dim3(512), C::LDS, st, reinterpret_cast<const unsigned char *>(gimg),
+                       reinterpret_cast<const unsigned char *>(aimg), (int)B, CO, CI, kinds, bands, partial);
+    hipLaunchKernelGGL(k_wgrad_px_finish, dim3((unsigned)((9 * CO * CI + 255) / 256)), dim3(256), 0, st, partial, (int)parts, CO, CI, ginfo, gw);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+template <class F>
+int dispatch_wgrad_px(int side, int cin, int cout, F &&f)
+{
+    if (side == 12) {
+        if (cin == 64 && cout == 64) return f(WCfg<12, 2, 8, 64, 64, 1>{});
+        if (cin == 32 && cout == 64) return f(WCfg<12, 2, 8, 64, 32, 2>{});
+        if (cin == 32 && cout == 32) return f(WCfg<12, 2, 8, 32, 32, 4>{});
+    } else if (side == 26) {
+        if (cin == 64 && cout == 64) return f(WCfg<26, 1, 6, 64, 32, 2>{});
+        if (cin == 32 && cout == 64) return f(WCfg<26, 1, 6, 64, 32, 2>{});
+        if (cin == 32 && cout == 32) return f(WCfg<26, 1, 6, 32, 32, 4>{});
+    }
+    return TRON_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int tron_conv1_px16_train(const int8_t *codes, const float *weight, const float *bias, int32_t cin, float plane4,
+                                     int64_t batch, int32_t side, void *out_px16, void *pre_px16, void *stream)
+{
+    if (!codes || !weight || !bias || !out_px16 || !pre_px16 || batch < 0 || (cin != 3 && cin != 4)) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(out_px16) | reinterpret_cast<uintptr_t>(pre_px16) | reinterpret_cast<uintptr_t>(bias)) & 15u) return TRON_ERR_BAD_ARG;
+    if (batch == 0) return TRON_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = batch * side * side;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 256 * 8 ? (total + 255) / 256 : 256 * 8);
+    unsigned char *o = reinterpret_cast<unsigned char *>(out_px16), *z = reinterpret_cast<unsigned char *>(pre_px16);
+    if (side == 12) hipLaunchKernelGGL((k_conv1_px<12, true>), dim3(grid), dim3(256), 0, st, codes, weight, bias, cin, plane4, batch, o, z);
+    else if (side == 26) hipLaunchKernelGGL((k_conv1_px<26, true>), dim3(grid), dim3(256), 0, st, codes, weight, bias, cin, plane4, batch, o, z);
+    else return TRON_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+#define TRON_WST_CASES(MODE_, ARGS_)                                                                                    \
+    TRON_WST_CASE(12, 12, 32, 32, 2, 12, MODE_, ARGS_)                                                                  \
+    TRON_WST_CASE(12, 12, 32, 64, 1, 12, MODE_, ARGS_)                                                                  \
+    TRON_WST_CASE(12, 12, 64, 64, 1, 8, MODE_, ARGS_)                                                                   \
+    TRON_WST_CASE(26, 13, 32, 32, 1, 12, MODE_, ARGS_)                                                                  \
+    TRON_WST_CASE(26, 13, 32, 64, 1, 12, MODE_, ARGS_)                                                                  \
+    TRON_WST_CASE(26, 7, 64, 64, 1, 8, MODE_, ARGS_)
+
+extern "C" int tron_conv3x3_ws_train_fwd(const void *in_px16, const void *wfrag, const float *bias, const void *res_px16,
+                                         void *out_px16, float *out_f32, void *pre_px16, int64_t batch, int32_t cin,
+                                         int32_t cout, int32_t side, void *stream)
+{
+    if (!in_px16 || !wfrag || !bias || !pre_px16 || batch < 0 || (!out_px16 && !out_f32)) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(in_px16) | reinterpret_cast<uintptr_t>(wfrag) | reinterpret_cast<uintptr_t>(res_px16) |
+         reinterpret_cast<uintptr_t>(out_px16) | reinterpret_cast<uintptr_t>(pre_px16) | reinterpret_cast<uintptr_t>(bias)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    if (batch == 0) return TRON_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define TRON_WST_CASE(S_, R_, CI_, CO_, IPI_, WAVES_, MODE_, ARGS_)                                                     \
+    if (side == S_ && cin == CI_ && cout == CO_) return launch_ws<Geo<S_, R_, CI_, CO_, IPI_, WAVES_, 1>, MODE_> ARGS_;
+    TRON_WST_CASES(WS_TRAIN, (in_px16, wfrag, bias, res_px16, out_px16, out_f32, nullptr, batch, 1, st, pre_px16))
+#undef TRON_WST_CASE
+    return TRON_ERR_UNSUPPORTED;
+}
+
+extern "C" int tron_conv3x3_ws_split_weights_bwd(const float *const *weights, const int32_t *cins, const int32_t *couts,
+                                                 void *const *workspaces, float *wnorms, int32_t n, void *stream)
+{
+    if (!weights || !cins || !couts || !workspaces || !wnorms || n < 1 || n > WS_SPLIT_MAX) return TRON_ERR_BAD_ARG;
+    WsJobs jobs{};
+    int most = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!weights[k] || !workspaces[k] || (reinterpret_cast<uintptr_t>(workspaces[k]) & 15u)) return TRON_ERR_BAD_ARG;
+        if (tron_conv3x3_ws_workspace(couts[k], cins[k]) == 0 || cins[k] > 1024 || couts[k] > 1024) return TRON_ERR_UNSUPPORTED;
+        jobs.w[k] = weights[k];
+        jobs.ws[k] = reinterpret_cast<f16 *>(workspaces[k]);
+        jobs.cin[k] = couts[k];                                          // the backward convolution: cout channels in, cin channels out
+        jobs.cout[k] = cins[k];
+        jobs.rot[k] = 1;
+        const int total = (cins[k] / 16) * 9 * (couts[k] / 32) * 512;
+        most = total > most ? total : most;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_ws_split_weights, dim3((most + 255) / 256, n), dim3(256), 0, st, jobs);
+    hipLaunchKernelGGL(k_ws_wnorm, dim3(n), dim3(64), 0, st, jobs, wnorms);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int64_t tron_px16_grad_workspace(int64_t batch, int32_t channels)
+{
+    if (batch < 1 || channels < 8 || channels > 64 || channels % 8) return 0;
+    return (int64_t)2 * 1024 * channels * (int64_t)sizeof(float) + 256;  // stats[2][<= 1024 groups][C]
+}
+
+extern "C" int tron_px16_grad_from_f32(const float *grad_out, const void *pre_px16, const float *scale4, int64_t batch,
+                                       int32_t channels, int32_t side, void *grad_px16, float *grad_info, float *bias_grad,
+                                       void *workspace, void *stream)
+{
+    if (!grad_out || !pre_px16 || !scale4 || !grad_px16 || !grad_info || !workspace || batch < 0) return TRON_ERR_BAD_ARG;
+    if (channels < 8 || channels > 64 || channels % 8 || side < 1) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(pre_px16) | reinterpret_cast<uintptr_t>(grad_px16) | reinterpret_cast<uintptr_t>(workspace)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    if (batch == 0) return TRON_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int groups = (int)(batch < 256 ? batch : 256);
+    float *stats = reinterpret_cast<float *>(workspace);
+    hipLaunchKernelGGL(k_gout_px, dim3((unsigned)groups, (unsigned)(channels / 8)), dim3(256), 0, st, grad_out,
+                       reinterpret_cast<const unsigned char *>(pre_px16), batch, channels, side * side, scale4,
+                       reinterpret_cast<unsigned char *>(grad_px16), stats, grad_info);
+    hipLaunchKernelGGL(k_wsb_finish, dim3(1), dim3(64), 0, st, stats, groups, channels, bias_grad, grad_info);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int64_t tron_conv3x3_ws_dgrad_workspace(int32_t cin, int32_t cout)
+{
+    if (tron_conv3x3_ws_workspace(cout, cin) == 0 || cin > 64) return 0;
+    return (int64_t)2 * 1024 * cin * (int64_t)sizeof(float) + 256;       // stats[2][workgroups <= 1024][cin] | scal[4]
+}
+
+// (conv^T(grad, W) + extra) * mish'(pre_below): cin / cout are the FORWARD layer's; the output has cin channels
+extern "C" int tron_conv3x3_ws_dgrad(const void *grad_px16, const float *grad_info, const void *wfrag_rot, const float *wnorm,
+                                     const void *extra_px16, const float *extra_info, const void *pre_below_px16, void *out_px16,
+                                     float *out_f32, float *out_info, float *bias_grad_below, int64_t batch, int32_t cin,
+                                     int32_t cout, int32_t side, void *workspace, void *stream)
+{
+    if (!grad_px16 || !grad_info || !wfrag_rot || !wnorm || !pre_below_px16 || !out_info || !workspace || batch < 0) return TRON_ERR_BAD_ARG;
+    if ((!out_px16 && !out_f32) || (extra_px16 && !extra_info)) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(grad_px16) | reinterpret_cast<uintptr_t>(wfrag_rot) | reinterpret_cast<uintptr_t>(extra_px16) |
+         reinterpret_cast<uintptr_t>(pre_below_px16) | reinterpret_cast<uintptr_t>(out_px16) | reinterpret_cast<uintptr_t>(workspace)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    if (batch == 0) return TRON_OK;
+    if (tron_conv3x3_ws_dgrad_workspace(cin, cout) == 0) return TRON_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float *stats = reinterpret_cast<float *>(workspace);
+    float *scal = stats + (size_t)2 * 1024 * cin;
+    hipLaunchKernelGGL(k_wsb_scale, dim3(1), dim3(1), 0, st, grad_info, extra_px16 ? extra_info : nullptr, wnorm, scal, out_info);
+    WsBwd bw{reinterpret_cast<const unsigned char *>(pre_below_px16), scal, stats};
+    int grid = 0, rc = TRON_ERR_UNSUPPORTED;
+    // the backward convolution has the forward layer's cout channels in and cin channels out
+#define TRON_WSB_CASE(S_, R_, CI_, CO_, IPI_, WAVES_)                                                                   \
+    if (side == S_ && cout == CI_ && cin == CO_)                                                                        \
+        rc = launch_ws<Geo<S_, R_, CI_, CO_, IPI_, WAVES_, 1>, WS_BWD>(grad_px16, wfrag_rot, nullptr, extra_px16, out_px16, out_f32, nullptr, \
+                                                                       batch, 1, st, nullptr, bw, &grid);
+    TRON_WSB_CASE(12, 12, 32, 32, 2, 8)          // (eight waves: the gradient epilogue's state does not fit three waves per SIMD)
+    TRON_WSB_CASE(12, 12, 64, 32, 1, 8)
+    TRON_WSB_CASE(12, 12, 64, 64, 1, 8)
+    TRON_WSB_CASE(26, 13, 32, 32, 1, 8)
+    TRON_WSB_CASE(26, 7, 64, 32, 1, 8)
+    TRON_WSB_CASE(26, 7, 64, 64, 1, 8)
+#undef TRON_WSB_CASE
+    if (rc != TRON_OK) return rc;
+    hipLaunchKernelGGL(k_wsb_finish, dim3(1), dim3(64), 0, st, stats, grid, cin, bias_grad_below, out_info);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int64_t tron_conv3x3_wgrad_px16_workspace(int64_t batch, int32_t cin, int32_t cout, int32_t side)
+{
+    if (batch < 1) return 0;
+    int64_t need = 0;
+    const int rc = dispatch_wgrad_px(side, cin, cout, [&](auto cfg) {
+        return launch_wgrad_px<decltype(cfg)>(nullptr, nullptr, nullptr, batch, cout, cin, nullptr, nullptr, nullptr, &need);
+    });
+    return rc == TRON_OK ? need + 256 : 0;
+}
+
+extern "C" int tron_conv3x3_wgrad_px16(const void *in_px16, const void *grad_px16, const float *grad_info, float *grad_weight,
+                                       int64_t batch, int32_t cin, int32_t cout, int32_t side, void *workspace, void *stream)
+{
+    if (!in_px16 || !grad_px16 || !grad_info || !grad_weight || !workspace || batch < 0) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(in_px16) | reinterpret_cast<uintptr_t>(grad_px16) | reinterpret_cast<uintptr_t>(workspace)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (batch == 0)
+        return hipMemsetAsync(grad_weight, 0, (size_t)cout * cin * 9 * sizeof(float), st) == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+    return dispatch_wgrad_px(side, cin, cout, [&](auto cfg) {
+        return launch_wgrad_px<decltype(cfg)>(grad_px16, in_px16, grad_info, batch, cout, cin, reinterpret_cast<float *>(workspace),
+                                              grad_weight, st, nullptr);
+    });
+}

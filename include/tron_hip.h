@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TRON_ABI_VERSION 8
+#define TRON_ABI_VERSION 9
 
 typedef enum {
     TRON_OK = 0,
@@ -512,6 +512,45 @@ int tron_conv7_bwd(const float *grad_y, const void *saved, const float *weight, 
 int tron_synchronize(void *stream);
 
 const char *tron_strerror(int status);
+/* ---- the learner's trunk on the weight-stationary design (csrc/tron_conv_ws_train.hip; DDQN.py:115-151 on DQNNet.py:33-50) ----
+ * Every tensor between conv1 and conv6 is a PX16 image (tron_px16_bytes): activations a_k and pre-activations z_k at the fixed
+ * 2^-6, GRADIENT images as PX16 of g * s with s a power of two kept in a 4-float device record info = {s, 1 / s, max |g|, -}.
+ *
+ * tron_conv1_px16_train / tron_conv3x3_ws_train_fwd: tron_conv1_px16 / tron_conv3x3_ws_fwd (mish on), which also write the
+ *   layer's pre-activation image pre_px16 (what the backward pass takes mish' of); out_f32 (optional, f32 NCHW) for the last
+ *   layer, whose consumer is the head.
+ * tron_conv3x3_ws_split_weights_bwd: the fragment images of the input gradient's weights — W'[ci][co][tap] = W[co][ci][8 - tap] —
+ *   for n layers in one launch (workspaces[k]: tron_conv3x3_ws_workspace(couts[k], cins[k]) bytes) and wnorms[k] = the largest
+ *   absolute row sum of W' (the bound the next gradient image's scale is chosen from).  cins / couts are the FORWARD layers'.
+ * tron_px16_grad_from_f32: the chain's entry: grad_px16 = PX16 of (grad_out * mish'(pre)) * s, grad_out f32 [batch][channels][side^2]
+ *   (the gradient at the trunk's output); scale4 = tron_absmax_pow2(grad_out, n, 14, ...)'s record (s = scale4[0]); bias_grad
+ *   (may be NULL) = the column sums; grad_info {s, 1 / s, max}.  workspace: tron_px16_grad_workspace(batch, channels) bytes.
+ * tron_conv3x3_ws_dgrad: out = (conv^T(grad, W) + extra) * mish'(pre_below) as a gradient image (out_px16; out_f32 optional, f32
+ *   NCHW unscaled: the consumer is conv1's weight gradient), extra (may be NULL) = the gradient image arriving along a residual
+ *   connection, bias_grad_below f32[cin] (may be NULL) = the column sums of out, out_info = its record.  cin / cout: the FORWARD
+ *   layer's.  workspace: tron_conv3x3_ws_dgrad_workspace(cin, cout) bytes.  Deterministic (fixed-order sums).
+ * tron_conv3x3_wgrad_px16: grad_weight f32[cout][cin][3][3] = sum over images and pixels of grad * shifted in (both PX16),
+ *   workspace: tron_conv3x3_wgrad_px16_workspace(batch, cin, cout, side) bytes (0: shape not covered).  Deterministic.
+ * Shapes: side 12 / 26, (cin, cout) in {(32,32), (32,64), (64,64)}.                                                        */
+int tron_conv1_px16_train(const int8_t *codes, const float *weight, const float *bias, int32_t cin, float plane4,
+                          int64_t batch, int32_t side, void *out_px16, void *pre_px16, void *stream);
+int tron_conv3x3_ws_train_fwd(const void *in_px16, const void *wfrag, const float *bias, const void *res_px16,
+                              void *out_px16, float *out_f32, void *pre_px16, int64_t batch, int32_t cin, int32_t cout,
+                              int32_t side, void *stream);
+int tron_conv3x3_ws_split_weights_bwd(const float *const *weights, const int32_t *cins, const int32_t *couts,
+                                      void *const *workspaces, float *wnorms, int32_t n, void *stream);
+int64_t tron_px16_grad_workspace(int64_t batch, int32_t channels);
+int tron_px16_grad_from_f32(const float *grad_out, const void *pre_px16, const float *scale4, int64_t batch, int32_t channels,
+                            int32_t side, void *grad_px16, float *grad_info, float *bias_grad, void *workspace, void *stream);
+int64_t tron_conv3x3_ws_dgrad_workspace(int32_t cin, int32_t cout);
+int tron_conv3x3_ws_dgrad(const void *grad_px16, const float *grad_info, const void *wfrag_rot, const float *wnorm,
+                          const void *extra_px16, const float *extra_info, const void *pre_below_px16, void *out_px16,
+                          float *out_f32, float *out_info, float *bias_grad_below, int64_t batch, int32_t cin, int32_t cout,
+                          int32_t side, void *workspace, void *stream);
+int64_t tron_conv3x3_wgrad_px16_workspace(int64_t batch, int32_t cin, int32_t cout, int32_t side);
+int tron_conv3x3_wgrad_px16(const void *in_px16, const void *grad_px16, const float *grad_info, float *grad_weight,
+                            int64_t batch, int32_t cin, int32_t cout, int32_t side, void *workspace, void *stream);
+
 int tron_abi_version(void);
 
 #ifdef __cplusplus

@@ -54,12 +54,12 @@ def main(out_dir):
     twin = copy.deepcopy(brain)
     brain.memory = mem
     twin.optimizer = torch.optim.Adam(twin.qnetwork_local.parameters(), fused=bool(brain.optimizer.defaults.get("fused")))
-    twin.optimizer.load_state_dict(brain.optimizer.state_dict())
+    twin.optimizer.load_state_dict(copy.deepcopy(brain.optimizer.state_dict()))   # (load_state_dict keeps tensors that already match: without the copy both optimizers would update ONE set of moments)
     twin.memory = brain.memory
     twin._side = None
     for net in (brain.qnetwork_local, twin.qnetwork_local):
         net.dropout.p = 0.0
-    deferred_equal = True
+    deferred_equal, diag = True, []
     for k in range(3):
         batch = brain.memory.sample_codes()
         l1 = brain.learn(batch, DDQN.GAMMA, defer=True)
@@ -67,14 +67,17 @@ def main(out_dir):
         brain.finish_learn()
         l2 = twin.learn(batch, DDQN.GAMMA, defer=False)
         deferred_equal &= bool(torch.equal(l1, l2))
+        diag.append((float(l1), float(l2), max(float((p - q).abs().max()) for p, q in
+                                               zip(brain.qnetwork_local.parameters(), twin.qnetwork_local.parameters()))))
     deferred_equal &= all(bool(torch.equal(p, q)) for p, q in zip(brain.qnetwork_local.parameters(), twin.qnetwork_local.parameters()))
+    print("deferred vs plain (loss, loss, max |dparam|):", diag, flush=True)
     flat = torch.cat([p.detach().reshape(-1) for p in brain.qnetwork_local.parameters()]).cpu().numpy()
     tflat = torch.cat([p.detach().reshape(-1) for p in brain.qnetwork_target.parameters()]).cpu().numpy()
     # each rank's replay shard holds its own transitions
     brain.memory.sample()
     idx = brain.memory.memory.last_indices(64).cpu().numpy()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), obs=obs_np, oracle_equal=same, local=flat, target=tflat,
-             learn_steps=out["learn_steps"], deferred_equal=deferred_equal, games=out["games"], env_steps=out["env_steps"], world=world, idx=idx)
+             learn_steps=out["learn_steps"], deferred_equal=deferred_equal, deferred_diag=np.array(diag), games=out["games"], env_steps=out["env_steps"], world=world, idx=idx)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -77,7 +77,7 @@ def test_trainer_two_ranks_on_one_gpu(tmp_path):
     # replicated parameters: same averaged gradient + same Adam step on every rank => identical weights
     assert int(r0["learn_steps"]) == int(r1["learn_steps"]) == 6
     # learn(defer=True) + finish_learn() through the side-stream all-reduce == learn(defer=False), on both ranks
-    assert bool(r0["deferred_equal"]) and bool(r1["deferred_equal"])
+    assert bool(r0["deferred_equal"]) and bool(r1["deferred_equal"]), (r0["deferred_diag"], r1["deferred_diag"])
     assert np.array_equal(r0["local"], r1["local"]) and np.array_equal(r0["target"], r1["target"])
     import DDQN
     torch.manual_seed(0x5EED)

@@ -173,13 +173,15 @@ def test_full_checkpoint_restores_the_replay_ring(tmp_path, contents):
     assert size == cap and head == 2048 % cap and calls == 3
     path = str(tmp_path / "full.ckpt")
     DDQN.save_checkpoint(path, a, epsilon=0.25, counters={"games": 11}, replay="contents" if contents else "cursor")
-    b = DDQN.Agent(W, 3, device="cuda", buffer_size=cap, batch_size=256, seed=1, rank=0)
-    b.qnetwork_local.dropout.p = 0.0
+    b = DDQN.Agent(W, 3, device="cuda", buffer_size=cap, batch_size=256, seed=77, rank=1)    # a resumed run: the same launch arguments
+    b.qnetwork_local.dropout.p = 0.0                                     # (the sampler's Philox key is the ring's (seed, rank))
     if not contents:                                                     # a cursor-only checkpoint needs the transitions from elsewhere:
         for k in range(4):                                               # (here: replayed) — into a ring that holds fewer it is skipped
             push(b, k)
     e, counters = DDQN.load_checkpoint(path, b)
     assert e == 0.25 and counters == {"games": 11} and b._eps_calls == a._eps_calls == 3 and b._eps_seed == 77
+    assert any(not torch.equal(p, q) for p, q in zip(DDQN.Agent(W, 3, device="cuda", make_memory=False).qnetwork_local.parameters(),
+                                                     b.qnetwork_local.parameters()))
     assert b.memory.memory.cursor() == (head, size, calls)
     x, y = a.memory.sample_codes(), b.memory.sample_codes()              # the same permutation (call counter) of the same contents
     assert all(torch.equal(p, q) for p, q in zip(x, y))
@@ -191,7 +193,6 @@ def test_full_checkpoint_restores_the_replay_ring(tmp_path, contents):
     assert torch.equal(la, lb)
     for p, q in zip(a.qnetwork_local.parameters(), b.qnetwork_local.parameters()):
         assert torch.equal(p, q)
-    b._eps_rank = a._eps_rank                                            # (the rank is the process's, not the checkpoint's)
     obs = _codes(64, S, 123)
     assert torch.equal(a.act_batch(obs, eps, codes=True), b.act_batch(obs, eps, codes=True))
     # a cursor that claims more than a fresh ring holds is not applied
