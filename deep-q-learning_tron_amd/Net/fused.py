@@ -261,13 +261,13 @@ use_trunk_px = _os.environ.get("TRON_TRUNK_PX", "1") != "0"
 
 
 class GradPX:
-    """A gradient tensor [batch, channels, side, side] as a PX16 image of g * s, with its device record info = {s, 1 / s,
-    max |g|, -} (include/tron_hip.h): s is a power of two chosen before the producing kernel runs."""
+    """A gradient tensor [batch, channels, side, side] as a PX16 image of g * s, with its device record info = {s, 1 / s, -, -,
+    max |g| per channel [64]} (include/tron_hip.h): s is a power of two chosen before the producing kernel runs."""
 
     def __init__(self, batch, channels, side, device):
         self.shape = (batch, channels, side, side)
         self.buf = torch.empty(batch * channels * side * side * 4, dtype=torch.uint8, device=device)
-        self.info = torch.zeros(4, dtype=torch.float32, device=device)
+        self.info = torch.zeros(68, dtype=torch.float32, device=device)
 
     def float(self):
         px = PX16.__new__(PX16)

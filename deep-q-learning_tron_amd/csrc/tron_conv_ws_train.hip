@@ -47,12 +47,22 @@ __device__ __forceinline__ float pow2_at_most(float x)                   // the 
     return __uint_as_float((uint32_t)(e + 127) << 23);
 }
 
-// scal = {1 / s_in, 1 / s_res, s_out, -} for one k_conv_ws<WS_BWD> launch; out_info = {s_out, 1 / s_out, (max: k_wsb_finish), -}
-__global__ void k_wsb_scale(const float *__restrict__ in_info, const float *__restrict__ res_info, const float *__restrict__ wnorm,
-                            float *__restrict__ scal, float *__restrict__ out_info)
+// A gradient image's record is info = {s, 1 / s, -, -} followed by the per-channel maxima chmax[<= 64] (k_wsb_finish): the
+// tensor's maximum is taken where it is needed.
+constexpr int INFO_FLOATS = 4 + 64;
+__device__ __forceinline__ float info_max(const float *info, int C)
+{
+    float m = 0.0f;
+    for (int c = 0; c < C; ++c) m = __builtin_fmaxf(m, info[4 + c]);
+    return m;
+}
+
+// scal = {1 / s_in, 1 / s_res, s_out, -} for one k_conv_ws<WS_BWD> launch; out_info = {s_out, 1 / s_out, ...}
+__global__ void k_wsb_scale(const float *__restrict__ in_info, int c_in, const float *__restrict__ res_info, int c_res,
+                            const float *__restrict__ wnorm, float *__restrict__ scal, float *__restrict__ out_info)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float bound = (in_info[2] * wnorm[0] + (res_info ? res_info[2] : 0.0f)) * 1.1f;
+    const float bound = (info_max(in_info, c_in) * wnorm[0] + (res_info ? info_max(res_info, c_res) : 0.0f)) * 1.1f;
     const float s = bound > 0.0f && bound < 3.0e38f ? pow2_at_most(32768.0f / bound) : 1.0f;
     scal[0] = in_info[1];
     scal[1] = res_info ? res_info[1] : 1.0f;
@@ -62,26 +72,33 @@ __global__ void k_wsb_scale(const float *__restrict__ in_info, const float *__re
     out_info[1] = 1.0f / s;
 }
 
-// stats[2][groups][C] of a k_conv_ws<WS_BWD> (or k_gout_px) launch -> bias_grad[c] = the column sums, added in a fixed order,
-// and info[2] = the largest magnitude written; one workgroup, one thread per channel
-__global__ __launch_bounds__(64) void k_wsb_finish(const float *__restrict__ stats, int groups, int C, float *__restrict__ bias_grad,
-                                                   float *__restrict__ info)
+// stats[2][groups][C] of a k_conv_ws<WS_BWD> (or k_gout_px) launch -> bias_grad[c] = the column sums and info[2] = the largest
+// magnitude written.  One workgroup per channel, a thread per group, fixed-order tree: deterministic.  (The first version — one
+// workgroup, one thread per channel walking the groups — took 78 us per call: 256 dependent loads per thread.)
+__global__ __launch_bounds__(256) void k_wsb_finish(const float *__restrict__ stats, int groups, int C, float *__restrict__ bias_grad,
+                                                    float *__restrict__ chmax)
 {
-    const int c = threadIdx.x;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f}, m = 0.0f;
-    if (c < C) {
-        int gidx = 0;
-        for (; gidx + 3 < groups; gidx += 4) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] += stats[(size_t)(gidx + k) * C + c];
-        }
-        for (int k = 0; gidx < groups; ++gidx, ++k) acc[k] += stats[(size_t)gidx * C + c];
-        for (int q = 0; q < groups; ++q) m = __builtin_fmaxf(m, stats[((size_t)groups + q) * C + c]);
-        if (bias_grad) bias_grad[c] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __shared__ float rs[256], rm[256];
+    const int c = blockIdx.x;
+    float s = 0.0f, m = 0.0f;
+    for (int q = threadIdx.x; q < groups; q += 256) {
+        s += stats[(size_t)q * C + c];
+        m = __builtin_fmaxf(m, stats[((size_t)groups + q) * C + c]);
     }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, d, 64));
-    if (threadIdx.x == 0) info[2] = m;
+    rs[threadIdx.x] = s;
+    rm[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            rs[threadIdx.x] += rs[threadIdx.x + d];
+            rm[threadIdx.x] = __builtin_fmaxf(rm[threadIdx.x], rm[threadIdx.x + d]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (bias_grad) bias_grad[c] = rs[0];
+        chmax[c] = rm[0];
+    }
 }
 
 // ---- the chain's entry: gp = g * mish'(z) as a gradient image ----------------------------------------------------------
@@ -183,12 +200,28 @@ struct WCfg {
     static_assert(2 * NI * 8 * SS < 0xFFFF, "source offsets in 16 bits");
 };
 
+// ds_read_b64_tr_b16 by inline asm, not by __builtin_amdgcn_ds_read_tr16_b64: behind the builtin hipcc (ROCm 7.2) puts an
+// s_waitcnt vmcnt(0) in front of every transposed read that follows an LDS-DMA (it cannot tell the read from the copy's
+// destination), which serialised each of an item's nine copies with the multiply — 11 us per item instead of 3 (the .s showed
+// ten vmcnt(0) per item).  The asm is invisible to that pass; what it costs is that the waits are ours: the reads of a tap go
+// out one tap ahead, `lds_wait()` (s_waitcnt lgkmcnt(0) + sched_barrier, so that no consumer moves above it) stands between a
+// read and the first use of its registers, and the two 8-byte halves are joined into the MFMA operand only AFTER that wait (a
+// copy the compiler might make of them then reads landed data).  EXEC must be all ones (the read crosses lanes).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f16x8 lds_tr8(const unsigned char *p0, const unsigned char *p1)   // two ds_read_b64_tr_b16 (EXEC all ones)
+__device__ __forceinline__ s16x4 lds_tr(uint32_t addr)
 {
-    typedef __attribute__((address_space(3))) s16x4 lds_v;
+    s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=&v"(r) : "v"(addr));
+    return r;
+}
+__device__ __forceinline__ void lds_wait()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ f16x8 join8(s16x4 a, s16x4 b)
+{
     typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v *)p0), b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v *)p1);
     const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return __builtin_bit_cast(f16x8, v);
 }
@@ -284,38 +317,52 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_px(const unsigned char *__rest
         for (int t = 0; t < 2; ++t) acc0[k][t] = acc1[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();                                                     // zeros and tables are in before any copy lands
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
     int stack = wb;
     if (stack < nstack)
         for (int j = 0; j < C::PPW; ++j) dma_piece(stack, 0, j);
     for (int cur = 0; stack < nstack; stack += nwb, cur ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // this item is in; everybody is done with the other buffer
         const int nxt = stack + nwb;
-        const unsigned char *I = lds + cur * C::ITEM;
+        const uint32_t I = lds_base + cur * C::ITEM;                     // LDS byte address of this item's buffer
         int pj = 0;                                                      // the next item's pieces ride between the taps: piece 9 si + tap at (slab si, tap)
 #pragma unroll
         for (int si = 0; si < (C::NSLAB + C::KG - 1) / C::KG; ++si) {
             const int s = kgroup + si * C::KG;
             if (s < nslab) {
-                f16x8 gh[2], gl[2];
+                s16x4 rg[8], ra[2][4];                                   // raw halves: gradient (2 tiles x hi / lo x 2 reads), activation (ring of two taps)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    gh[t] = lds_tr8(I + g_addr[0] + s * 512 + 2 * t * C::G_PLANE, I + g_addr[1] + s * 512 + 2 * t * C::G_PLANE);
-                    gl[t] = lds_tr8(I + C::G_HALF + g_addr[0] + s * 512 + 2 * t * C::G_PLANE, I + C::G_HALF + g_addr[1] + s * 512 + 2 * t * C::G_PLANE);
+                    rg[4 * t + 0] = lds_tr(I + g_addr[0] + s * 512 + 2 * t * C::G_PLANE);
+                    rg[4 * t + 1] = lds_tr(I + g_addr[1] + s * 512 + 2 * t * C::G_PLANE);
+                    rg[4 * t + 2] = lds_tr(I + C::G_HALF + g_addr[0] + s * 512 + 2 * t * C::G_PLANE);
+                    rg[4 * t + 3] = lds_tr(I + C::G_HALF + g_addr[1] + s * 512 + 2 * t * C::G_PLANE);
                 }
                 int a0 = a_addr[0][0], a1 = a_addr[0][1];
 #pragma unroll
                 for (int q = 1; q < C::NSLAB; ++q)
                     if (s == q) { a0 = a_addr[q][0]; a1 = a_addr[q][1]; }
-                f16x8 ah = lds_tr8(I + a0 - (C::WC + 1) * 16, I + a1 - (C::WC + 1) * 16);
-                f16x8 al = lds_tr8(I + C::A_HALF + a0 - (C::WC + 1) * 16, I + C::A_HALF + a1 - (C::WC + 1) * 16);
+                auto read_tap = [&](int slot, int tap) {
+                    const int sh = (tap / 3 - 1) * C::WC * 16 + (tap % 3 - 1) * 16;
+                    ra[slot][0] = lds_tr(I + a0 + sh);
+                    ra[slot][1] = lds_tr(I + a1 + sh);
+                    ra[slot][2] = lds_tr(I + C::A_HALF + a0 + sh);
+                    ra[slot][3] = lds_tr(I + C::A_HALF + a1 + sh);
+                };
+                read_tap(0, 0);
+                f16x8 gh[2], gl[2];
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    const f16x8 bh = ah, bl = al;
-                    if (tap < 8) {
-                        const int sh = ((tap + 1) / 3 - 1) * C::WC * 16 + ((tap + 1) % 3 - 1) * 16;
-                        ah = lds_tr8(I + a0 + sh, I + a1 + sh);
-                        al = lds_tr8(I + C::A_HALF + a0 + sh, I + C::A_HALF + a1 + sh);
+                    lds_wait();                                          // this tap's operands (and, at tap 0, the gradient's) have landed
+                    if (tap == 0) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            gh[t] = join8(rg[4 * t + 0], rg[4 * t + 1]);
+                            gl[t] = join8(rg[4 * t + 2], rg[4 * t + 3]);
+                        }
                     }
+                    const f16x8 bh = join8(ra[tap & 1][0], ra[tap & 1][1]), bl = join8(ra[tap & 1][2], ra[tap & 1][3]);
+                    if (tap < 8) read_tap((tap + 1) & 1, tap + 1);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) acc1[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[t], bl, acc1[tap][t], 0, 0, 0);
 #pragma unroll
@@ -344,22 +391,29 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_px(const unsigned char *__rest
 }
 
 // dW[co][ci][tap] = (2^12 / s) * sum over the parts of partial[part][tap][co][ci] (both operands carry 2^-6, the gradient its
-// scale s on top), eight independent chains joined in a fixed order
+// scale s on top).  A workgroup = 64 consecutive outputs x 4 part groups (parts q, q + 4, ...: two chains each), joined in a
+// fixed order: deterministic, and hundreds of workgroups in flight instead of one dependent chain of loads per output.
 __global__ __launch_bounds__(256) void k_wgrad_px_finish(const float *__restrict__ partial, int nparts, int CO, int CI,
                                                          const float *__restrict__ ginfo, float *__restrict__ gw)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, total = 9 * CO * CI;
-    if (i >= total) return;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int p = 0;
-    for (; p + 7 < nparts; p += 8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += partial[(size_t)(p + k) * total + i];
+    __shared__ float red[256];
+    const int total = 9 * CO * CI, i = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
+    float a0 = 0.0f, a1 = 0.0f;
+    if (i < total) {
+        int p = pg;
+        for (; p + 4 < nparts; p += 8) {
+            a0 += partial[(size_t)p * total + i];
+            a1 += partial[(size_t)(p + 4) * total + i];
+        }
+        if (p < nparts) a0 += partial[(size_t)p * total + i];
     }
-    for (int k = 0; p < nparts; ++p, ++k) acc[k] += partial[(size_t)p * total + i];
-    const float v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-    const int tap = i / (CO * CI), r = i - tap * CO * CI, co = r / CI, ci = r - co * CI;
-    gw[((size_t)co * CI + ci) * 9 + tap] = v * (4096.0f * ginfo[1]);
+    red[threadIdx.x] = a0 + a1;
+    __syncthreads();
+    if (threadIdx.x < 64 && i < total) {
+        const float v = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        const int tap = i / (CO * CI), r = i - tap * CO * CI, co = r / CI, ci = r - co * CI;
+        gw[((size_t)co * CI + ci) * 9 + tap] = v * (4096.0f * ginfo[1]);
+    }
 }
 
 template <class C>
@@ -402,7 +456,7 @@ int launch_wgrad_px(const void *gimg, const void *aimg, const float *ginfo, int6
     const int grid = (used + 7) / 8 * 8 * kinds;                        // (wg = 8 (block / (8 kinds)) + block % 8: whole groups of 8 per kind)
     hipLaunchKernelGGL(k_wgrad_px<C>, dim3((unsigned)grid), dim3(512), C::LDS, st, reinterpret_cast<const unsigned char *>(gimg),
                        reinterpret_cast<const unsigned char *>(aimg), (int)B, CO, CI, kinds, bands, partial);
-    hipLaunchKernelGGL(k_wgrad_px_finish, dim3((unsigned)((9 * CO * CI + 255) / 256)), dim3(256), 0, st, partial, (int)parts, CO, CI, ginfo, gw);
+    hipLaunchKernelGGL(k_wgrad_px_finish, dim3((unsigned)((9 * CO * CI + 63) / 64)), dim3(256), 0, st, partial, (int)parts, CO, CI, ginfo, gw);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
@@ -508,7 +562,7 @@ extern "C" int tron_px16_grad_from_f32(const float *grad_out, const void *pre_px
     hipLaunchKernelGGL(k_gout_px, dim3((unsigned)groups, (unsigned)(channels / 8)), dim3(256), 0, st, grad_out,
                        reinterpret_cast<const unsigned char *>(pre_px16), batch, channels, side * side, scale4,
                        reinterpret_cast<unsigned char *>(grad_px16), stats, grad_info);
-    hipLaunchKernelGGL(k_wsb_finish, dim3(1), dim3(64), 0, st, stats, groups, channels, bias_grad, grad_info);
+    hipLaunchKernelGGL(k_wsb_finish, dim3((unsigned)channels), dim3(256), 0, st, stats, groups, channels, bias_grad, grad_info + 4);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
@@ -534,7 +588,7 @@ extern "C" int tron_conv3x3_ws_dgrad(const void *grad_px16, const float *grad_in
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float *stats = reinterpret_cast<float *>(workspace);
     float *scal = stats + (size_t)2 * 1024 * cin;
-    hipLaunchKernelGGL(k_wsb_scale, dim3(1), dim3(1), 0, st, grad_info, extra_px16 ? extra_info : nullptr, wnorm, scal, out_info);
+    hipLaunchKernelGGL(k_wsb_scale, dim3(1), dim3(1), 0, st, grad_info, cout, extra_px16 ? extra_info : nullptr, cin, wnorm, scal, out_info);
     WsBwd bw{reinterpret_cast<const unsigned char *>(pre_below_px16), scal, stats};
     int grid = 0, rc = TRON_ERR_UNSUPPORTED;
     // the backward convolution has the forward layer's cout channels in and cin channels out
@@ -550,7 +604,7 @@ extern "C" int tron_conv3x3_ws_dgrad(const void *grad_px16, const float *grad_in
     TRON_WSB_CASE(26, 7, 64, 64, 1, 8)
 #undef TRON_WSB_CASE
     if (rc != TRON_OK) return rc;
-    hipLaunchKernelGGL(k_wsb_finish, dim3(1), dim3(64), 0, st, stats, grid, cin, bias_grad_below, out_info);
+    hipLaunchKernelGGL(k_wsb_finish, dim3((unsigned)cin), dim3(256), 0, st, stats, grid, cin, bias_grad_below, out_info + 4);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 

@@ -514,7 +514,8 @@ int tron_synchronize(void *stream);
 const char *tron_strerror(int status);
 /* ---- the learner's trunk on the weight-stationary design (csrc/tron_conv_ws_train.hip; DDQN.py:115-151 on DQNNet.py:33-50) ----
  * Every tensor between conv1 and conv6 is a PX16 image (tron_px16_bytes): activations a_k and pre-activations z_k at the fixed
- * 2^-6, GRADIENT images as PX16 of g * s with s a power of two kept in a 4-float device record info = {s, 1 / s, max |g|, -}.
+ * 2^-6, GRADIENT images as PX16 of g * s with s a power of two kept in a device record info = f32[68]: {s, 1 / s, -, -, max |g| of each
+ * channel [<= 64]}.
  *
  * tron_conv1_px16_train / tron_conv3x3_ws_train_fwd: tron_conv1_px16 / tron_conv3x3_ws_fwd (mish on), which also write the
  *   layer's pre-activation image pre_px16 (what the backward pass takes mish' of); out_f32 (optional, f32 NCHW) for the last
@@ -524,7 +525,7 @@ const char *tron_strerror(int status);
  *   absolute row sum of W' (the bound the next gradient image's scale is chosen from).  cins / couts are the FORWARD layers'.
  * tron_px16_grad_from_f32: the chain's entry: grad_px16 = PX16 of (grad_out * mish'(pre)) * s, grad_out f32 [batch][channels][side^2]
  *   (the gradient at the trunk's output); scale4 = tron_absmax_pow2(grad_out, n, 14, ...)'s record (s = scale4[0]); bias_grad
- *   (may be NULL) = the column sums; grad_info {s, 1 / s, max}.  workspace: tron_px16_grad_workspace(batch, channels) bytes.
+ *   (may be NULL) = the column sums; grad_info = the image's record (f32[68]).  workspace: tron_px16_grad_workspace(batch, channels) bytes.
  * tron_conv3x3_ws_dgrad: out = (conv^T(grad, W) + extra) * mish'(pre_below) as a gradient image (out_px16; out_f32 optional, f32
  *   NCHW unscaled: the consumer is conv1's weight gradient), extra (may be NULL) = the gradient image arriving along a residual
  *   connection, bias_grad_below f32[cin] (may be NULL) = the column sums of out, out_info = its record.  cin / cout: the FORWARD

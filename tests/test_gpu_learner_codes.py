@@ -52,7 +52,10 @@ def test_sample_codes_is_sample_without_the_expansion(S, batch):
 
 @pytest.mark.parametrize("W,cin,B", [(10, 3, 50), (10, 4, 129), (24, 3, 9)])
 def test_forward_codes_equals_forward_on_planes(W, cin, B):
-    """Same values (same kernel, two ways of staging conv1's input) and the same gradients for every parameter."""
+    """The same network two ways: from the int8 codes (the learner's path: `_TrunkPX`, conv1 as a table sum, PX16 images between
+    the layers) and from f32 planes (`_TrunkHIP`, the layer kernels).  Two f32-grade evaluations of one expression: equal to
+    rounding, for the values and for every parameter's gradient (each is held to float64 on its own in test_gpu_trunk_px.py /
+    test_gpu_trunk_node.py)."""
     from Net.DQNNet import Net
     from tron.vec import pop_up_planes
     torch.manual_seed(W + cin)
@@ -69,9 +72,9 @@ def test_forward_codes_equals_forward_on_planes(W, cin, B):
     net.zero_grad()
     q_p = net(planes)
     q_p.square().mean().backward()
-    assert torch.equal(q_c, q_p)
+    assert (q_c - q_p).abs().max().item() < 1e-5
     for a, p in zip(g_c, net.parameters()):
-        assert (a - p.grad).abs().max().item() <= 1e-6 * max(1.0, p.grad.abs().max().item())
+        assert (a - p.grad).abs().max().item() <= 2e-5 * max(p.grad.abs().max().item(), 1e-12)
 
 
 def test_learn_on_codes_equals_learn_on_planes():

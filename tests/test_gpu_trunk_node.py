@@ -21,6 +21,13 @@ def fused():
     return fused
 
 
+@pytest.fixture(autouse=True)
+def _layer_kernel_node(fused, monkeypatch):
+    """This file holds `_TrunkHIP` — the node on the layer kernels, what f32 planes (and TRON_TRUNK_PX=0) take; int8 codes go
+    to `_TrunkPX` by default (tests/test_gpu_trunk_px.py)."""
+    monkeypatch.setattr(fused, "use_trunk_px", False)
+
+
 def _codes(B, S, seed):
     gen = torch.Generator(device="cuda").manual_seed(seed)
     vals = torch.tensor([1, -1, -2, -3, 10, -10], dtype=torch.int8, device="cuda")
