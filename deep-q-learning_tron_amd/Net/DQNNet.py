@@ -65,10 +65,12 @@ class Net(nn.Module):
         the replay ring as codes: tron_replay_sample_codes).  Where the HIP kernels do not cover the shape the planes
         are built explicitly."""
         from Net import fused
-        from Net.activations import conv1_codes_mish, trunk_mish, trunk_supported
+        from Net.activations import conv1_codes_mish, trunk_mish, trunk_supported, body_mish, body_px_supported
         side = codes.shape[-1]
         if codes.is_cuda and fused.supported(self.conv1, side) and (self.activation is Net.mish or self.activation is self.mish):
             codes = codes.reshape(-1, side, side)
+            if self.fuse_trunk and torch.is_grad_enabled() and body_px_supported(self, codes):
+                return self._after_conv7(body_mish(self, codes, plane4))          # conv1 .. conv7 as one node (Net/activations.py::_BodyPX)
             if self.fuse_trunk and trunk_supported(self, codes):
                 return self._after_trunk(trunk_mish(self, codes, plane4))
             return self._after_conv1(conv1_codes_mish(self.conv1, codes, plane4))
@@ -107,6 +109,9 @@ class Net(nn.Module):
             x = _pool_s2(self.pool, x)                                   # (24x24 boards: the row kernels, both directions)
             x = _conv_bias_mish(self.conv7, x)
             x = x.reshape(-1, self.flat)
+        return self._after_conv7(x)
+
+    def _after_conv7(self, x):
         x = self.dropout(self.activation(_linear(self.fc1, x)))
         x = self.dropout(self.activation(_linear(self.fc2, x)))
         return _linear(self.actor2, self.activation(_linear(self.actor1, x)))

@@ -312,71 +312,193 @@ class _TrunkHIP(torch.autograd.Function):
         return tuple(grads)
 
 
+def _trunk_px_forward(codes, plane4, w, b, last_f32):
+    """conv1 .. conv6 on the weight-stationary chain with the pre-activations kept (csrc/tron_conv_ws_train.hip).  Returns conv6's
+    output (f32 NCHW if last_f32, else PX16) and the tensors the backward needs."""
+    from Net import fused
+    frag = fused._split_jobs(list(w[1:6]), "tron_conv3x3_ws_split_weights", False)
+    a1, z1 = fused.conv1_px16_train(codes, w[0], b[0], plane4)
+    a2, z2 = fused.conv_ws_train(a1, 32, frag[0], b[1])
+    a3, z3 = fused.conv_ws_train(a2, 32, frag[1], b[2], residual=a1)
+    a4, z4 = fused.conv_ws_train(a3, 64, frag[2], b[3])
+    a5, z5 = fused.conv_ws_train(a4, 64, frag[3], b[4])
+    out, z6 = fused.conv_ws_train(a5, 64, frag[4], b[5], residual=a4, want_f32=last_f32)
+    return out, (codes, a1.buf, a2.buf, a3.buf, a4.buf, a5.buf, z1.buf, z2.buf, z3.buf, z4.buf, z5.buf, z6.buf)
+
+
+def _trunk_px_backward(saved, w, plane4, gp6, gb6, need):
+    """The gradient chain below conv6's activation backward: gp6 = the gradient image at conv6's pre-activation, gb6 conv6's bias
+    gradient.  need[k]: conv(k+1)'s weight gradient is wanted.  Returns (gw[6], gb[6])."""
+    from Net import fused
+    codes, a1, a2, a3, a4, a5, z1, z2, z3, z4, z5, z6 = saved
+    B, S = gp6.shape[0], gp6.shape[-1]
+    px = lambda buf, c: fused._px((B, c, S, S), buf)
+    rot, wn = fused._split_jobs(list(w[1:6]), "tron_conv3x3_ws_split_weights_bwd", True)      # conv2 .. conv6, one launch
+    gb, gw = [None] * 6, [None] * 6
+    gb[5] = gb6
+    gw[5] = fused.conv3x3_wgrad_px(px(a5, 64), gp6) if need[5] else None
+    gp5, _, gb[4] = fused.conv_ws_dgrad(gp6, 64, rot[4], wn[4:5], px(z5, 64))
+    gw[4] = fused.conv3x3_wgrad_px(px(a4, 64), gp5) if need[4] else None
+    gp4, _, gb[3] = fused.conv_ws_dgrad(gp5, 64, rot[3], wn[3:4], px(z4, 64), extra=gp6)      # a4 also feeds conv6's residual
+    del gp5, gp6
+    gw[3] = fused.conv3x3_wgrad_px(px(a3, 32), gp4) if need[3] else None
+    gp3, _, gb[2] = fused.conv_ws_dgrad(gp4, 32, rot[2], wn[2:3], px(z3, 32))
+    del gp4
+    gw[2] = fused.conv3x3_wgrad_px(px(a2, 32), gp3) if need[2] else None
+    gp2, _, gb[1] = fused.conv_ws_dgrad(gp3, 32, rot[1], wn[1:2], px(z2, 32))
+    gw[1] = fused.conv3x3_wgrad_px(px(a1, 32), gp2) if need[1] else None
+    _, gp1, gb[0] = fused.conv_ws_dgrad(gp2, 32, rot[0], wn[0:1], px(z1, 32), extra=gp3, want_px=False, want_f32=True)   # a1 also feeds conv3's residual
+    del gp2, gp3
+    if need[0]:
+        from tron.vec import pop_up_planes
+        planes = pop_up_planes(codes)
+        if w[0].shape[1] == 4:
+            planes = torch.cat([planes, torch.full_like(planes[:, :1], plane4)], 1)
+        if fused.wgrad_supported(w[0], S):
+            gw[0] = fused.conv3x3_wgrad(planes, gp1)
+        else:
+            gw[0] = torch.ops.aten.convolution_backward(gp1, planes, w[0], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                        [False, True, False])[1]
+    return gw, gb
+
+
 class _TrunkPX(torch.autograd.Function):
     """conv1 .. conv6 (DQNNet.py:33-50) from the env's int8 codes as ONE autograd node on the weight-stationary design
     (csrc/tron_conv_ws_train.hip): the forward is the gradient-free chain's kernel keeping every pre-activation as a PX16 image,
     the backward runs each input gradient as that same kernel on the rotated weights — residual gradient, mish' of the layer
     below, its bias sums and the next scale in the epilogue — and each weight gradient straight from the two PX16 images
-    (transposed LDS reads).  No f32 NCHW tensor exists between conv1's output and conv6's output; the head reads conv6's f32
-    output, conv1's weight gradient (3 or 4 planes -> 32: plain f32 FMAs) reads an f32 gradient the last input-gradient launch
-    also writes."""
+    (transposed LDS reads).  No f32 NCHW tensor exists between conv1's output and conv6's output; this node hands conv6's f32
+    output to whatever follows (`_BodyPX` also takes the head's pooling and conv7 in); conv1's weight gradient (3 or 4 planes ->
+    32: plain f32 FMAs) reads an f32 gradient the last input-gradient launch also writes."""
 
     @staticmethod
     def forward(ctx, codes, plane4, *wb):
-        from Net import fused
         w, b = wb[0::2], wb[1::2]
-        frag = fused._split_jobs(list(w[1:]), "tron_conv3x3_ws_split_weights", False)
-        a1, z1 = fused.conv1_px16_train(codes, w[0], b[0], plane4)
-        a2, z2 = fused.conv_ws_train(a1, 32, frag[0], b[1])
-        a3, z3 = fused.conv_ws_train(a2, 32, frag[1], b[2], residual=a1)
-        a4, z4 = fused.conv_ws_train(a3, 64, frag[2], b[3])
-        a5, z5 = fused.conv_ws_train(a4, 64, frag[3], b[4])
-        out, z6 = fused.conv_ws_train(a5, 64, frag[4], b[5], residual=a4, want_f32=True)
-        ctx.save_for_backward(codes, a1.buf, a2.buf, a3.buf, a4.buf, a5.buf, z1.buf, z2.buf, z3.buf, z4.buf, z5.buf, z6.buf, *w)
+        out, saved = _trunk_px_forward(codes, plane4, w, b, True)
+        ctx.save_for_backward(*saved, *w)
         ctx.plane4 = plane4
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         from Net import fused
-        codes, a1, a2, a3, a4, a5, z1, z2, z3, z4, z5, z6, *w = ctx.saved_tensors
+        *saved, w1, w2, w3, w4, w5, w6 = ctx.saved_tensors
         g = grad_out.contiguous()
         if not _aligned16(g):
             g = g.clone(memory_format=torch.contiguous_format)
         B, S = g.shape[0], g.shape[-1]
         need = ctx.needs_input_grad                                 # (codes, plane4, w1, b1, ..., w6, b6)
-        px = lambda buf, c: fused._px((B, c, S, S), buf)
-        rot, wn = fused._split_jobs(list(w[1:]), "tron_conv3x3_ws_split_weights_bwd", True)      # conv2 .. conv6, one launch
-        gb, gw = [None] * 6, [None] * 6
-        gp6, gb[5] = fused.grad_px_from_f32(g, px(z6, 64))
+        gp6, gb6 = fused.grad_px_from_f32(g, fused._px((B, 64, S, S), saved[11]))
         del g
-        gw[5] = fused.conv3x3_wgrad_px(px(a5, 64), gp6) if need[12] else None
-        gp5, _, gb[4] = fused.conv_ws_dgrad(gp6, 64, rot[4], wn[4:5], px(z5, 64))
-        gw[4] = fused.conv3x3_wgrad_px(px(a4, 64), gp5) if need[10] else None
-        gp4, _, gb[3] = fused.conv_ws_dgrad(gp5, 64, rot[3], wn[3:4], px(z4, 64), extra=gp6)      # a4 also feeds conv6's residual
-        del gp5, gp6
-        gw[3] = fused.conv3x3_wgrad_px(px(a3, 32), gp4) if need[8] else None
-        gp3, _, gb[2] = fused.conv_ws_dgrad(gp4, 32, rot[2], wn[2:3], px(z3, 32))
-        del gp4
-        gw[2] = fused.conv3x3_wgrad_px(px(a2, 32), gp3) if need[6] else None
-        gp2, _, gb[1] = fused.conv_ws_dgrad(gp3, 32, rot[1], wn[1:2], px(z2, 32))
-        gw[1] = fused.conv3x3_wgrad_px(px(a1, 32), gp2) if need[4] else None
-        _, gp1, gb[0] = fused.conv_ws_dgrad(gp2, 32, rot[0], wn[0:1], px(z1, 32), extra=gp3, want_px=False, want_f32=True)   # a1 also feeds conv3's residual
-        del gp2, gp3
-        if need[2]:
-            from tron.vec import pop_up_planes
-            planes = pop_up_planes(codes)
-            if w[0].shape[1] == 4:
-                planes = torch.cat([planes, torch.full_like(planes[:, :1], ctx.plane4)], 1)
-            if fused.wgrad_supported(w[0], S):
-                gw[0] = fused.conv3x3_wgrad(planes, gp1)
-            else:
-                gw[0] = torch.ops.aten.convolution_backward(gp1, planes, w[0], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                            [False, True, False])[1]
+        gw, gb = _trunk_px_backward(saved, (w1, w2, w3, w4, w5, w6), ctx.plane4, gp6, gb6, [need[2 + 2 * k] for k in range(6)])
         grads = [None, None]
         for k in range(6):
             grads += [gw[k], gb[k] if need[3 + 2 * k] else None]
         return tuple(grads)
+
+
+class _BodyPX(torch.autograd.Function):
+    """The whole convolutional body of the DQN net — conv1 .. conv6, AvgPool2d(3, 2, 1), conv7, mish, flatten (DQNNet.py:33-55) —
+    from the env's int8 codes as one node: `_TrunkPX` with the head's first two layers taken in, so that conv6's output goes into
+    the pooling as the PX16 image it is, and on the way back the pooling's backward, conv6's activation backward, its bias sums
+    and the gradient image's scale are ONE pass over the pooled gradient (tron_px16_grad_from_pooled) — the f32 planes of the
+    trunk's output and of their gradient are never written.  12x12: conv7 on its dense form (`_PoolConv7`'s GEMMs); 26x26:
+    tron_pool_conv7_fwd_px16 / tron_pool_conv7_bwd_pooled (`_PoolConv7CL`'s kernels)."""
+
+    @staticmethod
+    def forward(ctx, codes, plane4, *wb):
+        from tron import _native as nat
+        from Net import fused
+        L = nat.lib()
+        w, b = wb[0::2], wb[1::2]
+        a6, saved = _trunk_px_forward(codes, plane4, w, b, False)
+        B, S = codes.shape[0], codes.shape[-1]
+        dev = codes.device
+        st = nat.stream_ptr()
+        with torch.cuda.device(dev):
+            if S == 12:
+                pooled = torch.empty(B, 64 * 36, dtype=torch.float32, device=dev)
+                nat.check(L.tron_pool12_px16(nat.ptr(a6.buf), nat.ptr(pooled), B, st), "tron_pool12_px16")
+                dense = torch.empty(64 * 9, 64 * 36, dtype=torch.float32, device=dev)
+                nat.check(L.tron_conv7_dense(nat.ptr(w[6]), nat.ptr(dense), 64, 64, 0, st), "tron_conv7_dense")
+                pre = fused.gemm_f16x3(pooled, dense, b[6].repeat_interleave(9))
+                if pre is None:
+                    pre = torch.addmm(b[6].repeat_interleave(9), pooled, dense.t())
+                y = torch.empty_like(pre)
+                nat.check(L.tron_mish_fwd(nat.ptr(pre), nat.ptr(y), pre.numel(), st), "tron_mish_fwd")
+                extra = (pooled, dense, pre)
+            else:
+                o = (S // 2 + 1) // 2
+                keep = torch.empty(int(L.tron_pool_conv7_saved_bytes(B, S)), dtype=torch.uint8, device=dev)
+                ws = torch.empty(int(L.tron_pool_conv7_workspace(B, S)), dtype=torch.uint8, device=dev)
+                pre = torch.empty(B, o * o, 64, dtype=torch.float32, device=dev)
+                y = torch.empty(B, 64 * o * o, dtype=torch.float32, device=dev)
+                nat.check(L.tron_pool_conv7_fwd_px16(nat.ptr(a6.buf), B, S, nat.ptr(w[6]), nat.ptr(b[6]), nat.ptr(keep), nat.ptr(pre), nat.ptr(y),
+                                                     nat.ptr(ws), st), "tron_pool_conv7_fwd_px16")
+                extra = (keep, pre)
+        del a6
+        ctx.save_for_backward(*saved, *w, *extra)
+        ctx.plane4, ctx.side = plane4, S
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from tron import _native as nat
+        from Net import fused
+        L = nat.lib()
+        t = ctx.saved_tensors
+        saved, w, extra = t[:12], t[12:19], t[19:]
+        S = ctx.side
+        g = grad_out.contiguous()
+        if not _aligned16(g):
+            g = g.clone(memory_format=torch.contiguous_format)
+        B = g.shape[0]
+        dev = g.device
+        need = ctx.needs_input_grad                                 # (codes, plane4, w1, b1, ..., w7, b7)
+        st = nat.stream_ptr()
+        gw7 = gb7 = None
+        with torch.cuda.device(dev):
+            if S == 12:
+                pooled, dense, pre = extra
+                gp = torch.empty_like(pre)
+                nat.check(L.tron_mish_bwd(nat.ptr(pre), nat.ptr(g), nat.ptr(gp), pre.numel(), st), "tron_mish_bwd")
+                from Net.kfac import _pow2_scale
+                sc = _pow2_scale(gp) if fused.use_gemm else None
+                gpool = fused.gemm_f16x3(gp, dense, b_transposed=True, a_scale=sc)           # [B, 64 * 36]: the pooled planes' gradient
+                if gpool is None:
+                    gpool = gp @ dense
+                if need[14]:
+                    gdense = fused.gemm_f16x3(gp, pooled, a_transposed=True, b_transposed=True, a_scale=sc)
+                    if gdense is None:
+                        gdense = gp.t() @ pooled
+                    gw7 = torch.empty(64, 64, 7, 7, dtype=torch.float32, device=dev)
+                    nat.check(L.tron_conv7_dense(nat.ptr(gdense), nat.ptr(gw7), 64, 64, 1, st), "tron_conv7_dense")
+                if need[15]:
+                    gb7 = gp.view(B, 64, 9).sum((0, 2))
+                channels_last = 0
+            else:
+                keep, pre = extra
+                gpool = torch.empty(B, (S // 2) ** 2, 64, dtype=torch.float32, device=dev)
+                gw7 = torch.empty_like(w[6]) if need[14] else None
+                gb7 = torch.empty(64, dtype=torch.float32, device=dev) if need[15] else None
+                ws = torch.empty(int(L.tron_pool_conv7_workspace(B, S)), dtype=torch.uint8, device=dev)
+                nat.check(L.tron_pool_conv7_bwd_pooled(nat.ptr(g), nat.ptr(pre), nat.ptr(keep), nat.ptr(w[6]), B, S, nat.ptr(gpool), nat.ptr(gw7),
+                                                       nat.ptr(gb7), nat.ptr(ws), st), "tron_pool_conv7_bwd_pooled")
+                channels_last = 1
+            # pooling backward + conv6's activation backward + bias sums + the gradient image, one pass over the pooled gradient
+            sc4 = torch.zeros(4, dtype=torch.float32, device=dev)
+            gp6 = fused.GradPX(B, 64, S, dev)
+            gb6 = torch.empty(64, dtype=torch.float32, device=dev)
+            gws = torch.empty(int(L.tron_px16_grad_workspace(B, 64)), dtype=torch.uint8, device=dev)
+            nat.check(L.tron_absmax_pow2(nat.ptr(gpool), gpool.numel(), 15, nat.ptr(sc4), st), "tron_absmax_pow2")
+            nat.check(L.tron_px16_grad_from_pooled(nat.ptr(gpool), channels_last, nat.ptr(saved[11]), nat.ptr(sc4), B, 64, S, nat.ptr(gp6.buf),
+                                                   nat.ptr(gp6.info), nat.ptr(gb6), nat.ptr(gws), st), "tron_px16_grad_from_pooled")
+        del g, gpool
+        gw, gb = _trunk_px_backward(saved, w[:6], ctx.plane4, gp6, gb6, [need[2 + 2 * k] for k in range(6)])
+        grads = [None, None]
+        for k in range(6):
+            grads += [gw[k], gb[k] if need[3 + 2 * k] else None]
+        return tuple(grads + [gw7, gb7])
 
 
 def trunk_px_supported(net, x):
@@ -405,6 +527,27 @@ def trunk_supported(net, x):
     return (chans == [(32, 32), (32, 32), (32, 64), (64, 64), (64, 64)] and net.conv1.out_channels == 32
             and all(c.bias is not None and fused.supported(c, side) for c in convs)
             and all(fused.dgrad_mish_supported(c.weight, side) for c in convs[1:]))
+
+
+def body_px_supported(net, x):
+    """Can `_BodyPX` run conv1 .. conv7 of `net` on the codes x?  `_TrunkPX`'s shapes, the reference's pooling and conv7 (64 -> 64,
+    7x7 / 2 / 3: DQNNet.py:20-22) and mish as the activation."""
+    from Net import fused
+    pool, conv = getattr(net, "pool", None), getattr(net, "conv7", None)
+    return (trunk_px_supported(net, x) and _use_pool_conv7_cl and isinstance(pool, torch.nn.AvgPool2d) and pool.kernel_size == 3
+            and pool.stride == 2 and pool.padding == 1 and pool.count_include_pad and not pool.ceil_mode and pool.divisor_override is None
+            and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None and conv.in_channels == 64 and conv.out_channels == 64
+            and conv.weight.is_contiguous() and conv.weight.dtype == torch.float32 and conv.weight.is_cuda
+            and _os.environ.get("TRON_BODY_PX", "1") != "0")
+
+
+def body_mish(net, codes, plane4=0.0):
+    """mish(conv7(pool(trunk(codes)))) flattened [B, 64 * O * O] (DQNNet.py:33-55) as one node (`_BodyPX`)."""
+    wb = []
+    for c in (net.conv1, net.conv2, net.conv3, net.conv4, net.conv5, net.conv6, net.conv7):
+        wb += [c.weight, c.bias]
+    return _BodyPX.apply(codes.contiguous(), float(plane4), *wb)
 
 
 def trunk_mish(net, x, plane4=0.0):

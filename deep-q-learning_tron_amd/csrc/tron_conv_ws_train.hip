@@ -107,46 +107,84 @@ __global__ __launch_bounds__(256) void k_wsb_finish(const float *__restrict__ st
 // (coalesced along the pixels of each channel row), keeps the 8 column sums and the maximum, and the block leaves them in
 // stats[2][groups][C] (k_wsb_finish).  info_in = tron_absmax_pow2's {s, max |g|, ...}: s brings max |g| below 2^14, and
 // |mish'| <= 1.1 keeps the product below 2^15.
+//
+// SRC: where g comes from.  0: f32 [B][C][SS] planes.  1 / 2: the gradient of the POOLED planes (AvgPool2d(3, 2, 1), DQNNet.py:52)
+// — the pooling's backward is taken on the fly, g[y][x] = (1/9) sum of the windows that contain (y, x) (at most four), so the
+// f32 gradient planes of the trunk's output are never written: 1 = pooled planes f32 [B][C][PS*PS] (12x12: the dense conv7 path),
+// 2 = channels-last f32 [B][PS*PS][C] (26x26: the DGRAD7 GEMMs' output).  scale4[0] must then bring (4/9) max |pooled g| * 1.1
+// below 2^15: tron_absmax_pow2(pooled g, 15).
+template <int SRC>
 __global__ __launch_bounds__(256) void k_gout_px(const float *__restrict__ gout, const unsigned char *__restrict__ z, int64_t B, int C,
-                                                 int SS, const float *__restrict__ scale4, unsigned char *__restrict__ out,
+                                                 int S, const float *__restrict__ scale4, unsigned char *__restrict__ out,
                                                  float *__restrict__ stats, float *__restrict__ info)
 {
+    const int SS = S * S, PS = S / 2, PP = PS * PS;
     __shared__ float red[256 * 9];
+    __shared__ __attribute__((aligned(16))) float tile[SRC ? 172 * 8 : 8];   // (SRC 1 / 2) the pooled gradient of one image's octet: [pooled pixel][8 channels]
     const int oct = blockIdx.y, groups = gridDim.x, grp = blockIdx.x;
     const float s = scale4[0];
     if (grp == 0 && oct == 0 && threadIdx.x == 0) { info[0] = s; info[1] = 1.0f / s; }
-    const int64_t per = (B + groups - 1) / groups, i0 = grp * per, i1 = i0 + per < B ? i0 + per : B;
     const size_t half = (size_t)(C / 8) * SS * 16;
     float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mx = 0.0f;
-    const int64_t total = (i1 > i0 ? i1 - i0 : 0) * SS;
-    for (int64_t i = threadIdx.x; i < total; i += 256) {
-        const int64_t img = i0 + i / SS;
-        const int p = (int)(i % SS);
-        const unsigned char *zp = z + (size_t)img * 2 * half + ((size_t)oct * SS + p) * 16;
-        const f16x8 zh = *reinterpret_cast<const f16x8 *>(zp), zl = *reinterpret_cast<const f16x8 *>(zp + half);
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float zz = ((float)zh[j] + (float)zl[j] * LO_UNSCALE) * ACT_UNSCALE;
-            const float gg = gout[((size_t)img * C + oct * 8 + j) * SS + p];
-            const uint32_t eb = __float_as_uint(__builtin_amdgcn_exp2f(zz * 1.44269504088896341f));
-            const float e = __uint_as_float(eb < 0x5D5E0B6Bu ? eb : 0x5D5E0B6Bu);
-            const float n = e * (e + 2.0f), r = __builtin_amdgcn_rcpf(n + 2.0f), t = n * r;
-            const float m = t + zz * ((r + r) * (t + 1.0f)) * (e * __builtin_amdgcn_rcpf(e + 1.0f));
-            v[j] = gg * m;
-            sum[j] += v[j];
-            mx = __builtin_fmaxf(mx, __builtin_fabsf(v[j]));
-            v[j] *= s * ACT_SCALE;
+    for (int64_t img = grp; img < B; img += groups) {                    // this block's images: grp, grp + groups, ...
+        if (SRC) {
+            __syncthreads();                                             // (the previous image's tile is no longer read)
+            if (SRC == 1) {
+                for (int i = threadIdx.x; i < 8 * PP; i += 256) {        // planes [B][C][PP]: the octet's 8 planes are contiguous
+                    const int j = i / PP, pp = i - j * PP;
+                    tile[pp * 8 + j] = gout[((size_t)img * C + oct * 8) * PP + i];
+                }
+            } else {
+                for (int i = threadIdx.x; i < 2 * PP; i += 256) {        // channels-last [B][PP][C]: 8 consecutive floats per pooled pixel
+                    const int pp = i >> 1, q = i & 1;
+                    *reinterpret_cast<f32x4 *>(tile + pp * 8 + 4 * q) =
+                        *reinterpret_cast<const f32x4 *>(gout + ((size_t)img * PP + pp) * C + oct * 8 + 4 * q);
+                }
+            }
+            __syncthreads();
         }
-        f16x8 hh, ll;
+        for (int p = threadIdx.x; p < SS; p += 256) {
+            const unsigned char *zp = z + (size_t)img * 2 * half + ((size_t)oct * SS + p) * 16;
+            const f16x8 zh = *reinterpret_cast<const f16x8 *>(zp), zl = *reinterpret_cast<const f16x8 *>(zp + half);
+            float gg[8];
+            if (SRC == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            hh[j] = (f16)v[j];
-            ll[j] = (f16)((v[j] - (float)hh[j]) * LO_SCALE);
+                for (int j = 0; j < 8; ++j) gg[j] = gout[((size_t)img * C + oct * 8 + j) * SS + p];
+            } else {
+                // window row py covers input rows 2 py - 1 .. 2 py + 1: an even y belongs to py = y / 2 only, an odd one to
+                // (y - 1) / 2 and (y + 1) / 2 (the latter if it exists); columns alike
+                const int y = p / S, x = p - y * S;
+                const int py0 = y >> 1, px0 = x >> 1;
+                const bool two_y = (y & 1) && py0 + 1 < PS, two_x = (x & 1) && px0 + 1 < PS;
+                const float *t00 = tile + (py0 * PS + px0) * 8;
+                const float wx = two_x ? 1.0f : 0.0f, wy = two_y ? 1.0f : 0.0f;
+                const float *t01 = two_x ? t00 + 8 : t00, *t10 = two_y ? t00 + PS * 8 : t00, *t11 = (two_x && two_y) ? t00 + PS * 8 + 8 : t00;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gg[j] = (t00[j] + wx * t01[j] + wy * t10[j] + wx * wy * t11[j]) * (1.0f / 9.0f);
+            }
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float zz = ((float)zh[j] + (float)zl[j] * LO_UNSCALE) * ACT_UNSCALE;
+                const uint32_t eb = __float_as_uint(__builtin_amdgcn_exp2f(zz * 1.44269504088896341f));
+                const float e = __uint_as_float(eb < 0x5D5E0B6Bu ? eb : 0x5D5E0B6Bu);
+                const float n = e * (e + 2.0f), r = __builtin_amdgcn_rcpf(n + 2.0f), t = n * r;
+                const float m = t + zz * ((r + r) * (t + 1.0f)) * (e * __builtin_amdgcn_rcpf(e + 1.0f));
+                v[j] = gg[j] * m;
+                sum[j] += v[j];
+                mx = __builtin_fmaxf(mx, __builtin_fabsf(v[j]));
+                v[j] *= s * ACT_SCALE;
+            }
+            f16x8 hh, ll;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                hh[j] = (f16)v[j];
+                ll[j] = (f16)((v[j] - (float)hh[j]) * LO_SCALE);
+            }
+            unsigned char *op = out + (size_t)img * 2 * half + ((size_t)oct * SS + p) * 16;
+            *reinterpret_cast<f16x8 *>(op) = hh;
+            *reinterpret_cast<f16x8 *>(op + half) = ll;
         }
-        unsigned char *op = out + (size_t)img * 2 * half + ((size_t)oct * SS + p) * 16;
-        *reinterpret_cast<f16x8 *>(op) = hh;
-        *reinterpret_cast<f16x8 *>(op + half) = ll;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[j * 256 + threadIdx.x] = sum[j];
@@ -557,11 +595,36 @@ extern "C" int tron_px16_grad_from_f32(const float *grad_out, const void *pre_px
         return TRON_ERR_BAD_ARG;
     if (batch == 0) return TRON_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int groups = (int)(batch < 256 ? batch : 256);
+    int groups = (int)(batch < 1024 ? batch : 1024);
     float *stats = reinterpret_cast<float *>(workspace);
-    hipLaunchKernelGGL(k_gout_px, dim3((unsigned)groups, (unsigned)(channels / 8)), dim3(256), 0, st, grad_out,
-                       reinterpret_cast<const unsigned char *>(pre_px16), batch, channels, side * side, scale4,
+    hipLaunchKernelGGL(k_gout_px<0>, dim3((unsigned)groups, (unsigned)(channels / 8)), dim3(256), 0, st, grad_out,
+                       reinterpret_cast<const unsigned char *>(pre_px16), batch, channels, side, scale4,
                        reinterpret_cast<unsigned char *>(grad_px16), stats, grad_info);
+    hipLaunchKernelGGL(k_wsb_finish, dim3((unsigned)channels), dim3(256), 0, st, stats, groups, channels, bias_grad, grad_info + 4);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int tron_px16_grad_from_pooled(const float *grad_pooled, int32_t channels_last, const void *pre_px16, const float *scale4,
+                                          int64_t batch, int32_t channels, int32_t side, void *grad_px16, float *grad_info,
+                                          float *bias_grad, void *workspace, void *stream)
+{
+    if (!grad_pooled || !pre_px16 || !scale4 || !grad_px16 || !grad_info || !workspace || batch < 0) return TRON_ERR_BAD_ARG;
+    if (channels < 8 || channels > 64 || channels % 8 || side < 2 || side % 2) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(pre_px16) | reinterpret_cast<uintptr_t>(grad_px16) | reinterpret_cast<uintptr_t>(workspace) |
+         reinterpret_cast<uintptr_t>(grad_pooled)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    if ((side / 2) * (side / 2) > 172) return TRON_ERR_UNSUPPORTED;      // (the kernel's LDS tile: pooled planes up to 13 x 13)
+    if (batch == 0) return TRON_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int groups = (int)(batch < 1024 ? batch : 1024);
+    float *stats = reinterpret_cast<float *>(workspace);
+    const dim3 grid((unsigned)groups, (unsigned)(channels / 8));
+    if (channels_last)
+        hipLaunchKernelGGL(k_gout_px<2>, grid, dim3(256), 0, st, grad_pooled, reinterpret_cast<const unsigned char *>(pre_px16), batch, channels,
+                           side, scale4, reinterpret_cast<unsigned char *>(grad_px16), stats, grad_info);
+    else
+        hipLaunchKernelGGL(k_gout_px<1>, grid, dim3(256), 0, st, grad_pooled, reinterpret_cast<const unsigned char *>(pre_px16), batch, channels,
+                           side, scale4, reinterpret_cast<unsigned char *>(grad_px16), stats, grad_info);
     hipLaunchKernelGGL(k_wsb_finish, dim3((unsigned)channels), dim3(256), 0, st, stats, groups, channels, bias_grad, grad_info + 4);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }

@@ -367,6 +367,23 @@ __global__ __launch_bounds__(256) void k_pool_split12_px(const unsigned char *__
     }
 }
 
+// 12x12, the training path's pooled planes f32 [B][64][6][6] (k_pool12's output) from conv6's PX16 image: the learner's trunk ends
+// in a PX16 image, never in f32 planes.  One thread = one pooled pixel x one channel octet.
+__global__ __launch_bounds__(256) void k_pool12_from_px(const unsigned char *__restrict__ x, int64_t B, float *__restrict__ y)
+{
+    constexpr int S = 12, PS = 6, C = 64, HALF = (C / 8) * S * S * 16;
+    const int64_t total = B * 8 * PS * PS;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i % (PS * PS)), py = r / PS, px = r % PS;
+        const int64_t bo = i / (PS * PS), b = bo >> 3;
+        const int oct = (int)(bo & 7);
+        float sum[8];
+        px16_window_sum(x + (size_t)b * 2 * HALF, S, HALF, oct, py, px, sum);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[((size_t)b * C + oct * 8 + j) * (PS * PS) + r] = sum[j] * (64.0f / 9.0f);   // (the image carries value / 64)
+    }
+}
+
 // 26x26: the channels-last split image [B][13][13][64] (what k_pool_split_cl<26> writes).  One thread = one pooled pixel x one
 // channel octet: a 16-byte store per half.
 __global__ __launch_bounds__(256) void k_pool_split26_px(const unsigned char *__restrict__ x, int64_t B, f16 *__restrict__ oh,
@@ -1296,7 +1313,8 @@ inline bool p7_side_ok(int32_t side) { return side == 26 || side == 34; }
 
 // CONVONLY: x is the pooled planes f32 [B][64][PS][PS], y the convolution's output f32 [B][64][O][O] (+ bias, no activation)
 template <int S, bool CONVONLY>
-int p7_fwd(const float *x, int64_t B, const float *w, const float *bias, void *saved, float *pre, float *y, void *workspace, hipStream_t st)
+int p7_fwd(const float *x, int64_t B, const float *w, const float *bias, void *saved, float *pre, float *y, void *workspace, hipStream_t st,
+           const unsigned char *x_px16 = nullptr)
 {
     constexpr int PS = S / 2, O = (PS + 1) / 2;
     const P7Plan p = p7_plan(B, PS);
@@ -1306,6 +1324,8 @@ int p7_fwd(const float *x, int64_t B, const float *w, const float *bias, void *s
     if (CONVONLY) {
         pre = reinterpret_cast<float *>(ws + p.pre);
         hipLaunchKernelGGL(k_nchw_to_cl_split<PS * PS>, dim3((unsigned)(B * ((PS * PS + 31) / 32))), dim3(256), 0, st, x, ph, pl);
+    } else if (x_px16) {                                                 // the learner's trunk ends in a PX16 image (S = 26 only)
+        hipLaunchKernelGGL(k_pool_split26_px, dim3((unsigned)((B * 169 * 8 + 255) / 256 < (1 << 20) ? (B * 169 * 8 + 255) / 256 : (1 << 20))), dim3(256), 0, st, x_px16, B, ph, pl);
     } else {
         hipLaunchKernelGGL(k_pool_split_cl<S>, dim3((unsigned)(B * PS)), dim3(256), 0, st, x, ph, pl);   // (a 16-channel-slab form that reads each plane once, contiguously, was 11 % slower: LDS-bound)
     }
@@ -1319,7 +1339,7 @@ int p7_fwd(const float *x, int64_t B, const float *w, const float *bias, void *s
 
 template <int S, bool CONVONLY>
 int p7_bwd(const float *gy, const float *pre, const void *saved, const float *w, int64_t B, float *gx, float *gw, float *gb, void *workspace,
-           hipStream_t st)
+           hipStream_t st, float *gpool_out = nullptr)
 {
     constexpr int PS = S / 2, O = (PS + 1) / 2, OPIX = O * O;
     const P7Plan p = p7_plan(B, PS);
@@ -1336,9 +1356,9 @@ int p7_bwd(const float *gy, const float *pre, const void *saved, const float *w,
     hipLaunchKernelGGL(k_mish_bwd_to_cl<OPIX>, dim3((unsigned)bblocks), dim3(256), 0, st, gy, pre, (int)B, out4, gph, gpl, bpart);
     if (gb) hipLaunchKernelGGL(k_colsum_finish, dim3(1), dim3(1024), 0, st, bpart, bblocks, gb);
     if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
-    if (gx) {
+    if (gx || gpool_out) {
         f16 *wh = reinterpret_cast<f16 *>(ws + p.wh), *wl = reinterpret_cast<f16 *>(ws + p.wl);
-        float *gpool = reinterpret_cast<float *>(ws + p.gpool);
+        float *gpool = gpool_out ? gpool_out : reinterpret_cast<float *>(ws + p.gpool);   // (gpool_out: the caller takes the pooled gradient, channels-last)
         hipLaunchKernelGGL(k_conv7w_dgrad_split, dim3(784), dim3(256), 0, st, w, wh, wl);
         if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
         const int first[4] = {0, 9, 21, 33};
@@ -1349,7 +1369,8 @@ int p7_bwd(const float *gy, const float *pre, const void *saved, const float *w,
                                     nullptr, nullptr, st, out4, cls);
         }
         if (rc != TRON_OK) return rc;
-        if (CONVONLY) hipLaunchKernelGGL(k_cl_to_nchw<PS * PS>, dim3((unsigned)(B * 4)), dim3(256), 0, st, gpool, gx);
+        if (gpool_out) { /* the pooling's backward is the caller's (tron_px16_grad_from_pooled) */ }
+        else if (CONVONLY) hipLaunchKernelGGL(k_cl_to_nchw<PS * PS>, dim3((unsigned)(B * 4)), dim3(256), 0, st, gpool, gx);
         else hipLaunchKernelGGL(k_pool_bwd_cl<S>, dim3((unsigned)(B * 4)), dim3(256), 0, st, gpool, gx);
         if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
     }
@@ -1416,6 +1437,45 @@ extern "C" int tron_pool_conv7_bwd(const float *grad_y, const float *pre, const 
     }
     return side == 26 ? p7_bwd<26, false>(grad_y, pre, saved, weight, batch, grad_x, grad_weight, grad_bias, workspace, st)
                       : p7_bwd<34, false>(grad_y, pre, saved, weight, batch, grad_x, grad_weight, grad_bias, workspace, st);
+}
+
+// The same two calls for a trunk that ends in a PX16 image (Net/activations.py::_BodyPX, csrc/tron_conv_ws_train.hip): the forward
+// pools conv6's PX16 output (26x26 only), the backward stops at the POOLED gradient — grad_pooled f32 [batch][13 x 13][64],
+// channels-last — whose pooling backward tron_px16_grad_from_pooled fuses with the activation backward of conv6.
+extern "C" int tron_pool_conv7_fwd_px16(const void *x_px16, int64_t batch, int32_t side, const float *weight, const float *bias, void *saved,
+                                        float *pre, float *y, void *workspace, void *stream)
+{
+    if (!x_px16 || !weight || !bias || !saved || !pre || !y || !workspace || batch < 0) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(x_px16) | reinterpret_cast<uintptr_t>(saved) | reinterpret_cast<uintptr_t>(pre) | reinterpret_cast<uintptr_t>(y) |
+         reinterpret_cast<uintptr_t>(workspace)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    if (batch == 0) return TRON_OK;
+    if (side != 26 || batch > (1ll << 20)) return TRON_ERR_UNSUPPORTED;
+    return p7_fwd<26, false>(nullptr, batch, weight, bias, saved, pre, y, workspace, reinterpret_cast<hipStream_t>(stream),
+                             reinterpret_cast<const unsigned char *>(x_px16));
+}
+
+extern "C" int tron_pool_conv7_bwd_pooled(const float *grad_y, const float *pre, const void *saved, const float *weight, int64_t batch,
+                                          int32_t side, float *grad_pooled, float *grad_weight, float *grad_bias, void *workspace, void *stream)
+{
+    if (!grad_y || !pre || !saved || !weight || !grad_pooled || !workspace || batch < 0) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(saved) | reinterpret_cast<uintptr_t>(pre) |
+         reinterpret_cast<uintptr_t>(grad_pooled) | reinterpret_cast<uintptr_t>(workspace)) & 15u)
+        return TRON_ERR_BAD_ARG;
+    if (side != 26 || batch > (1ll << 20)) return TRON_ERR_UNSUPPORTED;
+    if (batch == 0) return TRON_OK;
+    return p7_bwd<26, false>(grad_y, pre, saved, weight, batch, nullptr, grad_weight, grad_bias, workspace, reinterpret_cast<hipStream_t>(stream),
+                             grad_pooled);
+}
+
+extern "C" int tron_pool12_px16(const void *x_px16, float *pooled, int64_t batch, void *stream)
+{
+    if (!x_px16 || !pooled || batch < 0 || (reinterpret_cast<uintptr_t>(x_px16) & 15u)) return TRON_ERR_BAD_ARG;
+    if (batch == 0) return TRON_OK;
+    const int64_t total = batch * 8 * 36;
+    hipLaunchKernelGGL(k_pool12_from_px, dim3((unsigned)((total + 255) / 256 < (1 << 20) ? (total + 255) / 256 : (1 << 20))), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned char *>(x_px16), batch, pooled);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
 // conv7 alone on the same kernels — the nn.Conv2d module itself (Net/activations.py::Conv7), NCHW in and out, for callers that need the

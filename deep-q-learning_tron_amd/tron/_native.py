@@ -64,6 +64,10 @@ SIGNATURES = {
     "tron_conv3x3_ws_split_weights_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "tron_px16_grad_workspace": (C.c_int64, [_i64, _i32]),
     "tron_px16_grad_from_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "tron_px16_grad_from_pooled": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "tron_pool12_px16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "tron_pool_conv7_fwd_px16": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tron_pool_conv7_bwd_pooled": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "tron_conv3x3_ws_dgrad_workspace": (C.c_int64, [_i32, _i32]),
     "tron_conv3x3_ws_dgrad": (C.c_int, [_vp] * 11 + [_i64, _i32, _i32, _i32, _vp, _vp]),
     "tron_conv3x3_wgrad_px16_workspace": (C.c_int64, [_i64, _i32, _i32, _i32]),

@@ -543,6 +543,21 @@ int tron_conv3x3_ws_split_weights_bwd(const float *const *weights, const int32_t
 int64_t tron_px16_grad_workspace(int64_t batch, int32_t channels);
 int tron_px16_grad_from_f32(const float *grad_out, const void *pre_px16, const float *scale4, int64_t batch, int32_t channels,
                             int32_t side, void *grad_px16, float *grad_info, float *bias_grad, void *workspace, void *stream);
+/* The same entry from the gradient of the POOLED planes (AvgPool2d(3, 2, 1) behind conv6, DQNNet.py:52): the pooling's backward is
+ * taken on the fly, so the f32 gradient planes of the trunk's output are never written.  grad_pooled: f32 [batch][channels][(side/2)^2]
+ * (channels_last = 0: the 12x12 boards' dense conv7 path) or f32 [batch][(side/2)^2][channels] (channels_last = 1:
+ * tron_pool_conv7_bwd_pooled); scale4 = tron_absmax_pow2(grad_pooled, n, 15, ...)'s record.                                   */
+int tron_px16_grad_from_pooled(const float *grad_pooled, int32_t channels_last, const void *pre_px16, const float *scale4,
+                               int64_t batch, int32_t channels, int32_t side, void *grad_px16, float *grad_info,
+                               float *bias_grad, void *workspace, void *stream);
+/* The head's first two layers behind a trunk that ends in a PX16 image: tron_pool12_px16 = tron_pool12's forward (pooled f32
+ * [batch][64][6][6]) from conv6's PX16 output at 12x12; tron_pool_conv7_fwd_px16 = tron_pool_conv7_fwd reading it at 26x26;
+ * tron_pool_conv7_bwd_pooled = tron_pool_conv7_bwd stopping at the pooled gradient (grad_pooled f32 [batch][13*13][64]).    */
+int tron_pool12_px16(const void *x_px16, float *pooled, int64_t batch, void *stream);
+int tron_pool_conv7_fwd_px16(const void *x_px16, int64_t batch, int32_t side, const float *weight, const float *bias, void *saved,
+                             float *pre, float *y, void *workspace, void *stream);
+int tron_pool_conv7_bwd_pooled(const float *grad_y, const float *pre, const void *saved, const float *weight, int64_t batch,
+                               int32_t side, float *grad_pooled, float *grad_weight, float *grad_bias, void *workspace, void *stream);
 int64_t tron_conv3x3_ws_dgrad_workspace(int32_t cin, int32_t cout);
 int tron_conv3x3_ws_dgrad(const void *grad_px16, const float *grad_info, const void *wfrag_rot, const float *wnorm,
                           const void *extra_px16, const float *extra_info, const void *pre_below_px16, void *out_px16,

@@ -79,7 +79,8 @@ def test_forward_codes_equals_forward_on_planes(W, cin, B):
 
 def test_learn_on_codes_equals_learn_on_planes():
     """Agent.learn (DDQN.py:115-151) with the batch as codes — conv1 from the codes, both target forwards on the
-    weight-stationary chain — against the same step fed with f32 planes: loss within 1e-5, updated weights within 1e-6."""
+    weight-stationary chain, the body as `_BodyPX` — against the same step fed with f32 planes (the layer kernels): loss within
+    1e-5, updated weights to rounding (Adam's first step is lr * sign-like: 1e-3 +- a few 1e-6 where two f32-grade gradients differ)."""
     import DDQN
     from tron.vec import pop_up_planes
     torch.manual_seed(3)
@@ -96,7 +97,7 @@ def test_learn_on_codes_equals_learn_on_planes():
     loss_p = agents[1].learn((pop_up_planes(s), a, r, pop_up_planes(s2), d), DDQN.GAMMA)
     assert abs(float(loss_c) - float(loss_p)) < 1e-5 * max(1.0, abs(float(loss_p)))
     for pc, pp in zip(agents[0].qnetwork_local.parameters(), agents[1].qnetwork_local.parameters()):
-        assert (pc - pp).abs().max().item() < 2e-6
+        assert (pc - pp).abs().max().item() < 5e-6
 
 
 def test_split_push_equals_push():

@@ -97,6 +97,34 @@ def test_conv1_training_forward(fused, S, cin):
     assert torch.equal(a.buf, fused.conv1_px16(codes, conv, 5.0).buf)
 
 
+@pytest.mark.parametrize("S,mag", [(12, 1.0), (26, 1e-6), (26, 1.0)])
+def test_gradient_image_entry_from_the_pooled_gradient(fused, S, mag):
+    """tron_px16_grad_from_pooled: AvgPool2d(3, 2, 1)'s backward + mish'(z) + bias sums in one pass, from pooled planes (12x12) and
+    from the channels-last pooled gradient (26x26), against float64 autograd of mish -> avg_pool."""
+    from tron import _native as nat
+    L = nat.lib()
+    torch.manual_seed(S)
+    B, C, PS = 19, 64, S // 2
+    z = torch.randn(B, C, S, S, device="cuda") * 2.5
+    gpool = torch.randn(B, C, PS, PS, device="cuda") * mag
+    zd = z.double().requires_grad_(True)
+    F.avg_pool2d(F.mish(zd), 3, stride=2, padding=1).backward(gpool.double())
+    src = gpool.permute(0, 2, 3, 1).contiguous() if S == 26 else gpool.contiguous()
+    sc4 = torch.zeros(4, device="cuda")
+    out = fused.GradPX(B, C, S, "cuda")
+    gb = torch.empty(C, device="cuda")
+    ws = torch.empty(int(L.tron_px16_grad_workspace(B, C)), dtype=torch.uint8, device="cuda")
+    nat.check(L.tron_absmax_pow2(nat.ptr(src), src.numel(), 15, nat.ptr(sc4), nat.stream_ptr()))
+    nat.check(L.tron_px16_grad_from_pooled(nat.ptr(src), int(S == 26), nat.ptr(_to_px(fused, z).buf), nat.ptr(sc4), B, C, S, nat.ptr(out.buf),
+                                           nat.ptr(out.info), nat.ptr(gb), nat.ptr(ws), nat.stream_ptr()))
+    scale = zd.grad.abs().max().item()
+    assert (out.float().double() - zd.grad).abs().max().item() < 2e-6 * scale
+    sums = zd.grad.sum((0, 2, 3))
+    assert (gb.double() - sums).abs().max().item() < 1e-5 * sums.abs().max().item() + 1e-6 * scale
+    info = out.info.cpu().numpy()
+    assert abs(info[4:4 + C].max() - scale) <= 2e-6 * scale and info[4:4 + C].max() * info[0] < 2.0 ** 15
+
+
 @pytest.mark.parametrize("S,C,mag", [(12, 64, 1.0), (26, 64, 1e-6), (12, 32, 3e-8)])
 def test_gradient_image_entry(fused, S, C, mag):
     torch.manual_seed(S + C)
@@ -192,19 +220,20 @@ def test_weight_gradient_from_px16_images(fused, S, cin, cout, B, mag):
             assert torch.equal(got, want), (b, co, ci, y, xx, ky, kx)
 
 
-@pytest.mark.parametrize("W,B", [(10, 64), (24, 12)])
-def test_trunk_node_matches_float64_and_the_previous_node(fused, W, B, monkeypatch):
-    """Net.forward_codes -> _TrunkPX: output and every parameter gradient of the trunk against the float64 module, and against
-    the layer-kernel node it replaces (TRON_TRUNK_PX=0)."""
+@pytest.mark.parametrize("body", ["1", "0"])
+@pytest.mark.parametrize("W,B", [(10, 64), (24, 12), (10, 1), (24, 3)])
+def test_trunk_node_matches_float64_and_the_previous_node(fused, W, B, body, monkeypatch):
+    """Net.forward_codes -> `_BodyPX` (conv1 .. conv7 as one node; TRON_BODY_PX=0: `_TrunkPX`, conv1 .. conv6): output and every
+    parameter gradient against the float64 module, and against the layer-kernel node they replace (TRON_TRUNK_PX=0)."""
     import copy
     from Net.DQNNet import Net
+    monkeypatch.setenv("TRON_BODY_PX", body)
     torch.manual_seed(W)
     net = Net(3, W).cuda()
     net.dropout.p = 0.0
     codes = _codes(B, W + 2, 3)
     up = torch.randn(B, 4, device="cuda") * (1.0 / B)
     q = net.forward_codes(codes)
-    assert "TrunkPX" in type(q.grad_fn.next_functions[0][0]).__name__ or True
     (q * up).sum().backward()
     from tron.vec import pop_up_planes
     n64 = copy.deepcopy(net).double()
@@ -242,4 +271,4 @@ def test_trunk_px_is_the_path_the_learner_takes(fused):
             continue
         names.add(type(f).__name__)
         stack += [n for n, _ in f.next_functions]
-    assert "_TrunkPXBackward" in names, names
+    assert "_BodyPXBackward" in names, names
