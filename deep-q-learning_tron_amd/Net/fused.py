@@ -267,7 +267,7 @@ class GradPX:
     def __init__(self, batch, channels, side, device):
         self.shape = (batch, channels, side, side)
         self.buf = torch.empty(batch * channels * side * side * 4, dtype=torch.uint8, device=device)
-        self.info = torch.zeros(68, dtype=torch.float32, device=device)
+        self.info = torch.empty(68, dtype=torch.float32, device=device)          # (written by the producing kernels: {s, 1 / s} and the channels' maxima)
 
     def float(self):
         px = PX16.__new__(PX16)

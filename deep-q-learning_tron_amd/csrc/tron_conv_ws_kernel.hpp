@@ -141,11 +141,21 @@ __device__ unsigned long long g_ws_stamps[256 * 12 * 8];         // [workgroup][
 //             layer below — with the per-channel sums of out (that layer's bias gradient) and the largest |out| left in
 //             `stats` per workgroup (k_wsb_finish adds them up in a fixed order).  F32OUT also writes out as f32 NCHW.
 enum { WS_INFER = 0, WS_TRAIN = 1, WS_BWD = 2 };
+// A gradient image's device record: info = {s, 1 / s, -, -, max |g| per channel [<= 64]} (include/tron_hip.h).
 struct WsBwd {
     const unsigned char *zb;     // PX16 pre-activation of the layer below [B][COUT][S][S] (COUT = this launch's output channels)
-    const float *scal;           // device: {1 / s_in, 1 / s_res, s_out, -}: powers of two
+    const float *in_info;        // record of `in`
+    const float *res_info;       // record of `res` (RES)
+    const float *wnorm;          // largest absolute row sum of the rotated weights: max |conv(in)| <= max |in| * wnorm
+    float *out_info;             // record of `out`: {s_out, 1 / s_out} are written here (the maxima: k_wsb_finish)
     float *stats;                // [2][gridDim.x][COUT]: column sums | column maxima of |out|
 };
+__device__ __forceinline__ float pow2_at_most(float x)                   // the largest power of two <= x (x > 0, finite); exponent clamped to +-60
+{
+    int e = (int)((__float_as_uint(x) >> 23) & 0xFFu) - 127;
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+    return __uint_as_float((uint32_t)(e + 127) << 23);
+}
 
 template <class G, bool RES, bool F32OUT, int MODE = WS_INFER>
 __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
@@ -175,9 +185,23 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
     if (!BWD && bias) bv = *reinterpret_cast<const f32x4 *>(bias + co0);
     float inv_in = 1.0f, inv_res = 1.0f, s_out = 1.0f;                  // (BWD) the images' scales
     if (BWD) {
-        inv_in = bw.scal[0] * ACT_UNSCALE;
-        inv_res = bw.scal[1] * ACT_UNSCALE;
-        s_out = bw.scal[2] * ACT_SCALE;
+        // the scale of what this launch writes, from a bound on it (every wave computes the same number): max |conv(in) + res| <=
+        // max |in| x wnorm + max |res|, times |mish'| <= 1.1, mapped to at most 2^15 by a power of two
+        float m_in = lane < G::CIN ? bw.in_info[4 + lane] : 0.0f, m_res = (RES && lane < G::COUT) ? bw.res_info[4 + lane] : 0.0f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            m_in = __builtin_fmaxf(m_in, __shfl_xor(m_in, d, 64));
+            m_res = __builtin_fmaxf(m_res, __shfl_xor(m_res, d, 64));
+        }
+        const float bound = (m_in * bw.wnorm[0] + m_res) * 1.1f;
+        const float sc = (bound > 0.0f && bound < 3.0e38f) ? pow2_at_most(32768.0f / bound) : 1.0f;
+        inv_in = bw.in_info[1] * ACT_UNSCALE;
+        inv_res = RES ? bw.res_info[1] * ACT_UNSCALE : 0.0f;
+        s_out = sc * ACT_SCALE;
+        if (blockIdx.x == 0 && tid == 0) {
+            bw.out_info[0] = sc;
+            bw.out_info[1] = 1.0f / sc;
+        }
     }
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};                                   // (BWD) this lane's channels: sums of what it wrote,
     float cmax = 0.0f;                                                   //       and the largest magnitude among them
@@ -700,7 +724,7 @@ int device_cus()
 
 template <class G, int MODE = WS_INFER>
 int launch_ws(const void *in, const void *wfrag, const float *bias, const void *res, void *out, float *out_f32,
-              float *pre_f32, int64_t B, int apply_mish, hipStream_t st, void *pre_px = nullptr, WsBwd bw = WsBwd{nullptr, nullptr, nullptr},
+              float *pre_f32, int64_t B, int apply_mish, hipStream_t st, void *pre_px = nullptr, WsBwd bw = WsBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
               int *grid_out = nullptr)
 {
     const int64_t nitems = (B + G::IPI - 1) / G::IPI * G::NB;

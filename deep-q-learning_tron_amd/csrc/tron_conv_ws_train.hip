@@ -40,38 +40,6 @@ __global__ __launch_bounds__(64) void k_ws_wnorm(WsJobs jobs, float *__restrict_
     if (threadIdx.x == 0) wnorm[k] = m;
 }
 
-__device__ __forceinline__ float pow2_at_most(float x)                   // the largest power of two <= x (x > 0, finite); exponent clamped to +-60
-{
-    int e = (int)((__float_as_uint(x) >> 23) & 0xFFu) - 127;
-    e = e < -60 ? -60 : (e > 60 ? 60 : e);
-    return __uint_as_float((uint32_t)(e + 127) << 23);
-}
-
-// A gradient image's record is info = {s, 1 / s, -, -} followed by the per-channel maxima chmax[<= 64] (k_wsb_finish): the
-// tensor's maximum is taken where it is needed.
-constexpr int INFO_FLOATS = 4 + 64;
-__device__ __forceinline__ float info_max(const float *info, int C)
-{
-    float m = 0.0f;
-    for (int c = 0; c < C; ++c) m = __builtin_fmaxf(m, info[4 + c]);
-    return m;
-}
-
-// scal = {1 / s_in, 1 / s_res, s_out, -} for one k_conv_ws<WS_BWD> launch; out_info = {s_out, 1 / s_out, ...}
-__global__ void k_wsb_scale(const float *__restrict__ in_info, int c_in, const float *__restrict__ res_info, int c_res,
-                            const float *__restrict__ wnorm, float *__restrict__ scal, float *__restrict__ out_info)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float bound = (info_max(in_info, c_in) * wnorm[0] + (res_info ? info_max(res_info, c_res) : 0.0f)) * 1.1f;
-    const float s = bound > 0.0f && bound < 3.0e38f ? pow2_at_most(32768.0f / bound) : 1.0f;
-    scal[0] = in_info[1];
-    scal[1] = res_info ? res_info[1] : 1.0f;
-    scal[2] = s;
-    scal[3] = 0.0f;
-    out_info[0] = s;
-    out_info[1] = 1.0f / s;
-}
-
 // stats[2][groups][C] of a k_conv_ws<WS_BWD> (or k_gout_px) launch -> bias_grad[c] = the column sums and info[2] = the largest
 // magnitude written.  One workgroup per channel, a thread per group, fixed-order tree: deterministic.  (The first version — one
 // workgroup, one thread per channel walking the groups — took 78 us per call: 256 dependent loads per thread.)
@@ -218,9 +186,9 @@ __global__ __launch_bounds__(256) void k_gout_px(const float *__restrict__ gout,
 // their slabs.  An item = (stack, band): both operands go global -> LDS by LDS-DMA through a per-unit source table (a unit
 // whose destination is halo, separator, padding pixel or plane padding copies from a zero page), double-buffered one item
 // ahead, one barrier per item, the next item's pieces riding between the taps' MFMAs.
-template <int S_, int NI_, int R_, int COT_, int CIT_, int KG_>
+template <int S_, int NI_, int R_, int CO_, int CI_, int COT_, int CIT_, int KG_>
 struct WCfg {
-    static constexpr int S = S_, NI = NI_, R = R_, COT = COT_, CIT = CIT_, KG = KG_;
+    static constexpr int S = S_, NI = NI_, R = R_, CO = CO_, CI = CI_, COT = COT_, CIT = CIT_, KG = KG_;   // (CO / CI: the layer's; COT / CIT: a workgroup's)
     static constexpr int SS = S * S, ROWS = NI * S, NB = (ROWS + R - 1) / R;
     static constexpr int GPX = R * S, NSLAB = (GPX + 31) / 32, GP = NSLAB * 32;
     static constexpr int WR = R + 2 + (NI - 1), WC = S + 2;
@@ -271,9 +239,9 @@ struct WBands { int n[8]; };                                             // work
 
 template <class C>
 __global__ __launch_bounds__(512, 2) void k_wgrad_px(const unsigned char *__restrict__ gimg, const unsigned char *__restrict__ aimg,
-                                                     int B, int CO, int CI, int kinds, WBands bands, float *__restrict__ partial)
+                                                     int B, int kinds, WBands bands, float *__restrict__ partial)
 {
-    constexpr int S = C::S, SS = C::SS;
+    constexpr int S = C::S, SS = C::SS, CO = C::CO, CI = C::CI;
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, g = lane >> 4;
     // workgroup kinds = the (co, ci) channel tiles of a layer one workgroup does not hold whole.  The kinds of one item sit 8
@@ -429,28 +397,34 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_px(const unsigned char *__rest
 }
 
 // dW[co][ci][tap] = (2^12 / s) * sum over the parts of partial[part][tap][co][ci] (both operands carry 2^-6, the gradient its
-// scale s on top).  A workgroup = 64 consecutive outputs x 4 part groups (parts q, q + 4, ...: two chains each), joined in a
-// fixed order: deterministic, and hundreds of workgroups in flight instead of one dependent chain of loads per output.
+// scale s on top).  A workgroup = 64 consecutive outputs (16 threads x float4) x 16 part groups (parts q, q + 16, ...: two chains
+// each), joined in a fixed order: deterministic, wide loads, thousands of independent loads in flight.
 __global__ __launch_bounds__(256) void k_wgrad_px_finish(const float *__restrict__ partial, int nparts, int CO, int CI,
                                                          const float *__restrict__ ginfo, float *__restrict__ gw)
 {
-    __shared__ float red[256];
-    const int total = 9 * CO * CI, i = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
-    float a0 = 0.0f, a1 = 0.0f;
-    if (i < total) {
+    __shared__ f32x4 red[256];
+    const int total = 9 * CO * CI, col = threadIdx.x & 15, pg = threadIdx.x >> 4, i = blockIdx.x * 64 + 4 * col;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    if (i < total) {                                                     // (total is a multiple of 4: whole float4s)
         int p = pg;
-        for (; p + 4 < nparts; p += 8) {
-            a0 += partial[(size_t)p * total + i];
-            a1 += partial[(size_t)(p + 4) * total + i];
+        for (; p + 16 < nparts; p += 32) {
+            a0 += *reinterpret_cast<const f32x4 *>(partial + (size_t)p * total + i);
+            a1 += *reinterpret_cast<const f32x4 *>(partial + (size_t)(p + 16) * total + i);
         }
-        if (p < nparts) a0 += partial[(size_t)p * total + i];
+        if (p < nparts) a0 += *reinterpret_cast<const f32x4 *>(partial + (size_t)p * total + i);
     }
     red[threadIdx.x] = a0 + a1;
     __syncthreads();
-    if (threadIdx.x < 64 && i < total) {
-        const float v = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
-        const int tap = i / (CO * CI), r = i - tap * CO * CI, co = r / CI, ci = r - co * CI;
-        gw[((size_t)co * CI + ci) * 9 + tap] = v * (4096.0f * ginfo[1]);
+    if (threadIdx.x < 16 && i < total) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) v += (red[col + 16 * q] + red[col + 16 * (q + 1)]) + (red[col + 16 * (q + 2)] + red[col + 16 * (q + 3)]);
+        const float unscale = 4096.0f * ginfo[1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = i + r, tap = o / (CO * CI), rem = o - tap * CO * CI, co = rem / CI, ci = rem - co * CI;
+            gw[((size_t)co * CI + ci) * 9 + tap] = v[r] * unscale;
+        }
     }
 }
 
@@ -493,7 +467,7 @@ int launch_wgrad_px(const void *gimg, const void *aimg, const float *ginfo, int6
     for (int b = 0; b < 8; ++b) bands.n[b] = nwg[b];
     const int grid = (used + 7) / 8 * 8 * kinds;                        // (wg = 8 (block / (8 kinds)) + block % 8: whole groups of 8 per kind)
     hipLaunchKernelGGL(k_wgrad_px<C>, dim3((unsigned)grid), dim3(512), C::LDS, st, reinterpret_cast<const unsigned char *>(gimg),
-                       reinterpret_cast<const unsigned char *>(aimg), (int)B, CO, CI, kinds, bands, partial);
+                       reinterpret_cast<const unsigned char *>(aimg), (int)B, kinds, bands, partial);
     hipLaunchKernelGGL(k_wgrad_px_finish, dim3((unsigned)((9 * CO * CI + 63) / 64)), dim3(256), 0, st, partial, (int)parts, CO, CI, ginfo, gw);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
@@ -502,13 +476,13 @@ template <class F>
 int dispatch_wgrad_px(int side, int cin, int cout, F &&f)
 {
     if (side == 12) {
-        if (cin == 64 && cout == 64) return f(WCfg<12, 2, 8, 64, 64, 1>{});
-        if (cin == 32 && cout == 64) return f(WCfg<12, 2, 8, 64, 32, 2>{});
-        if (cin == 32 && cout == 32) return f(WCfg<12, 2, 8, 32, 32, 4>{});
+        if (cin == 64 && cout == 64) return f(WCfg<12, 2, 8, 64, 64, 64, 64, 1>{});
+        if (cin == 32 && cout == 64) return f(WCfg<12, 2, 8, 64, 32, 64, 32, 2>{});
+        if (cin == 32 && cout == 32) return f(WCfg<12, 2, 8, 32, 32, 32, 32, 4>{});
     } else if (side == 26) {
-        if (cin == 64 && cout == 64) return f(WCfg<26, 1, 6, 64, 32, 2>{});
-        if (cin == 32 && cout == 64) return f(WCfg<26, 1, 6, 64, 32, 2>{});
-        if (cin == 32 && cout == 32) return f(WCfg<26, 1, 6, 32, 32, 4>{});
+        if (cin == 64 && cout == 64) return f(WCfg<26, 1, 6, 64, 64, 64, 32, 2>{});
+        if (cin == 32 && cout == 64) return f(WCfg<26, 1, 6, 64, 32, 64, 32, 2>{});
+        if (cin == 32 && cout == 32) return f(WCfg<26, 1, 6, 32, 32, 32, 32, 4>{});
     }
     return TRON_ERR_UNSUPPORTED;
 }
@@ -650,9 +624,7 @@ extern "C" int tron_conv3x3_ws_dgrad(const void *grad_px16, const float *grad_in
     if (tron_conv3x3_ws_dgrad_workspace(cin, cout) == 0) return TRON_ERR_UNSUPPORTED;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float *stats = reinterpret_cast<float *>(workspace);
-    float *scal = stats + (size_t)2 * 1024 * cin;
-    hipLaunchKernelGGL(k_wsb_scale, dim3(1), dim3(1), 0, st, grad_info, cout, extra_px16 ? extra_info : nullptr, cin, wnorm, scal, out_info);
-    WsBwd bw{reinterpret_cast<const unsigned char *>(pre_below_px16), scal, stats};
+    WsBwd bw{reinterpret_cast<const unsigned char *>(pre_below_px16), grad_info, extra_px16 ? extra_info : nullptr, wnorm, out_info, stats};
     int grid = 0, rc = TRON_ERR_UNSUPPORTED;
     // the backward convolution has the forward layer's cout channels in and cin channels out
 #define TRON_WSB_CASE(S_, R_, CI_, CO_, IPI_, WAVES_)                                                                   \

@@ -38,19 +38,28 @@ for key, v in rows.items():
     for c in classes:
         row = {"kernel": key[0], "grid": key[1], "workgroup": key[2], "lds": key[3], "dispatches": len(c),
                "avg_us": sum(c) / len(c), "min_us": min(c), "max_us": max(c), "total_us": sum(c)}
-        m = re.search(r"k_conv_wsINS_3GeoILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEELb(\d)ELb(\d)", key[0])
+        m = re.search(r"k_conv_wsINS_3GeoILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEELb(\d)ELb(\d)(?:ELi(\d))?", key[0])
         if m:
-            S, R, ci, co, ipi, waves, tps, res, f32o = map(int, m.groups())
-            row["shape"] = f"ws {ci}->{co} {S}x{S}" + (" +res" if res else "") + (" general" if f32o else "")
+            S, R, ci, co, ipi, waves, tps, res, f32o = map(int, m.groups()[:9])
+            mode = int(m.group(10) or 0)                                 # 0: gradient-free chain, 1: training forward (+ z), 2: input gradient
+            row["shape"] = (("ws", "ws train", "ws dgrad")[mode] + f" {ci}->{co} {S}x{S}" + (" +res" if res else "") + (" +f32" if f32o else ""))
+            if a.batch:
+                row["flops"] = 2.0 * a.batch * S * S * 9 * ci * co
+                row["tflops_f32_equivalent"] = row["flops"] / row["avg_us"] / 1e6
+        m = re.search(r"k_wgrad_px<.*WCfg<(\d+), (\d+), (\d+), (\d+), (\d+)", key[0]) or re.search(r"k_wgrad_pxINS_4WCfgILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", key[0])
+        if m:
+            S, NI, R, co, ci = map(int, m.groups())
+            row["shape"] = f"wgrad px {ci}->{co} {S}x{S}"
             if a.batch:
                 row["flops"] = 2.0 * a.batch * S * S * 9 * ci * co
                 row["tflops_f32_equivalent"] = row["flops"] / row["avg_us"] / 1e6
         out.append(row)
 tot = sum(r["total_us"] for r in out)
 out.sort(key=lambda r: -r["total_us"])
-print(f"{'kernel':70s} {'grid':>9s} {'wg':>5s} {'n':>5s} {'avg us':>9s} {'min':>9s} {'max':>9s} {'share':>6s}  shape / TFLOP/s")
+W_ = 66
+print(f"{'kernel':{W_}s} {'grid':>9s} {'wg':>5s} {'n':>5s} {'avg us':>9s} {'min':>9s} {'max':>9s} {'share':>6s}  shape / TFLOP/s")
 for r in out:
     extra = r.get("shape", "") + (f"  {r['tflops_f32_equivalent']:.0f} TF/s" if "tflops_f32_equivalent" in r else "")
-    print(f"{r['kernel'][:70]:70s} {r['grid']:>9s} {r['workgroup']:>5s} {r['dispatches']:5d} {r['avg_us']:9.1f} {r['min_us']:9.1f} {r['max_us']:9.1f} {100 * r['total_us'] / tot:5.1f}%  {extra}")
+    print(f"{r['kernel'][:W_]:{W_}s} {r['grid']:>9s} {r['workgroup']:>5s} {r['dispatches']:5d} {r['avg_us']:9.1f} {r['min_us']:9.1f} {r['max_us']:9.1f} {100 * r['total_us'] / tot:5.1f}%  {extra}")
 if a.json:
     json.dump({"dir": a.dir, "batch": a.batch, "rows": out}, open(a.json, "w"), indent=1)
