@@ -235,6 +235,43 @@ def test_dropin_agent_and_batched_trainer():
     assert len(out["brain"].memory) == min(2 * 512 * 12, 1 << 14)
 
 
+def test_batched_dqn_train_cycle():
+    """DQN.train (DQN.py:135-308) on the batched env: cycles of finished games, one smooth-L1 step per cycle on a sample of the
+    device ring, epsilon x 0.999 per finished game, the reference's +100 / -25 / step-index rewards in the ring."""
+    import torch
+    import DQN
+    torch.manual_seed(4)
+    net = DQN.Net(in_channels=1, width=10)
+    w0 = [p.detach().clone() for p in net.parameters()]
+    logs = []
+    out = DQN.train(model=net, n_envs=64, width=10, cycles=3, games_per_cycle=96, batch_size=64, capacity=4096, seed=9, log=logs.append)
+    assert out["cycles"] == 3 and len(out["losses"]) == 3 and all(np.isfinite(out["losses"]))
+    assert out["games"] >= 3 * 96 and out["draws"] + out["wins_p1"] + out["wins_p2"] == out["games"]
+    assert abs(out["epsilon"] - DQN.EPSILON_START * DQN.DECAY_RATE ** out["games"]) < 1e-9          # far from the floor: one decay per game
+    assert any((p.detach().cpu() - q).abs().max().item() > 0 for p, q in zip(out["model"].parameters(), w0))   # the net was trained
+    assert [l["cycle"] for l in logs] == [0, 1, 2] and logs[-1]["games"] == out["games"]
+    # the ring holds the reference's rewards: terminal +100 / -25 / 0, otherwise the step index
+    from tron.vec import VecTron, DeviceReplay
+    env = VecTron(32, 10, seed=2, obs_format="codes", reward="dqn")
+    ring = DeviceReplay(1024, 144, seed=2)
+    codes = env.reset().reshape(64, 12, 12)
+    seen = set()
+    for _ in range(12):
+        ring.add_states(codes)
+        obs, reward, done, winner = env.step(autoreset=False)
+        r, d, w = reward.cpu().numpy(), done.cpu().numpy().astype(bool), winner.cpu().numpy()
+        for i in range(32):
+            if d[i]:
+                want = {0: (0.0, 0.0), 1: (100.0, -25.0), 2: (-25.0, 100.0)}[int(w[i])]
+                assert tuple(r[i]) == want
+                seen.add(int(w[i]))
+            else:
+                assert r[i, 0] == r[i, 1] and r[i, 0] >= 0 and float(r[i, 0]).is_integer()
+        env.reset(mask=done)
+        codes = env.obs.reshape(64, 12, 12)
+    assert seen
+
+
 def test_batched_rating_sweep():
     """play.py:72-98 as one batch: 3 slide values x 400 fair/ice games between two random policies."""
     import play
