@@ -997,16 +997,27 @@ struct W7 {
     static constexpr int G_LO = GROWS * W7_PITCH, P_BASE = 2 * GROWS * W7_PITCH, P_LO = PROWS * W7_PITCH;
     static_assert(LDS <= 160 * 1024 && NSLOT <= 32, "layout");
 };
+// ds_read_b64_tr_b16 by inline asm (EXEC must be all ones).  Behind __builtin_amdgcn_ds_read_tr16_b64 hipcc (ROCm 7.2) puts an
+// s_waitcnt vmcnt(0) in front of the first transposed read that follows an LDS-DMA — the next image's copy, issued right before
+// the multiply, was waited for before the multiply began: no overlap (found on csrc/tron_conv_ws_train.hip's k_wgrad_px, round 4).
+// The asm is invisible to that pass, so the waits are written here: a step's reads go out one step ahead, `lds_tr_wait()`
+// (s_waitcnt lgkmcnt(0) + sched_barrier) stands between a read and the first use of its registers, and the two 8-byte halves
+// are joined into the MFMA operand only after that wait.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ s16x4 lds_tr(const unsigned char *p)           // ds_read_b64_tr_b16 (EXEC must be all ones)
+__device__ __forceinline__ s16x4 lds_tr(uint32_t addr)
 {
-    typedef __attribute__((address_space(3))) s16x4 lds_v;
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v *)p);
+    s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=&v"(r) : "v"(addr));
+    return r;
 }
-__device__ __forceinline__ f16x8 lds_tr8(const unsigned char *p0, const unsigned char *p1)
+__device__ __forceinline__ void lds_tr_wait()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ f16x8 join8(s16x4 a, s16x4 b)
 {
     typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x4 a = lds_tr(p0), b = lds_tr(p1);
     const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return __builtin_bit_cast(f16x8, v);
 }
@@ -1084,38 +1095,52 @@ __global__ __launch_bounds__(W7_THREADS) void k_conv7_wgrad(const f16 *__restric
     // One (slab, tap) step = 12 MFMAs; the next step's pooled fragments (and, at a slab's last tap, the next slab's gradient
     // fragments) are requested first and land under them.  The sched_barrier keeps the compiler from hoisting every read of
     // the image to the top (which it does at one wave per SIMD, and then spills).
-    auto multiply = [&](const unsigned char *S) {
-        f16x8 ah[4], al[4], bh, bl;
-        auto load_a = [&](int s) {
+    auto multiply = [&](const unsigned char *Sp) {
+        const uint32_t S = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char *)Sp;
+        s16x4 ra[2][4][4], rb[2][4];                                     // raw halves: gradient [slab parity][tile][h0 h1 l0 l1], pooled [step parity][h0 h1 l0 l1]
+        auto read_a = [&](int slot, int s) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                ah[t] = lds_tr8(S + a_addr[s][0] + 32 * t, S + a_addr[s][1] + 32 * t);
-                al[t] = lds_tr8(S + C::G_LO + a_addr[s][0] + 32 * t, S + C::G_LO + a_addr[s][1] + 32 * t);
+                ra[slot][t][0] = lds_tr(S + a_addr[s][0] + 32 * t);
+                ra[slot][t][1] = lds_tr(S + a_addr[s][1] + 32 * t);
+                ra[slot][t][2] = lds_tr(S + C::G_LO + a_addr[s][0] + 32 * t);
+                ra[slot][t][3] = lds_tr(S + C::G_LO + a_addr[s][1] + 32 * t);
             }
         };
-        load_a(0);
-        bh = lds_tr8(S + b_addr[0][0][0], S + b_addr[0][0][1]);
-        bl = lds_tr8(S + C::P_LO + b_addr[0][0][0], S + C::P_LO + b_addr[0][0][1]);
+        auto read_b = [&](int slot, int kx, int s) {
+            rb[slot][0] = lds_tr(S + b_addr[kx][s][0]);
+            rb[slot][1] = lds_tr(S + b_addr[kx][s][1]);
+            rb[slot][2] = lds_tr(S + C::P_LO + b_addr[kx][s][0]);
+            rb[slot][3] = lds_tr(S + C::P_LO + b_addr[kx][s][1]);
+        };
+        read_a(0, 0);
+        read_b(0, 0, 0);
+        f16x8 ah[4], al[4];
 #pragma unroll
         for (int s = 0; s < C::SLABS; ++s)
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
-                const f16x8 ch = bh, cl = bl;
-                f16x8 a0[4], a1[4];
+                const int step = s * 7 + kx;
+                lds_tr_wait();                                           // this step's operands have landed
+                if (kx == 0) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { a0[t] = ah[t]; a1[t] = al[t]; }
+                    for (int t = 0; t < 4; ++t) {
+                        ah[t] = join8(ra[s & 1][t][0], ra[s & 1][t][1]);
+                        al[t] = join8(ra[s & 1][t][2], ra[s & 1][t][3]);
+                    }
+                }
+                const f16x8 ch = join8(rb[step & 1][0], rb[step & 1][1]), cl = join8(rb[step & 1][2], rb[step & 1][3]);
                 const int nk = kx == 6 ? 0 : kx + 1, ns = kx == 6 ? s + 1 : s;
                 if (ns < C::SLABS) {
-                    bh = lds_tr8(S + b_addr[nk][ns][0], S + b_addr[nk][ns][1]);
-                    bl = lds_tr8(S + C::P_LO + b_addr[nk][ns][0], S + C::P_LO + b_addr[nk][ns][1]);
-                    if (kx == 6) load_a(ns);
+                    read_b((step + 1) & 1, nk, ns);
+                    if (kx == 6) read_a(ns & 1, ns);
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc1[kx][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[t], cl, acc1[kx][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc1[kx][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], cl, acc1[kx][t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc0[kx][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[t], ch, acc0[kx][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc0[kx][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], ch, acc0[kx][t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc1[kx][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[t], ch, acc1[kx][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc1[kx][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], ch, acc1[kx][t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
