@@ -4,7 +4,7 @@ board side are parameters, so fc1 is sized from the grid instead of hard-wired t
 Parameter names/shapes are the reference's (22 tensors, 501 924 parameters at 4 channels,
 12x12), so `torch.save(state_dict)` .bak files interchange.
 
-The network is compute-bound on matrix throughput (36 MFLOP per 12x12 sample; DESIGN.md 4b), so its layers run on the
+The network is compute-bound on matrix throughput (36 MFLOP per 12x12 sample; DESIGN.md §5), so its layers run on the
 hand-written kernels of csrc/: the 3x3 convolutions forward / input gradient / weight gradient (tron_conv*.hip), the
 pooling + conv7 + linear + arg-max head of gradient-free forwards (tron_head.hip, `Net.infer`), pooling + conv7 as
 GEMMs on conv7's dense form when training.  Shapes those kernels do not cover, and CPU tensors, take the PyTorch

@@ -97,7 +97,7 @@ __device__ __forceinline__ float mish1(float x)                         // as in
 }
 
 // Four values at once, written on vectors so that the compiler packs the arithmetic two per instruction (v_pk_*): the
-// epilogue is VALU-issue-bound.  No select for large x: e^x is capped at 1e18 (an unsigned integer min
+// epilogue is VALU-issue-bound (docs/DESIGN_history_r01_r03.md 4b).  No select for large x: e^x is capped at 1e18 (an unsigned integer min
 // on the bits — e is never negative — so no NaN-canonicalising v_max comes with it); n = e (e + 2) then stays finite
 // and n / (n + 2) is exactly 1 up there, so the product is x itself.  One rcp (1 ulp), no Newton step.
 __device__ __forceinline__ f32x4 mish4(f32x4 x)

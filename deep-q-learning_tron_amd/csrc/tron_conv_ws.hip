@@ -2,7 +2,7 @@
 // gradient-free forwards, WEIGHT-STATIONARY on the split-f16 matrix cores (the arithmetic of tron_conv_f16.hip:
 // v = hi + lo 2^-11, three v_mfma_f32_16x16x32_f16 per k-slab, f32 accumulation).
 //
-// What bounded tron_conv_f16.hip (wave stamps): every 16-channel chunk re-pulled 41 KB of split weights
+// What bounded tron_conv_f16.hip (docs/DESIGN_history_r01_r03.md 4b, wave stamps): every 16-channel chunk re-pulled 41 KB of split weights
 // from L2 into LDS per workgroup, input pieces were converted and stored to LDS by VALU work inside the MFMA loop, and
 // the epilogue wrote the next layer's operand image with 2-byte stores.  Here
 //   * the WEIGHTS LIVE IN REGISTERS for the whole launch: GEMM view M = output channels, N = pixels, K = taps x input
