@@ -206,32 +206,6 @@ struct WCfg {
     static_assert(2 * NI * 8 * SS < 0xFFFF, "source offsets in 16 bits");
 };
 
-// ds_read_b64_tr_b16 by inline asm, not by __builtin_amdgcn_ds_read_tr16_b64: behind the builtin hipcc (ROCm 7.2) puts an
-// s_waitcnt vmcnt(0) in front of every transposed read that follows an LDS-DMA (it cannot tell the read from the copy's
-// destination), which serialised each of an item's nine copies with the multiply — 11 us per item instead of 3 (the .s showed
-// ten vmcnt(0) per item).  The asm is invisible to that pass; what it costs is that the waits are ours: the reads of a tap go
-// out one tap ahead, `lds_wait()` (s_waitcnt lgkmcnt(0) + sched_barrier, so that no consumer moves above it) stands between a
-// read and the first use of its registers, and the two 8-byte halves are joined into the MFMA operand only AFTER that wait (a
-// copy the compiler might make of them then reads landed data).  EXEC must be all ones (the read crosses lanes).
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ s16x4 lds_tr(uint32_t addr)
-{
-    s16x4 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=&v"(r) : "v"(addr));
-    return r;
-}
-__device__ __forceinline__ void lds_wait()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ f16x8 join8(s16x4 a, s16x4 b)
-{
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    return __builtin_bit_cast(f16x8, v);
-}
-
 // row index (with halo and separator rows counted) of stack row t: image i = t / S occupies e = i (S + 1) + 1 ... i (S + 1) + S
 template <class C> __device__ __forceinline__ int stack_e(int t) { return t + t / C::S + 1; }
 

@@ -16,6 +16,8 @@
 #include <stdint.h>
 
 #include "../../include/tron_hip.h"
+#include "tron_kfac_px.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -621,6 +623,11 @@ inline bool nchw_gram_geometry(int32_t channels, int32_t kh, int32_t kw, int32_t
 {
     return kh == 1 && kw == 1 && pad == 0 && stride == 1 && (channels == 32 || channels == 64) && per % 4 == 0;
 }
+inline bool kfac_px_enabled()                                            // TRON_KFAC_PX=0: the patch-matrix path (A/B measurements)
+{
+    static const bool on = [] { const char *e = getenv("TRON_KFAC_PX"); return !(e && e[0] == '0'); }();
+    return on;
+}
 inline int nchw_gram_splits(int64_t batch) { return (int)(batch < 2048 ? batch : 2048); }
 inline int64_t nchw_gram_bytes(int64_t batch, int32_t channels)
 {
@@ -637,6 +644,10 @@ extern "C" int64_t tron_kfac_patch_gram_workspace(int64_t batch, int32_t channel
     if (OH < 1 || OW < 1 || (int64_t)channels * kh * kw > 8192) return 0;
     const int64_t per = (int64_t)OH * OW;
     int64_t need = gram_plan(batch * per, per, channels * kh * kw).total;
+    if (kfac_px_enabled() && tron_kfac_px_supported(batch, channels, height, width, kh, kw, pad, stride)) {
+        const int64_t px = tron_kfac_px_workspace(batch, channels, height);
+        if (px > need) need = px;
+    }
     if (nchw_gram_geometry(channels, kh, kw, pad, stride, per)) {
         const int64_t direct = nchw_gram_bytes(batch, channels);
         if (direct > need) need = direct;
@@ -658,6 +669,10 @@ extern "C" int tron_kfac_patch_gram(const float *x, int64_t batch, int32_t chann
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (batch == 0) return hipMemsetAsync(gram, 0, (size_t)d * d * sizeof(float), st) == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
     const int64_t per = (int64_t)OH * OW;
+    // a 3x3 / pad 1 / stride 1 layer's input factor at the trunk's shapes: from the image's PX16 window, no patch matrix (csrc/tron_kfac_px.hip)
+    if (!in_scale && kfac_px_enabled() && tron_kfac_px_supported(batch, channels, height, width, kh, kw, pad, stride) &&
+        tron_kfac_px_workspace(batch, channels, height) > 0)
+        return tron_kfac_px_gram(x, batch, channels, height, scale, gram, workspace, st);
     if (nchw_gram_geometry(channels, kh, kw, pad, stride, per) && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
         // a gradient factor (or any 1x1 "patch matrix"): straight from the NCHW tensor, k_gram_nchw
         const int nsplit = nchw_gram_splits(batch);
