@@ -132,6 +132,30 @@ __device__ __forceinline__ void kfac_px_body(const unsigned char *__restrict__ x
 #pragma unroll
         for (int t = 0; t < 2; ++t) acc0[k][t] = acc1[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // partial[kind][part][pair][c][c'], part = (workgroup, kgroup); D row = 4 g + r -> c within the tile, column li -> c'.
+    // The matrix unit's f32 accumulate is not round-to-nearest over a long chain: an all-positive sum (the factor's diagonal) drifts
+    // low by ~3.6e-10 of the sum per MFMA (measured: -2.4e-6 after 6 700 steps at 8 192 x 34 x 34), so a wave adds its accumulators
+    // into its own slots of `partial` every FLUSH_STEPS slab steps (VALU adds, IEEE) and starts them again from zero.
+    float *out = partial + ((size_t)wg * C::KG + kgroup) * 9 * CH * CH;
+    auto spill = [&](bool add) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4 v = acc0[i][t] + acc1[i][t] * LO_UNSCALE;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float *o = out + ((size_t)i * CH + 32 * cot2 + 16 * t + 4 * g + r) * CH + 16 * cit + li;
+                    *o = add ? *o + v[r] : v[r];
+                }
+                acc0[i][t] = acc1[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+    };
+    constexpr int FLUSH_STEPS = 256;
+    const int steps_per_stack = kgroup < nslab ? (nslab - kgroup + C::KG - 1) / C::KG : 0;
+    int since = 0;
+    bool wrote = false;
+
     __syncthreads();
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
     int stack = wb;
@@ -204,18 +228,15 @@ __device__ __forceinline__ void kfac_px_body(const unsigned char *__restrict__ x
             }
         }
         for (; pj < C::PPW; ++pj) dma_piece(nxt, cur ^ 1, pj);
+        since += steps_per_stack;
+        if (since >= FLUSH_STEPS && nxt < nstack) {                      // (wave-uniform; the last stack's sums go out below)
+            spill(wrote);
+            wrote = true;
+            since = 0;
+        }
     }
 
-    // partial[kind][part][pair][c][c'], part = (workgroup, kgroup); D row = 4 g + r -> c within the tile, column li -> c'
-    float *out = partial + ((size_t)wg * C::KG + kgroup) * 9 * CH * CH;
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x4 v = acc0[i][t] + acc1[i][t] * LO_UNSCALE;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[((size_t)i * CH + 32 * cot2 + 16 * t + 4 * g + r) * CH + 16 * cit + li] = v[r];
-        }
+    spill(wrote);
 }
 
 template <class C>
