@@ -8,7 +8,9 @@ replaced by fresh ones.  Workload = BASELINE.json configs[2]'s env side: 65 536 
 GPU, mode=None.
 
 The timed region (K steps, bracketed by barrier + synchronize, MAX over ranks) is repeated R times
-(--repeats, default 5); `value` is the median repeat, min / max are in the line.  Two further records ride
+(--repeats, default 5); `value` is the median repeat, min / max are in the line.  Order: W warm-up steps, the
+K steps timed as they are then (`cold_start`: the chip was idle before the warm-up), --settle-steps further
+untimed steps (the same launches, back to back), then the R timed regions of the headline.  Further records ride
 on the same line: `per_step_launches` (the same K steps as one kernel launch per step — what a caller that
 supplies actions every step gets) and `dqn` (DDQN.train at BASELINE configs[1]: env-steps/s with the
 epsilon-greedy CNN policy in the loop and transitions/s consumed by learn()).
@@ -335,6 +337,11 @@ def main():
     ap.add_argument("--acktr", action="store_true", help="print the ACKTR record instead (BASELINE configs[4]: 16 384 envs 32x32)")
     ap.add_argument("--acktr-iterations", type=int, default=2)
     ap.add_argument("--dqn3-steps", type=int, default=8, help="config-3 DQN record (65 536 envs x 24x24): env steps per timed region")
+    ap.add_argument("--settle-steps", type=int, default=6400,
+                    help="untimed steps (in launches of --steps) run after the --warmup steps and before the timed regions, so that "
+                         "the timed K steps see the clocks of a chip under load: from an idle chip the same launch is 5-12 %% slower "
+                         "for the first tens of milliseconds (scripts/roll_fixed_cost.sh).  The K steps timed right after --warmup "
+                         "alone are reported beside the headline as `cold_start`; 0 = skip (the headline is then the cold figure)")
     ap.add_argument("--only-rollout", action="store_true",
                     help="profiling runs: the warm-up and the timed persistent-rollout launches only (no per-step, two-stream "
                          "or resident passes, no temper / DQN / CPU records), so that every dispatch of the step kernel in a "
@@ -458,16 +465,27 @@ def main():
             def run(k, per_step=False, two=False, resident=main_resident):
                 env.rollout_random(k, nonreversing=nonrev, per_step_launches=per_step, two_streams=two, resident=resident)
         run(args.warmup)
-        for _ in range(max(1, args.repeats)):
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            barrier()
-            t0 = time.perf_counter()
-            ev0.record()                           # same stream the kernels are launched on
-            run(args.steps)
-            ev1.record()
-            barrier()
-            walls.append(max_over_ranks(time.perf_counter() - t0, world))
-            dev_ms.append(ev0.elapsed_time(ev1))
+
+        def timed_regions(n):
+            w, d = [], []
+            for _ in range(n):
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                barrier()
+                t0 = time.perf_counter()
+                ev0.record()                       # same stream the kernels are launched on
+                run(args.steps)
+                ev1.record()
+                barrier()
+                w.append(max_over_ranks(time.perf_counter() - t0, world))
+                d.append(ev0.elapsed_time(ev1))
+            return w, d
+        cold_walls, cold_ms, settled = None, None, 0
+        if args.settle_steps > args.warmup:
+            cold_walls, cold_ms = timed_regions(max(1, min(args.repeats, 3)))
+            while settled < args.settle_steps:     # the same launches as the timed ones, back to back, untimed
+                run(args.steps)
+                settled += args.steps
+        walls, dev_ms = timed_regions(max(1, args.repeats))
         # the same K steps as one launch per step (what a caller that supplies actions every step gets)
         if not args.incremental and not args.only_rollout and not os.environ.get("TRON_ROLL_PER_STEP"):
             run(min(args.warmup, 16), True)
@@ -579,6 +597,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": settled,
             "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -611,6 +630,17 @@ def main():
                          "alg_bytes_per_env_step": b_alg,
                          "alg_bytes_per_launch": b_alg * args.envs * args.steps / n_launches},
         }
+        if cold_walls:
+            cw, cm = statistics.median(cold_walls), statistics.median(cold_ms)
+            c_ach = b_alg * args.envs / (cm / args.steps * 1e-3) / 1e9
+            out["cold_start"] = {
+                "metric": "env-steps/sec, the same K steps timed right after the --warmup steps alone (chip idle before them)",
+                "value": total_env_steps / cw, "ms_per_step": cw / args.steps * 1e3, "repeats": len(cold_walls),
+                "kernel_ms": cm / n_launches, "kernel_ms_min_max": [min(cold_ms) / n_launches, max(cold_ms) / n_launches],
+                "roofline": {"bound": "hbm", "achieved": c_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c_ach / HBM_PEAK_GBS},
+                "note": f"the headline's timed regions follow {settled} further untimed steps (the same launches back to back): "
+                        "the step kernel is HBM-bound and the same launch runs 5-12 % slower on a chip that was idle tens of "
+                        "milliseconds earlier (profiles/r04_roll_fixed_cost.txt); a trainer steps continuously"}
         if per_step_ms:
             ps = statistics.median(per_step_ms)
             ps_ach = b_alg * args.envs / (ps * 1e-3) / 1e9
