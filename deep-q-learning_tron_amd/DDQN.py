@@ -87,6 +87,64 @@ def _world(group=None):
     return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
 
+class AdamSoft(optim.Adam):
+    """optim.Adam (DDQN.py:52: defaults, no weight decay / amsgrad) whose step() on device tensors is ONE launch that also applies
+    Agent.soft_update to the target net's tensors (csrc/tron_dqn.hip::k_adam_soft; torch's fused form + the soft update: four
+    launches, 75 us per learn step).  The state is torch's own (`step`, `exp_avg`, `exp_avg_sq` per parameter: state_dict() /
+    load_state_dict() interchange with optim.Adam); `step` counters are host scalars.  Host tensors take optim.Adam's step."""
+
+    def __init__(self, params, **kw):
+        super().__init__(params, foreach=False, fused=False, capturable=False, **kw)
+
+    @torch.no_grad()
+    def step(self, closure=None, targets=None, tau=0.0):
+        """targets: the target net's parameters, in the order of this optimizer's; theta_t <- tau theta + (1 - tau) theta_t after
+        the step (DDQN.py:153-165).  Returns True when the soft update was applied here."""
+        params = [p for g in self.param_groups for p in g["params"]]
+        if not params or not params[0].is_cuda:
+            super().step(closure)
+            return False
+        import ctypes as C
+        from tron import _native as nat
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("AdamSoft: one parameter group")
+        grp = self.param_groups[0]
+        if grp["weight_decay"] or grp["amsgrad"] or grp["maximize"]:
+            raise NotImplementedError("AdamSoft: plain Adam only")
+        targets = list(targets) if targets is not None else None
+        if targets is not None and len(targets) != len(params):
+            raise ValueError("AdamSoft.step: one target tensor per parameter")
+        n = len(params)
+        P, G, M, V, T = ((C.c_void_p * n)() for _ in range(5))
+        numel, steps = (C.c_int64 * n)(), (C.c_double * n)()
+        for k, p in enumerate(params):
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise TypeError("AdamSoft: contiguous f32 parameters")
+            P[k], numel[k] = p.data_ptr(), p.numel()
+            if targets is not None:
+                if targets[k].shape != p.shape or targets[k].dtype != torch.float32 or not targets[k].is_contiguous():
+                    raise TypeError("AdamSoft: targets must match the parameters")
+                T[k] = targets[k].data_ptr()
+            if p.grad is None:
+                continue
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.is_sparse:
+                raise TypeError("AdamSoft: contiguous dense f32 gradients")
+            st = self.state[p]
+            if len(st) == 0:                                             # optim.Adam._init_group
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if st["step"].is_cuda:                                       # (a checkpoint of the fused form keeps them on the device)
+                st["step"] = st["step"].detach().cpu()
+            st["step"] += 1
+            G[k], M[k], V[k], steps[k] = g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), float(st["step"])
+        b1, b2 = grp["betas"]
+        nat.check(nat.lib().tron_adam_soft_update(n, P, G, M, V, T if targets is not None else None, numel, steps, float(grp["lr"]),
+                                                  float(b1), float(b2), float(grp["eps"]), float(tau), nat.stream_ptr()), "tron_adam_soft_update")
+        return targets is not None
+
+
 def all_reduce_mean_(flat, group=None):
     """flat <- mean over the ranks of flat, in place: ONE collective for the whole gradient (2.0 MB at 12x12, 4.6 MB at
     26x26: latency-bound on xGMI, so a single bucket).  RCCL for device tensors; the gloo rehearsal backend (several ranks
@@ -164,10 +222,11 @@ class Agent():
         self.qnetwork_target = Net(in_channels, width).to(self.device)
         self.action_size = 4
         self.steps = 0
-        # DDQN.py:52.  On the GPU the update of all 22 tensors is one fused launch (the per-tensor loop is 22 x 5 small kernels,
-        # the multi-tensor form still six); TRON_ADAM_FUSED=0 keeps the multi-tensor form.
+        # DDQN.py:52.  On the GPU the update of all 22 tensors AND the soft update of the target net are one launch (AdamSoft; the
+        # per-tensor loop is 22 x 5 small kernels, torch's fused form + a multi-tensor soft update four); TRON_ADAM_FUSED=0 keeps
+        # torch's multi-tensor form.
         fused = self.device.type == "cuda" and os.environ.get("TRON_ADAM_FUSED", "1") != "0"
-        self.optimizer = optim.Adam(self.qnetwork_local.parameters(), fused=True) if fused else optim.Adam(self.qnetwork_local.parameters())
+        self.optimizer = AdamSoft(self.qnetwork_local.parameters()) if fused else optim.Adam(self.qnetwork_local.parameters())
         self.epsilon = 0
         # act_batch's exploration draws: Philox keyed (seed, rank) at counter (observation, call).  The reference's
         # random.random() (DDQN.py:105) is unseeded, so without a seed the key comes from the OS; the call counter is part of
@@ -259,8 +318,10 @@ class Agent():
             return
         if getattr(self, "_pending_on_side", False):
             torch.cuda.current_stream(self.device).wait_stream(self._side)
-        self.optimizer.step()
-        self.soft_update(self.qnetwork_local, self.qnetwork_target, TAU)
+        if not (isinstance(self.optimizer, AdamSoft) and self.optimizer.step(targets=self.qnetwork_target.parameters(), tau=TAU)):
+            if not isinstance(self.optimizer, AdamSoft):
+                self.optimizer.step()
+            self.soft_update(self.qnetwork_local, self.qnetwork_target, TAU)
         self._pending = self._pending_on_side = False
 
     def learn(self, experiences, gamma, defer=False):           # DDQN.py:115-151

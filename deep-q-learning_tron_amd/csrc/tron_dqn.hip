@@ -264,6 +264,87 @@ extern "C" int tron_linear_wgrad(const float *grad_out, const float *input, int6
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
 
+// ---- Adam + soft update of every parameter tensor in one launch (DDQN.py:52,149-150,153-165) -----------------------------------
+// torch's fused Adam is one multi-tensor launch of 43 us for these 22 tensors (0.5-1.2 M elements: a block walks its tensor's chunks
+// in turn), its step counters a second launch, the soft update two more (75 us per learn step together); the arithmetic is 5 reads
+// and 4 writes of 2-5 MB.  Here the tensors' pointers ride in the kernel arguments and a block = one 1 024-element chunk of one tensor.
+namespace {
+struct AdamJobs {
+    float *p[TRON_ADAM_MAX_TENSORS], *m[TRON_ADAM_MAX_TENSORS], *v[TRON_ADAM_MAX_TENSORS], *t[TRON_ADAM_MAX_TENSORS];
+    const float *g[TRON_ADAM_MAX_TENSORS];
+    int chunk0[TRON_ADAM_MAX_TENSORS + 1];                               // first chunk of tensor k (prefix sums)
+    int numel[TRON_ADAM_MAX_TENSORS];
+    float step_size[TRON_ADAM_MAX_TENSORS], bc2_sqrt[TRON_ADAM_MAX_TENSORS];
+    int n;
+};
+constexpr int ADAM_CHUNK = 1024;
+__global__ __launch_bounds__(256) void k_adam_soft(AdamJobs J, float beta1, float beta2, float eps, float tau)
+{
+    int k = 0;
+    while (k + 1 < J.n && (int)blockIdx.x >= J.chunk0[k + 1]) ++k;       // (block-uniform: scalar loads from the kernel arguments)
+    const int base = ((int)blockIdx.x - J.chunk0[k]) * ADAM_CHUNK, n = J.numel[k];
+    float *__restrict__ p = J.p[k], *__restrict__ m = J.m[k], *__restrict__ v = J.v[k], *__restrict__ t = J.t[k];
+    const float *__restrict__ g = J.g[k];
+    const float ss = J.step_size[k], bc = J.bc2_sqrt[k];
+#pragma unroll
+    for (int j = 0; j < ADAM_CHUNK / 256; ++j) {
+        const int i = base + j * 256 + (int)threadIdx.x;
+        if (i >= n) break;
+        float w = p[i];
+        if (g) {
+            // torch/optim's single-tensor formulas in f32: m <- lerp(m, g, 1 - b1); v <- b2 v + (1 - b2) g g;
+            // w <- w - (lr / (1 - b1^step)) m / (sqrt(v) / sqrt(1 - b2^step) + eps)
+            const float gi = g[i];
+            const float mi = __fmaf_rn(1.0f - beta1, gi - m[i], m[i]);
+            const float vi = __fmaf_rn(beta2, v[i], (1.0f - beta2) * gi * gi);
+            m[i] = mi;
+            v[i] = vi;
+            w -= ss * (mi / (__fsqrt_rn(vi) / bc + eps));
+            p[i] = w;
+        }
+        if (t) t[i] = __fmaf_rn(tau, w, (1.0f - tau) * t[i]);           // theta_target <- tau theta + (1 - tau) theta_target
+    }
+}
+}  // namespace
+
+extern "C" int tron_adam_soft_update(int32_t n, float *const *params, const float *const *grads, float *const *exp_avg,
+                                     float *const *exp_avg_sq, float *const *targets, const int64_t *numel, const double *steps,
+                                     double lr, double beta1, double beta2, double eps, double tau, void *stream)
+{
+    if (n < 0 || (n && (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !steps))) return TRON_ERR_BAD_ARG;
+    if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0 && tau >= 0.0 && tau <= 1.0)) return TRON_ERR_BAD_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int k = 0; k < n;) {
+        AdamJobs J{};
+        int cnt = 0;
+        J.chunk0[0] = 0;
+        for (; k < n && cnt < TRON_ADAM_MAX_TENSORS; ++k) {
+            if (!params[k] || numel[k] < 0 || numel[k] >= (1ll << 31) - ADAM_CHUNK) return TRON_ERR_BAD_ARG;
+            if (grads[k] && (!exp_avg[k] || !exp_avg_sq[k] || !(steps[k] >= 1.0))) return TRON_ERR_BAD_ARG;
+            if (numel[k] == 0 || (!grads[k] && !(targets && targets[k]))) continue;
+            J.p[cnt] = params[k];
+            J.g[cnt] = grads[k];
+            J.m[cnt] = exp_avg[k];
+            J.v[cnt] = exp_avg_sq[k];
+            J.t[cnt] = targets ? targets[k] : nullptr;
+            J.numel[cnt] = (int)numel[k];
+            if (grads[k]) {
+                J.step_size[cnt] = (float)(lr / (1.0 - pow(beta1, steps[k])));
+                J.bc2_sqrt[cnt] = (float)sqrt(1.0 - pow(beta2, steps[k]));
+            }
+            const int64_t chunks = (numel[k] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+            if ((int64_t)J.chunk0[cnt] + chunks >= (1ll << 31)) return TRON_ERR_UNSUPPORTED;
+            J.chunk0[cnt + 1] = J.chunk0[cnt] + (int)chunks;
+            ++cnt;
+        }
+        J.n = cnt;
+        if (!cnt) continue;
+        hipLaunchKernelGGL(k_adam_soft, dim3((unsigned)J.chunk0[cnt]), dim3(256), 0, st, J, (float)beta1, (float)beta2, (float)eps, (float)tau);
+        if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
+    }
+    return TRON_OK;
+}
+
 extern "C" int tron_absmax_pow2(const float *x, int64_t n, int32_t target_exp, float *out4, void *stream)
 {
     if (!x || !out4 || n < 0 || target_exp < -60 || target_exp > 60) return TRON_ERR_BAD_ARG;

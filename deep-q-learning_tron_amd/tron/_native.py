@@ -14,7 +14,7 @@ MODE = {None: 0, "none": 0, "ice": 1, "temper": 2}                 # tron/game.p
 OBS_NONE, OBS_CODES_I8, OBS_PLANES3_F32, OBS_PLANES4_F32 = 0, 1, 2, 3
 OBS = {None: OBS_NONE, "none": OBS_NONE, "codes": OBS_CODES_I8, "planes3": OBS_PLANES3_F32,
        "planes4": OBS_PLANES4_F32}
-ABI_VERSION = 9                                                    # include/tron_hip.h TRON_ABI_VERSION
+ABI_VERSION = 10                                                    # include/tron_hip.h TRON_ABI_VERSION
 STEP_AUTORESET = 1
 STEP_INCREMENTAL = 2
 STEP_NONREVERSING = 4
@@ -88,6 +88,7 @@ SIGNATURES = {
     "tron_absmax_pow2": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "tron_linear_wgrad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "tron_linear_wgrad_workspace": (C.c_int64, [_i64, _i32, _i32]),
+    "tron_adam_soft_update": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _vp]),
     "tron_ddqn_td_loss": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp, _vp, _vp]),
     "tron_eps_greedy": (C.c_int, [_vp, _i64, _vp, C.c_uint32, C.c_uint32, C.c_uint64, _vp, _vp]),
     "tron_eps_schedule": (C.c_int, [_vp, _i64, _vp, _i64, C.c_double, C.c_double, _vp, _vp, _vp]),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TRON_ABI_VERSION 9
+#define TRON_ABI_VERSION 10
 
 typedef enum {
     TRON_OK = 0,
@@ -262,6 +262,16 @@ int tron_absmax_pow2(const float *x, int64_t n, int32_t target_exp, float *out4,
 int tron_linear_wgrad(const float *grad_out, const float *input, int64_t batch, int32_t out_features, int32_t in_features,
                       float *grad_weight, float *grad_bias, void *workspace, void *stream);
 int64_t tron_linear_wgrad_workspace(int64_t batch, int32_t out_features, int32_t in_features);
+/* optim.Adam's step (DDQN.py:52,149-150: no weight decay, no amsgrad) and Agent.soft_update (DDQN.py:153-165) for n parameter
+ * tensors in one launch per TRON_ADAM_MAX_TENSORS tensors.  For tensor k (numel[k] f32 elements, device pointers in HOST arrays):
+ *   m <- m + (1 - beta1)(g - m);  v <- beta2 v + (1 - beta2) g g;
+ *   w <- w - lr / (1 - beta1^steps[k]) * m / (sqrt(v) / sqrt(1 - beta2^steps[k]) + eps)      (steps[k] >= 1: the count INCLUDING this step)
+ *   target <- tau w + (1 - tau) target                                                     (targets == NULL or targets[k] == NULL: skipped)
+ * grads[k] == NULL: that tensor takes no Adam step (its soft update still runs).  The bias corrections are computed in double on the host. */
+#define TRON_ADAM_MAX_TENSORS 32
+int tron_adam_soft_update(int32_t n, float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                          float *const *targets, const int64_t *numel, const double *steps, double lr, double beta1, double beta2,
+                          double eps, double tau, void *stream);
 int tron_ddqn_td_loss(const float *q, const int64_t *actions, const float *rewards, const float *dones,
                       const float *q_local_next, const float *q_target_next, float gamma, int64_t batch, float *loss,
                       float *grad_q, void *stream);

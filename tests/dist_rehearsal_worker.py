@@ -53,7 +53,7 @@ def main(out_dir):
     mem, brain.memory, brain._side = brain.memory, None, None            # (the ring's handle and the stream are not copyable; both agents share the ring)
     twin = copy.deepcopy(brain)
     brain.memory = mem
-    twin.optimizer = torch.optim.Adam(twin.qnetwork_local.parameters(), fused=bool(brain.optimizer.defaults.get("fused")))
+    twin.optimizer = type(brain.optimizer)(twin.qnetwork_local.parameters())
     twin.optimizer.load_state_dict(copy.deepcopy(brain.optimizer.state_dict()))   # (load_state_dict keeps tensors that already match: without the copy both optimizers would update ONE set of moments)
     twin.memory = brain.memory
     twin._side = None

@@ -131,7 +131,7 @@ def test_flat_gradient_buffer_and_deferred_update():
     a1.qnetwork_local.dropout.p = 0.0
     a1.force_flat_grads = True                 # (what one-rank-per-GPU runs use; a single process lets autograd assign the gradients)
     a2 = copy.deepcopy(a1)
-    a2.optimizer = torch.optim.Adam(a2.qnetwork_local.parameters(), fused=bool(a1.optimizer.defaults.get("fused")))   # (as Agent builds it)
+    a2.optimizer = type(a1.optimizer)(a2.qnetwork_local.parameters())      # (as Agent builds it)
     for step in range(3):
         s, s2 = _codes(B, W + 2, step), _codes(B, W + 2, 50 + step)
         act = torch.randint(0, 4, (B, 1), device="cuda")
@@ -146,6 +146,52 @@ def test_flat_gradient_buffer_and_deferred_update():
         assert torch.equal(torch.cat([p.grad.reshape(-1) for p in a1.qnetwork_local.parameters()]), flat)
     for p, q in zip(a1.qnetwork_local.parameters(), a2.qnetwork_local.parameters()):
         assert torch.equal(p, q)
+
+
+def test_adam_soft_is_adam_then_soft_update():
+    """DDQN.AdamSoft (one launch: Adam's step of every tensor + the target net's soft update, DDQN.py:52,149-165) against
+    torch.optim.Adam + the reference's soft-update formula over five steps: parameters with gradients that are views of one flat
+    buffer at odd offsets, one parameter without a gradient (no Adam step, soft update still applied), more tensors than one
+    launch holds; the state interchanges with optim.Adam's."""
+    import DDQN
+    torch.manual_seed(11)
+    shapes = [(3, 5), (64, 64, 3, 3), (7,), (1023,), (1025,), (256, 577)] + [(k + 1,) for k in range(34)]
+    ps = [torch.nn.Parameter(torch.randn(*sh, device="cuda")) for sh in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    tp = [torch.randn_like(p) for p in ps]
+    tq = [t.clone() for t in tp]
+    mine, ref = DDQN.AdamSoft(ps), torch.optim.Adam(qs)
+    flat = torch.zeros(sum(p.numel() for p in ps) + 1, device="cuda")
+    tau, skip = 0.05, 2
+    for step in range(5):
+        flat.normal_()
+        off = 1                                                           # (odd offsets: the views are not 16-byte aligned)
+        for k, (p, q) in enumerate(zip(ps, qs)):
+            if k == skip:
+                p.grad = q.grad = None
+            else:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                q.grad = p.grad.clone() * (1.0 + step)                    # (scaled below as well: magnitudes change from step to step)
+                p.grad = p.grad * (1.0 + step)
+            off += p.numel()
+        assert mine.step(targets=tp, tau=tau) is True
+        ref.step()
+        with torch.no_grad():
+            for t, q in zip(tq, qs):
+                t.copy_(tau * q + (1 - tau) * t)
+        for k, (p, q, t, u) in enumerate(zip(ps, qs, tp, tq)):
+            assert (p - q).abs().max().item() <= 2e-7 * max(1.0, q.abs().max().item()) * (step + 1), (step, k)
+            assert (t - u).abs().max().item() <= 2e-7 * max(1.0, u.abs().max().item()) * (step + 1), (step, k)
+    assert torch.equal(ps[skip], qs[skip]) and ps[skip] not in mine.state
+    sd = mine.state_dict()
+    assert all(float(v["step"]) == 5.0 for v in sd["state"].values())
+    ref2 = torch.optim.Adam(qs)
+    ref2.load_state_dict(sd)                                              # torch's optimizer takes AdamSoft's state ...
+    mine2 = DDQN.AdamSoft(ps)
+    mine2.load_state_dict(ref.state_dict())                               # ... and the other way round
+    for k, p in enumerate(ps):
+        if k != skip:
+            assert (mine2.state[p]["exp_avg"] - mine.state[p]["exp_avg"]).abs().max().item() < 1e-6
 
 
 @pytest.mark.parametrize("contents", [True, False])
