@@ -405,7 +405,7 @@ def main():
                 "conv7": ("csrc/tron_head.hip (tron_conv7_fwd / _bwd)" if (side // 2 in (13, 17) and activations._use_pool_conv7_cl
                                                                               and fused.default_math == "f16x3") else "MIOpen"),
                 "kfac_factors": "csrc/tron_kfac_px.hip (3x3 input factors from one haloed PX16 window, no patch matrix) + csrc/tron_kfac.hip Gram kernels" if kfac.use_gram else "extract_patches + library GEMM",
-                "bias_residual_activation": "one pass behind each hooked convolution (tron_bias_mish_fwd / _bwd)",
+                "bias_residual_activation": "in the hooked convolutions' own kernel (epilogue: activation and pre-activation; backward: mish', bias sums and the gradient's scale in one pass), K-FAC's hooks fed by hand (Net/kfac.py::SplitBias)",
                 "fisher_pass": "statistics only" if o["brain"].fisher_stats_only else "full backward",
                 "eigendecompositions": "torch.linalg.eigh (rocSOLVER)"}
             print(json.dumps({

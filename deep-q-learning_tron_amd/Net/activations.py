@@ -64,11 +64,16 @@ class _ConvBiasMishHIP(torch.autograd.Function):
     the gradient kernels do not cover (24x24 boards' weight gradient) go through aten.convolution_backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual):
+    def forward(ctx, x, weight, bias, residual, grad_pre_hook=None):
+        """grad_pre_hook (may be None) is called in backward with the gradient at the pre-activation: what K-FAC's statistics
+        hooks of the convolution module and of its split-off bias layer take (Net/kfac.py::SplitBias, kfac.py:156-189)."""
         from Net import fused
-        out, pre = fused.conv3x3_raw(x, weight, bias, residual, act=True, want_pre=True)
+        out, pre = fused.conv3x3_raw(x, weight, bias.reshape(-1), residual, act=True, want_pre=True)
         ctx.save_for_backward(x, weight, pre)
         ctx.has_res = residual is not None
+        ctx.bias_shape = tuple(bias.shape)
+        ctx.grad_pre_hook = grad_pre_hook
+        ctx.grad_scope = _current_scope()
         return out
 
     @staticmethod
@@ -79,6 +84,8 @@ class _ConvBiasMishHIP(torch.autograd.Function):
         if not _aligned16(g):
             g = g.clone(memory_format=torch.contiguous_format)
         gp, gb, absmax = bias_mish_bwd(pre, g, want_absmax=True)
+        if ctx.grad_pre_hook is not None:
+            ctx.grad_pre_hook(gp)
         gx = None
         if ctx.needs_input_grad[0]:
             if weight.shape[1] in (32, 64):
@@ -87,13 +94,13 @@ class _ConvBiasMishHIP(torch.autograd.Function):
                 gx = torch.ops.aten.convolution_backward(gp, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
         gw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not (_skips_weight_gradient(ctx) and weight.shape[1] >= 16):
             if fused.wgrad_supported(weight, x.shape[-1]):
                 gw = fused.conv3x3_wgrad(x, gp, absmax)
             else:
                 gw = torch.ops.aten.convolution_backward(gp, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [False, True, False])[1]
-        return gx, gw, (gb if ctx.needs_input_grad[2] else None), (gp if ctx.has_res else None)
+        return gx, gw, (gb.reshape(ctx.bias_shape) if ctx.needs_input_grad[2] else None), (gp if ctx.has_res else None), None
 
 
 class _Conv1CodesHIP(torch.autograd.Function):
@@ -921,7 +928,7 @@ def conv_bias_mish(conv, x, residual=None):
         from Net import fused
         if (fused.supported(conv, x.shape[-1]) and x.shape[-2] == x.shape[-1] and _aligned16(x, residual)
                 and (conv.in_channels in (3, 4) or (conv.in_channels % 8 == 0 and conv.in_channels in (32, 64)))):
-            return _ConvBiasMishHIP.apply(x, conv.weight, conv.bias, residual)
+            return _ConvBiasMishHIP.apply(x, conv.weight, conv.bias, residual, None)
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if (y.shape[2] * y.shape[3]) % 4 == 0 and y.numel() < 2 ** 32 and _aligned16(y, residual):
             return _BiasMish.apply(y, conv.bias, residual, None)

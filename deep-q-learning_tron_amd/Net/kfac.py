@@ -77,6 +77,27 @@ class SplitBias(nn.Module):
                     and m.in_channels in (3, 4, 32, 64) and _aligned16(input, residual)
                     and (residual is None or (residual.dtype == torch.float32 and residual.is_contiguous()))):
                 return fused.conv3x3_raw(input.contiguous(), m.weight, self.add_bias._bias.reshape(-1), residual, act=True)
+        if act:
+            # the training graph: convolution, bias, residual and activation as ONE node (the convolution kernel's epilogue writes
+            # activation and pre-activation; its backward takes mish' and the bias sums in one pass), with K-FAC's statistics hooks
+            # of the convolution module and of the bias layer fed by hand — they would have seen `input` on the way in and the
+            # gradient at the pre-activation on the way back (kfac.py:156-189).  A separate bias + activation pass behind the
+            # hooked module (below) cost one more read and write of the layer's output each way.
+            from Net import activations, fused
+            m = self.module
+            if (isinstance(m, activations.Conv3x3) and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and input.shape[0] > 0
+                    and input.shape[-1] == input.shape[-2] and input.shape[1] == m.in_channels and fused.supported(m, input.shape[-1])
+                    and m.in_channels in (3, 4, 32, 64) and not (m.in_channels in (3, 4) and m.out_channels != 32)
+                    and activations._aligned16(input, residual) and not m._forward_hooks
+                    and (residual is None or (residual.dtype == torch.float32 and residual.is_contiguous()))
+                    and activations.bias_mish_supported(*((residual, residual) if residual is not None else (input,)))):
+                opt = self.add_bias._kfac
+                hook = None
+                if opt is not None:
+                    opt._save_input(m, (input,))
+                    opt._save_input(self.add_bias, (input,))              # (an AddBias's input factor takes the batch size only)
+                    hook = lambda gp, m=m, b=self.add_bias, o=opt: (o._save_grad_output(m, None, (gp,)), o._save_grad_output(b, None, (gp,)))
+                return activations._ConvBiasMishHIP.apply(input.contiguous(), m.weight, self.add_bias._bias, residual, hook)
         y = self.module(input)
         if act:
             from Net.activations import bias_mish_supported, mish
