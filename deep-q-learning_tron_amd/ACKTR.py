@@ -179,8 +179,10 @@ class Brain(object):
 
 def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterations=100, acktr=True,
           num_steps=NUM_ADVANCED_STEP, gamemode=None, seed=0x5EED, log_every=0, save_path=None, args=None,
-          micro_batch=8192, act_batch=16384, ai_p1=True, ai_p2=True):
+          micro_batch=8192, act_batch=16384, ai_p1=True, ai_p2=True, trace=None):
     """Batched self-play ACKTR/A2C on VecTron.  Returns counters and the Brain.
+    trace (tests): called as trace("step", it, step, actions) after every env step and trace("collected", it, rollouts, returns
+    bootstrap values) once an iteration's rollouts are complete, before the two updates consume them.
     ai_p1 / ai_p2 False seat MinimaxPlayer(2, "voronoi") there (ACKTR.py:176-177,286-287): that
     player's executed move comes from the search; like the reference, the rollout still stores
     the move the net sampled."""
@@ -229,6 +231,8 @@ def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterat
             games += int(done.sum())
             for p in range(2):
                 rollouts[p].insert(obs[:, p], acts[p], reward[:, p:p + 1], masks, None if is_map else probs[p])
+            if trace is not None:
+                trace("step", it, step, actions)
         with torch.no_grad():
             nxt = []
             for p in range(2):
@@ -238,6 +242,8 @@ def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterat
                                       for i in range(0, n_envs, act_batch)]))
         for p in range(2):
             rollouts[p].compute_returns(nxt[p])
+        if trace is not None:
+            trace("collected", it, rollouts, nxt)
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
         stats = brain.update(rollouts[0], micro_batch)

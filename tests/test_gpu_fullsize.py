@@ -199,3 +199,56 @@ def test_sampler_uniformity(T):
     assert 800 < chi2 < 1200, chi2
     chi2p = ((pos_counts - calls / 10) ** 2 / (calls / 10)).sum(1)   # 9 dof each
     assert np.all(chi2p < 30), chi2p
+
+
+def test_acktr_rollout_at_config5_against_the_oracle(T):
+    """ACKTR.train's rollout side (ACKTR.py:285-353: act, step, reward, mask = 1 - done, the stored observation replaced by the
+    fresh game's when a game ended, the per-step env vector get_multy) at BASELINE config 5 — 16 384 envs of 32x32, temper mode,
+    5 steps, both players — replayed on the CPU oracle with the actions the nets sampled: every stored observation plane, reward,
+    mask, action and env vector, bit for bit, and the n-step returns (ACKTR.py:60-69) recomputed in numpy."""
+    import ACKTR
+    import config
+    tv, oracle = T
+    N, W, K = 16384, 32, 5
+    rec = {"actions": [], "roll": None}
+
+    def trace(kind, it, *a):
+        if kind == "step":
+            rec["actions"].append(np_(a[1]).copy())
+        elif rec["roll"] is None:
+            rolls, nxt = a
+            rec["roll"] = [dict(obs=np_(r.observations), masks=np_(r.masks), rewards=np_(r.rewards), actions=np_(r.actions),
+                                probs=np_(r.probs), returns=np_(r.returns)) for r in rolls]
+            rec["next"] = [np_(v) for v in nxt]
+    out = ACKTR.train(n_envs=N, width=W, model="mul", reward="3", iterations=1, acktr=False, num_steps=K, gamemode="temper",
+                      seed=0x5EED, trace=trace)
+    assert out["env_steps"] == N * K and len(rec["actions"]) == K
+    c = config.reward_cons3
+    ref = oracle.VecOracle(N, W, mode="temper", seed=0x5EED, stream=0,
+                           reward=dict(step=-1.0, win=float(c[0]), lose=float(c[1]), draw=0.0, step_is_index=0))
+    ref.reset_all()
+    S = W + 2
+    planes = lambda codes: np.moveaxis(oracle.pop_up(codes.reshape(N, S, S)), 0, 1)          # [N, 3, S, S]
+    for p in range(2):                             # observation 0: the reset boards as each player sees them (game.py:124-132)
+        assert np.array_equal(rec["roll"][p]["obs"][0], planes(oracle.state_for_player(ref.grid, p + 1))), p
+    ended = 0
+    for k in range(K):
+        probs = [np.stack([ref.degree.astype(np.float32), ref.weight[:, p].astype(np.float32)], 1) for p in range(2)]
+        a = rec["actions"][k]
+        obs, done, winner, reward = ref.step(actions=a, autoreset=True)
+        ended += int(done.sum())
+        for p in range(2):
+            r = rec["roll"][p]
+            assert np.array_equal(r["obs"][k + 1], planes(obs[:, p])), (k, p)
+            assert np.array_equal(r["rewards"][k][:, 0], reward[:, p]), (k, p)
+            assert np.array_equal(r["masks"][k + 1][:, 0], 1.0 - done.astype(np.float32)), (k, p)
+            assert np.array_equal(r["actions"][k][:, 0], a[:, p].astype(np.int64)), (k, p)
+            assert np.array_equal(r["probs"][k], probs[p]), (k, p)
+    assert ended == out["games"] and ended > 0
+    for p in range(2):
+        r = rec["roll"][p]
+        ret = np.zeros_like(r["returns"])
+        ret[-1] = rec["next"][p]
+        for t in reversed(range(K)):
+            ret[t] = ret[t + 1] * np.float32(ACKTR.GAMMA) * r["masks"][t + 1] + r["rewards"][t]
+        assert np.allclose(r["returns"], ret, rtol=1e-6, atol=1e-6)
