@@ -393,6 +393,7 @@ def main():
         torch.cuda.reset_peak_memory_stats()
         ACKTR.train(n_envs=envs, width=width, model="mul", reward="3", iterations=1, acktr=True, log_every=0)   # warm-up (MIOpen find)
         o = ACKTR.train(n_envs=envs, width=width, model="mul", reward="3", iterations=args.acktr_iterations, acktr=True, log_every=0)
+        job_seconds = max_over_ranks(o["seconds"], world)    # one net over all ranks (gradients and K-FAC factor samples all-reduced per update)
         if rank == 0:
             from Net import activations, fused, kfac
             net = o["brain"].actor_critic
@@ -411,7 +412,7 @@ def main():
             print(json.dumps({
                 "paths": paths,
                 "metric": "env-steps/sec (ACKTR trainer: 5-step A2C rollouts of both players + two K-FAC updates per iteration)",
-                "value": o["env_steps_per_s"] * world, "unit": "env-steps/s", "n_gpus": world, "higher_is_better": True,
+                "value": o["env_steps"] * world / job_seconds, "unit": "env-steps/s", "n_gpus": world, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "iterations": o["iterations"], "seconds": o["seconds"],
                 "kfac_update_seconds_per_iteration": o["update_seconds"] / o["iterations"],
@@ -420,7 +421,8 @@ def main():
                 "config": {"workload": f"{envs} parallel {width}x{width} self-play envs (temper mode), Mulnet actor-critic, "
                                        f"ACKTR: Fisher statistics every update (Ts = 1), eigendecompositions every tenth (Tf = 10, kfac.py:107-110,217: "
                                        f"a run starts at update 0, so each player's first update of the timed run pays one), "
-                                       f"micro-batches of 8 192", "parallelism": f"env-shard x{world}"}}), flush=True)
+                                       f"micro-batches of 8 192", "parallelism": f"env-shard x{world}" + ("; one net: gradients and K-FAC factor samples "
+                                       "averaged over the ranks per update" if world > 1 else "")}}), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return

@@ -171,18 +171,43 @@ class Brain(object):
                     p.grad = g
             if self.acktr:
                 self.optimizer.end_accumulate()
+        from DDQN import average_gradients             # one rank per GPU: the update of the global batch (no-op in a single process)
+        average_gradients(self.actor_critic)
         self.optimizer.step()
         value_loss, action_gain, entropy, logp, radv = sums.unbind(0)
         total_loss = value_loss * config.value_loss_coef - action_gain * config.policy_loss_coef - entropy * config.entropy_coef
         return total_loss, value_loss, action_gain, entropy, logp, radv
 
 
+def _rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _fails_the_job(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def guarded(*a, **k):
+        from DDQN import fails_the_job
+        return fails_the_job(fn)(*a, **k)
+    return guarded
+
+
+@_fails_the_job
 def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterations=100, acktr=True,
           num_steps=NUM_ADVANCED_STEP, gamemode=None, seed=0x5EED, log_every=0, save_path=None, args=None,
           micro_batch=8192, act_batch=16384, ai_p1=True, ai_p2=True, trace=None):
     """Batched self-play ACKTR/A2C on VecTron.  Returns counters and the Brain.
     trace (tests): called as trace("step", it, step, actions) after every env step and trace("collected", it, rollouts, returns
     bootstrap values) once an iteration's rollouts are complete, before the two updates consume them.
+    One rank per GPU (torch.distributed initialised): the reference runs independent workers (ACKTR.py:183,285-289); here rank
+    r owns its own n_envs envs (Philox stream (seed, r)) and the ranks train ONE net — same initial weights, every update that of
+    the global batch: gradients and K-FAC factor samples are averaged over the ranks (DDQN.average_gradients,
+    KFACOptimizer._mean_over_ranks), so the weights stay identical without ever being broadcast again.  A rank that fails ends
+    the job (DDQN.fails_the_job).
     ai_p1 / ai_p2 False seat MinimaxPlayer(2, "voronoi") there (ACKTR.py:176-177,286-287): that
     player's executed move comes from the search; like the reference, the rollout still stores
     the move the net sampled."""
@@ -194,7 +219,18 @@ def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterat
     net = MapNet(width) if is_map else Mulnet(width)
     brain = Brain(net, args, acktr=acktr, device="cuda")
     dev = brain.device
-    env = VecTron(n_envs, width, mode=gamemode, seed=seed, obs_format="planes4" if is_map else "planes3",
+    rank, world = _rank_world()
+    if world > 1:
+        import torch.distributed as dist
+        for t in list(net.parameters()) + list(net.buffers()):            # (the same seed already gave the same weights; this makes it a fact)
+            if dist.get_backend() == "gloo" and t.is_cuda:                  # (rehearsals: gloo's collectives take host tensors)
+                h = t.data.cpu()
+                dist.broadcast(h, 0)
+                t.data.copy_(h)
+            else:
+                dist.broadcast(t.data, 0)
+        torch.manual_seed(seed + 1000003 * (rank + 1))                      # action sampling, dropout and Fisher noise: each rank its own draws
+    env = VecTron(n_envs, width, mode=gamemode, seed=seed, rank=rank, obs_format="planes4" if is_map else "planes3",
                   reward=dict(step=-1.0, win=float(constants[0]), lose=float(constants[1]), draw=0.0, step_is_index=0))
     ch = 4 if is_map else 3
     rollouts = [RolloutStorage(num_steps, n_envs, ch, width, 0 if is_map else 2, dev) for _ in range(2)]

@@ -293,6 +293,17 @@ class KFACOptimizer(optim.Optimizer):
         self.optim = optim.SGD(model.parameters(), lr=self.lr * (1 - self.momentum), momentum=self.momentum)
 
     # ---- factor statistics -----------------------------------------------------------------
+    @staticmethod
+    def _mean_over_ranks(sample):
+        """One process per GPU (torch.distributed initialised, world > 1): a factor sample is the mean of the ranks' samples — each
+        rank's batch is its share of one global batch (A = E[a a^T] and G = E[g g^T] over that batch, the gradients being those of
+        per-sample losses: cov_grads), every rank the same size.  A single process: the sample as it is."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from DDQN import all_reduce_mean_
+            all_reduce_mean_(sample)
+        return sample
+
     def _running(self, store, module, sample):
         if self.steps == 0:
             store[module] = sample.clone()
@@ -302,7 +313,7 @@ class KFACOptimizer(optim.Optimizer):
         if torch.is_grad_enabled() and self.steps % self.Ts == 0:
             with torch.no_grad():
                 if self._whole_batch is None:
-                    self._running(self.m_aa, module, cov_inputs(inputs[0].detach(), module))
+                    self._running(self.m_aa, module, self._mean_over_ranks(cov_inputs(inputs[0].detach(), module)))
                 else:
                     part = cov_inputs(inputs[0].detach(), module, self._whole_batch)
                     self._sum_aa[module] = part if module not in self._sum_aa else self._sum_aa[module].add_(part)
@@ -311,7 +322,7 @@ class KFACOptimizer(optim.Optimizer):
         if self.acc_stats:
             with torch.no_grad():
                 if self._whole_batch is None:
-                    self._running(self.m_gg, module, cov_grads(grad_output[0].detach(), module))
+                    self._running(self.m_gg, module, self._mean_over_ranks(cov_grads(grad_output[0].detach(), module)))
                 else:
                     part = cov_grads(grad_output[0].detach(), module, self._whole_batch)
                     self._sum_gg[module] = part if module not in self._sum_gg else self._sum_gg[module].add_(part)
@@ -322,10 +333,12 @@ class KFACOptimizer(optim.Optimizer):
         self._sum_aa, self._sum_gg = {}, {}
 
     def end_accumulate(self):
-        for module, s in self._sum_aa.items():
-            self._running(self.m_aa, module, s)
-        for module, s in self._sum_gg.items():
-            self._running(self.m_gg, module, s)
+        for module in self.modules:                 # (a fixed order: with one rank per GPU every sample is a collective)
+            if module in self._sum_aa:
+                self._running(self.m_aa, module, self._mean_over_ranks(self._sum_aa[module]))
+        for module in self.modules:
+            if module in self._sum_gg:
+                self._running(self.m_gg, module, self._mean_over_ranks(self._sum_gg[module]))
         self._whole_batch = None
         self._sum_aa, self._sum_gg = {}, {}
 

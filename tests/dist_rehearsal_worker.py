@@ -8,7 +8,8 @@ ranks share one GPU:
   2. builds its env shard VecTron(seed, rank=RANK), steps it with in-kernel Philox actions and checks it
      against the oracle on Philox key (seed, stream=RANK) — rank-own random streams;
   3. runs DDQN.train (own envs, own replay shard, gradients averaged across ranks each learn step);
-  4. writes its observations and its network weights to <out>/rank<r>.npz for the parent to compare.
+  4. runs ACKTR.train the same way (gradients and K-FAC factor samples averaged over the ranks);
+  5. writes its observations and its network weights to <out>/rank<r>.npz for the parent to compare.
 """
 import os
 import sys
@@ -76,7 +77,16 @@ def main(out_dir):
     # each rank's replay shard holds its own transitions
     brain.memory.sample()
     idx = brain.memory.memory.last_indices(64).cpu().numpy()
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), obs=obs_np, oracle_equal=same, local=flat, target=tflat,
+    # 5. the ACKTR trainer the same way: own env shard, one net, gradients and K-FAC factor samples averaged over the ranks
+    import ACKTR
+    acktr_games = []
+    ao = ACKTR.train(n_envs=64, width=10, model="mul", reward="3", iterations=2, acktr=True, seed=seed, micro_batch=128,
+                     trace=lambda kind, it, *a: acktr_games.append(a[1].cpu().numpy().copy()) if kind == "step" else None)
+    aflat = torch.cat([p.detach().reshape(-1) for p in ao["brain"].actor_critic.parameters()]).cpu().numpy()
+    opt = ao["brain"].optimizer
+    afac = torch.cat([opt.m_aa[m].reshape(-1) for m in opt.modules] + [opt.m_gg[m].reshape(-1) for m in opt.modules]).cpu().numpy()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), obs=obs_np, acktr_weights=aflat, acktr_factors=afac, acktr_actions=np.stack(acktr_games),
+             acktr_finite=bool(np.isfinite(aflat).all()), oracle_equal=same, local=flat, target=tflat,
              learn_steps=out["learn_steps"], deferred_equal=deferred_equal, deferred_diag=np.array(diag), games=out["games"], env_steps=out["env_steps"], world=world, idx=idx)
     dist.barrier()
     dist.destroy_process_group()

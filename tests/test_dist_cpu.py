@@ -206,3 +206,88 @@ def test_env_shards_use_distinct_philox_streams():
     a = oracle.philox([0, 0, 0, 0], [0x5EED, 0])
     b = oracle.philox([0, 0, 0, 0], [0x5EED, 1])
     assert not np.array_equal(a, b)
+
+
+# ---- ACKTR with one rank per GPU: the update of the global batch (gradients and K-FAC factor samples averaged over the ranks) ----
+def _acktr_rollouts(T, N, W, lo, hi, seed=9):
+    """Envs [lo, hi) of a fixed synthetic rollout of N envs: a rank's share, or (0, N) for the single process."""
+    import ACKTR
+    rs = np.random.RandomState(seed)
+    S = W + 2
+    obs = rs.rand(T + 1, N, 3, S, S).astype(np.float32)
+    acts = rs.randint(0, 4, (T, N, 1))
+    probs = rs.rand(T, N, 2).astype(np.float32)
+    rets = rs.randn(T + 1, N, 1).astype(np.float32)
+    noise = rs.randn(T, N, 1).astype(np.float32)
+    r = ACKTR.RolloutStorage(T, hi - lo, 3, W, 2, "cpu")
+    r.observations.copy_(torch.from_numpy(obs[:, lo:hi]))
+    r.actions.copy_(torch.from_numpy(acts[:, lo:hi]))
+    r.probs.copy_(torch.from_numpy(probs[:, lo:hi]))
+    r.returns.copy_(torch.from_numpy(rets[:, lo:hi]))
+    return r, torch.from_numpy(noise[:, lo:hi].reshape(-1, 1).copy())
+
+
+def _acktr_update(rollouts, noise, micro_batch, updates=2):
+    """`updates` ACKTR updates of a fresh, seeded Mulnet on `rollouts` with the Fisher noise given (Brain.update draws it with
+    torch.randn: patched for the call).  Returns the parameters and the running factors."""
+    import ACKTR
+    from Net.ACNet import Mulnet
+    torch.manual_seed(4)
+    net = Mulnet(10)
+    net.dropout.p = 0.0
+    brain = ACKTR.Brain(net, acktr=True, device="cpu")
+    real = torch.randn
+    torch.randn = lambda *shape, **kw: noise.clone() if tuple(shape) == tuple(noise.shape) else real(*shape, **kw)
+    try:
+        for _ in range(updates):
+            brain.update(rollouts, micro_batch)
+    finally:
+        torch.randn = real
+    opt = brain.optimizer
+    return ([p.detach().clone() for p in net.parameters()], [opt.m_aa[m].clone() for m in opt.modules], [opt.m_gg[m].clone() for m in opt.modules])
+
+
+def _acktr_worker(rank, world, port, q, micro_batch):
+    for p in (ROOT, PKG, GOLDEN):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    T, N, W = 2, 8, 10
+    share = N // world
+    r, noise = _acktr_rollouts(T, N, W, rank * share, (rank + 1) * share)
+    params, aa, gg = _acktr_update(r, noise, micro_batch)
+    q.put((rank, [p.numpy() for p in params], [a.numpy() for a in aa], [g.numpy() for g in gg]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("micro_batch", [None, 4])
+def test_acktr_update_over_two_ranks_equals_the_global_batch(micro_batch):
+    """Two gloo ranks, each with half the envs of one rollout, run two ACKTR updates (ACKTR.py:88-159 with kfac.py:156-254): their
+    weights and running Kronecker factors equal each other's and those of one process updating on the whole rollout — the
+    gradient and every factor sample are means over the ranks.  micro_batch: the accumulate path (factor sums reduced once per
+    update) and the immediate one (every hook's sample reduced)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 7 + (3 if micro_batch else 0)) % 2000
+    procs = [ctx.Process(target=_acktr_worker, args=(r, world, port, q, micro_batch)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=500) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for p in (ROOT, PKG, GOLDEN):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    r, noise = _acktr_rollouts(2, 8, 10, 0, 8)
+    want = _acktr_update(r, noise, None if micro_batch is None else 2 * micro_batch)
+    for kind in range(3):
+        for a, b, w in zip(res[0][1 + kind], res[1][1 + kind], want[kind]):
+            assert np.array_equal(a, b)                                   # the ranks hold the same numbers
+            w = w.numpy()
+            assert np.abs(a - w).max() <= 2e-4 * max(1.0, np.abs(w).max()), (kind, np.abs(a - w).max(), np.abs(w).max())

@@ -79,6 +79,9 @@ def test_trainer_two_ranks_on_one_gpu(tmp_path):
     # learn(defer=True) + finish_learn() through the side-stream all-reduce == learn(defer=False), on both ranks
     assert bool(r0["deferred_equal"]) and bool(r1["deferred_equal"]), (r0["deferred_diag"], r1["deferred_diag"])
     assert np.array_equal(r0["local"], r1["local"]) and np.array_equal(r0["target"], r1["target"])
+    # ACKTR: one net on both ranks (averaged gradients and K-FAC factor samples => identical weights and factors), different games
+    assert np.array_equal(r0["acktr_weights"], r1["acktr_weights"]) and np.array_equal(r0["acktr_factors"], r1["acktr_factors"])
+    assert bool(r0["acktr_finite"]) and not np.array_equal(r0["acktr_actions"], r1["acktr_actions"])
     import DDQN
     torch.manual_seed(0x5EED)
     init = DDQN.Agent(10, 3, device="cpu", make_memory=False)
