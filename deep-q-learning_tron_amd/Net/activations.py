@@ -354,18 +354,10 @@ def _trunk_px_backward(saved, w, plane4, gp6, gb6, need):
     gw[2] = fused.conv3x3_wgrad_px(px(a2, 32), gp3) if need[2] else None
     gp2, _, gb[1] = fused.conv_ws_dgrad(gp3, 32, rot[1], wn[1:2], px(z2, 32))
     gw[1] = fused.conv3x3_wgrad_px(px(a1, 32), gp2) if need[1] else None
-    _, gp1, gb[0] = fused.conv_ws_dgrad(gp2, 32, rot[0], wn[0:1], px(z1, 32), extra=gp3, want_px=False, want_f32=True)   # a1 also feeds conv3's residual
+    gp1, _, gb[0] = fused.conv_ws_dgrad(gp2, 32, rot[0], wn[0:1], px(z1, 32), extra=gp3)    # a1 also feeds conv3's residual
     del gp2, gp3
     if need[0]:
-        from tron.vec import pop_up_planes
-        planes = pop_up_planes(codes)
-        if w[0].shape[1] == 4:
-            planes = torch.cat([planes, torch.full_like(planes[:, :1], plane4)], 1)
-        if fused.wgrad_supported(w[0], S):
-            gw[0] = fused.conv3x3_wgrad(planes, gp1)
-        else:
-            gw[0] = torch.ops.aten.convolution_backward(gp1, planes, w[0], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                        [False, True, False])[1]
+        gw[0] = fused.conv1_wgrad_px(codes, gp1, w[0].shape[1], plane4)       # from the codes themselves: no f32 planes, no f32 gradient
     return gw, gb
 
 

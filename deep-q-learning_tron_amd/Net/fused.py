@@ -399,6 +399,23 @@ def conv3x3_wgrad_px(a, gp):
     return gw
 
 
+def conv1_wgrad_px(codes, gp, cin, plane4=0.0):
+    """conv1's weight gradient from the int8 codes [B, S, S] and the gradient image at its pre-activation (32 channels) -> f32
+    [32, cin, 3, 3] (tron_conv1_wgrad_px16): no f32 planes, no f32 gradient."""
+    L = nat.lib()
+    B, S = codes.shape[0], codes.shape[-1]
+    dev = gp.buf.device
+    nbytes = int(L.tron_conv1_wgrad_px16_workspace(B, S))
+    if nbytes <= 0 or gp.shape[1] != 32 or cin not in (3, 4):
+        raise nat.TronNativeError(f"tron_conv1_wgrad_px16: no kernel for side={S} cin={cin}")
+    gw = torch.empty(32, cin, 3, 3, dtype=torch.float32, device=dev)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(L.tron_conv1_wgrad_px16(nat.ptr(codes), nat.ptr(gp.buf), nat.ptr(gp.info), B, S, cin, float(plane4), nat.ptr(gw), nat.ptr(ws),
+                                          nat.stream_ptr()), "tron_conv1_wgrad_px16")
+    return gw
+
+
 def conv3x3_dgrad(gp, weight, absmax=None):
     """Input gradient of conv3x3(x, weight, padding=1): gp f32 [B, Cout, S, S] (the gradient at the convolution's output),
     weight the FORWARD layer's [Cout, Cin, 3, 3] -> f32 [B, Cin, S, S] (tron_conv3x3_dgrad).  absmax: per-block maxima of

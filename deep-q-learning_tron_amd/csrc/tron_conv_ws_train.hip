@@ -461,7 +461,265 @@ int dispatch_wgrad_px(int side, int cin, int cout, F &&f)
     return TRON_ERR_UNSUPPORTED;
 }
 
+// ---- conv1's weight gradient from the int8 codes and the gradient image ---------------------------------------------------
+// dW[co][plane][tap] = sum over images and pixels of g[co][p] * plane value at p + tap (util.pop_up's planes of the codes: wall 1;
+// own body 1 / head 10; enemy body 1 / head 10; a fourth plane = plane4 on every cell, game.py:124-132).  GEMM view: M = the 32
+// output channels (A = the gradient image by transposed LDS reads, as k_wgrad_px), N = the (plane, tap) pairs — 27 or 36 of 48
+// columns — K = pixels; the B operand does not exist in memory: a lane assembles its eight f16 plane values per slab from a
+// small f16 plane window in LDS that is rebuilt from the codes with every item (0, 1 and 10 are exact in f16: no lo half, two
+// MFMAs per product) — kept in three copies shifted by 0, 1 and 2 columns, so that the four consecutive cells a lane needs under
+// any tap are ONE aligned 8-byte read (eight 2-byte reads per fragment cost 45 % of the kernel).  A slab = 32 k positions = one image row (26x26) or two (12x12) padded to 32 / 16: positions past the row
+// read the gradient plane's zero unit.  An item = an image (12x12) or half of one (13 rows of 26x26); the next item's loads are in
+// flight (in registers) under this item's slabs and go to the one LDS buffer behind a barrier — 22 / 48 KB of LDS per workgroup, so
+// several workgroups of 4 waves share a CU and cover each other's load latency; persistent over the items.
+template <int S_>
+struct C1W {
+    static constexpr int S = S_, SS = S * S;
+    static constexpr int R = S <= 16 ? S : (S + 1) / 2, NBAND = (S + R - 1) / R;
+    static constexpr int XW = S <= 16 ? 16 : 32, RPS = 32 / XW, NSLAB = (R + RPS - 1) / RPS;
+    static constexpr int GP = R * S;
+    static constexpr int odd128(int x) { return ((x + 127) / 256) * 256 + 128; }
+    static constexpr int G_PLANE = odd128((GP + 1) * 16), G_HALF = 4 * G_PLANE, G_BYTES = 2 * G_HALF;    // (+ 1: the zero unit)
+    static constexpr int PW = (S + 2 + 3) / 4 * 4, PR = NSLAB * RPS + 2, CELLS = PR * PW;               // (rows of whole 8-byte groups)
+    static constexpr int P_PLANE = ((CELLS + XW + 8) * 2 + 63) / 64 * 64, NPL = 13;                      // (wall, own, enemy, inside) x 3 column shifts, zeros
+    static constexpr int P_OFF = G_BYTES, ITEM = (G_BYTES + NPL * P_PLANE + 255) / 256 * 256;
+    static constexpr int NCOL = 48, RED = 4 * 32 * NCOL * 4, LDS = ITEM > RED ? ITEM : RED;             // ONE item buffer (the next item waits in registers); the final sums of the four waves
+    static constexpr int GU = 8 * GP, GU_PT = (GU + 255) / 256, CELL_PT = (CELLS + 255) / 256;
+    static_assert(S % R == 0 && S <= XW && LDS <= 160 * 1024, "geometry");
+};
+
+#ifndef TRON_C1W_ABLATE      // diagnostic builds only (wrong results): 1 no B build, 2 no transposed reads, 3 no LDS stores of the item, 4 no global loads, 5 no MFMAs
+#define TRON_C1W_ABLATE 0
+#endif
+template <class C>
+__global__ __launch_bounds__(256) void k_conv1_wgrad_px(const int8_t *__restrict__ codes, const unsigned char *__restrict__ gimg, int B,
+                                                        float *__restrict__ partial)
+{
+    constexpr int S = C::S, SS = C::SS;
+    extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, g = lane >> 4;
+    for (int i = tid * 16; i < C::LDS; i += 256 * 16) *reinterpret_cast<uint4 *>(lds + i) = make_uint4(0u, 0u, 0u, 0u);
+    const int nitems = B * C::NBAND;
+
+    f32x4 gu[C::GU_PT];                                                  // (ext vectors, not HIP's uint4 struct: the latter stayed in scratch)
+    int cc[C::CELL_PT];
+    auto load_item = [&](int item) __attribute__((always_inline)) {
+        const int b = item / C::NBAND, r0 = (item - b * C::NBAND) * C::R;
+#pragma unroll
+        for (int k = 0; k < C::GU_PT; ++k) {
+            int u = tid + 256 * k;
+            u = u < C::GU ? u : C::GU - 1;                               // (past the item's units: any valid unit, never stored)
+            const int pl8 = u / C::GP, px = u - pl8 * C::GP;
+            if (TRON_C1W_ABLATE == 4) { gu[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; continue; }
+            gu[k] = *reinterpret_cast<const f32x4 *>(gimg + (((size_t)b * 8 + pl8) * SS + r0 * S + px) * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < C::CELL_PT; ++k) {
+            const int c = tid + 256 * k;
+            const int wr = c / C::PW, y = r0 + wr - 1, x = c - wr * C::PW - 1;
+            const bool in = c < C::CELLS && y >= 0 && y < S && x >= 0 && x < S;
+            const int8_t v = codes[in ? (size_t)b * SS + y * S + x : (size_t)b * SS];
+            cc[k] = in ? (int)v : 0;
+        }
+    };
+    auto store_item = [&]() __attribute__((always_inline)) {
+        unsigned char *I = lds;
+#pragma unroll
+        for (int k = 0; k < C::GU_PT; ++k) {
+            const int u = tid + 256 * k;
+            if (u < C::GU && TRON_C1W_ABLATE != 3) {
+                const int pl8 = u / C::GP, px = u - pl8 * C::GP;
+                *reinterpret_cast<f32x4 *>(I + (pl8 >> 2) * C::G_HALF + (pl8 & 3) * C::G_PLANE + px * 16) = gu[k];
+            }
+            if (TRON_C1W_ABLATE == 3) asm volatile("" ::"v"(gu[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < C::CELL_PT; ++k) {
+            const int c = tid + 256 * k;
+            if (c < C::CELLS) {
+                const int nib = cc[k] & 15;                              // k_conv1_px's decode: 15 wall, 14 / 10 own body / head, 13 / 6 enemy body / head, 1 empty
+                const f16 one = (f16)1.0f, ten = (f16)10.0f, zero = (f16)0.0f;
+                const f16 v[4] = {nib == 15 ? one : zero, nib == 14 ? one : (nib == 10 ? ten : zero), nib == 13 ? one : (nib == 6 ? ten : zero),
+                                  (nib == 1 || nib == 15 || nib == 14 || nib == 10 || nib == 13 || nib == 6) ? one : zero};
+                const int wc = c % C::PW;
+                f16 *P = reinterpret_cast<f16 *>(I + C::P_OFF) + c;
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+                    for (int sh = 0; sh < 3; ++sh)                       // copy sh holds cell (row, column + sh) at (row, column)
+                        if (wc >= sh) P[(pl * 3 + sh) * (C::P_PLANE / 2) - sh] = v[pl];
+            }
+        }
+    };
+
+    // A operand (gradient), read j of a slab: this lane supplies the 8 bytes (li & 3) of k position 16 j + 4 g + (li >> 2)
+    const int q4 = li >> 2, p4 = li & 3;
+    int a_row[2], a_x[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = 16 * j + 4 * g + q4;
+        a_row[j] = i / C::XW;
+        a_x[j] = i - a_row[j] * C::XW;
+    }
+    const int a_plane = (p4 >> 1) * C::G_PLANE + (p4 & 1) * 8;            // M tile t: + 2 t G_PLANE; lo half: + G_HALF
+    // B operand (planes), N tile nt: column 16 nt + li = (plane, tap); element e sits at k position 16 (e >> 2) + 4 g + (e & 3)
+    int b_base[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int c = 16 * nt + li, pl = c < 36 ? c / 9 : -1, tap = c < 36 ? c - (c / 9) * 9 : 4;
+        b_base[nt] = C::P_OFF + (pl < 0 ? C::NPL - 1 : pl * 3 + tap % 3) * C::P_PLANE + 2 * ((tap / 3) * C::PW + 4 * g);
+    }
+
+    f32x4 acc0[2][3], acc1[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc0[t][n] = acc1[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
+
+    int item = blockIdx.x;
+    __syncthreads();                                                     // the zeros are in
+    if (item < nitems) {
+        load_item(item);
+        store_item();
+    }
+    __syncthreads();
+    for (; item < nitems; item += (int)gridDim.x) {
+        const int nxt = item + (int)gridDim.x;
+        if (nxt < nitems) load_item(nxt);                                // in flight under this item's slabs
+        const uint32_t I = lds_base;
+        const unsigned char *Ip = lds;
+        for (int s = wave; s < C::NSLAB; s += 4) {
+            s16x4 rg[8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int y = s * C::RPS + a_row[j];
+                const bool ok = a_x[j] < S && y < C::R;
+                const uint32_t a = I + a_plane + (ok ? (y * S + a_x[j]) * 16 : C::GP * 16);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (TRON_C1W_ABLATE == 2) { asm volatile("" : "=v"(rg[4 * t + j]), "=v"(rg[4 * t + 2 + j]) : "v"(a)); continue; }
+                    rg[4 * t + j] = lds_tr(a + 2 * t * C::G_PLANE);
+                    rg[4 * t + 2 + j] = lds_tr(a + C::G_HALF + 2 * t * C::G_PLANE);
+                }
+            }
+            f16x8 bf[3];
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                const f16 *P = reinterpret_cast<const f16 *>(Ip + b_base[nt] + 2 * s * C::RPS * C::PW);
+                typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+                const f16x4v r0 = *reinterpret_cast<const f16x4v *>(P), r1 = *reinterpret_cast<const f16x4v *>(P + (C::XW == 16 ? C::PW : 16));
+                bf[nt] = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+                if (TRON_C1W_ABLATE == 1) asm volatile("" : "=v"(bf[nt]) : "v"(P));
+            }
+            lds_wait();
+            f16x8 gh[2], gl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                gh[t] = join8(rg[4 * t + 0], rg[4 * t + 1]);
+                gl[t] = join8(rg[4 * t + 2], rg[4 * t + 3]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    if (TRON_C1W_ABLATE == 5) { asm volatile("" ::"v"(gh[t]), "v"(gl[t]), "v"(bf[nt])); continue; }
+                    acc0[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[t], bf[nt], acc0[t][nt], 0, 0, 0);
+                    acc1[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl[t], bf[nt], acc1[t][nt], 0, 0, 0);
+                }
+        }
+        __syncthreads();                                                 // everybody is done reading this item
+        if (nxt < nitems) store_item();
+        __syncthreads();
+    }
+    // the four waves' sums, joined in a fixed order: partial[workgroup][co][column]; D row = 4 g + r (co within the tile), column = li
+    float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const f32x4 v = acc0[t][nt] + acc1[t][nt] * LO_UNSCALE;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * 32 + 16 * t + 4 * g + r) * C::NCOL + 16 * nt + li] = v[r];
+        }
+    __syncthreads();
+    for (int i = tid; i < 32 * C::NCOL; i += 256)
+        partial[(size_t)blockIdx.x * 32 * C::NCOL + i] = (red[i] + red[32 * C::NCOL + i]) + (red[2 * 32 * C::NCOL + i] + red[3 * 32 * C::NCOL + i]);
+}
+
+// dW[co][plane][tap] = (64 / s) * sum over the workgroups of partial[workgroup][co][9 plane + tap]  (x plane4 for the fourth plane):
+// one workgroup per output channel, a thread = one column x one of five part groups, joined in a fixed order
+__global__ __launch_bounds__(768) void k_conv1_wgrad_finish(const float *__restrict__ partial, int nparts, int cin, float plane4,
+                                                            const float *__restrict__ ginfo, float *__restrict__ gw)
+{
+    __shared__ float red[16][48];
+    const int co = blockIdx.x, col = threadIdx.x % 48, pg = threadIdx.x / 48;
+    float a0 = 0.0f, a1 = 0.0f;
+    int p = pg;
+    for (; p + 16 < nparts; p += 32) {
+        a0 += partial[((size_t)p * 32 + co) * 48 + col];
+        a1 += partial[((size_t)(p + 16) * 32 + co) * 48 + col];
+    }
+    if (p < nparts) a0 += partial[((size_t)p * 32 + co) * 48 + col];
+    red[pg][col] = a0 + a1;
+    __syncthreads();
+    if (threadIdx.x < 9 * cin) {
+        const int c = threadIdx.x;
+        float v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) v += (red[q][c] + red[q + 1][c]) + (red[q + 2][c] + red[q + 3][c]);
+        gw[(size_t)co * cin * 9 + c] = v * (64.0f * ginfo[1]) * (c >= 27 ? plane4 : 1.0f);
+    }
+}
+
+template <class C>
+int launch_conv1_wgrad(const int8_t *codes, const void *gimg, const float *ginfo, int64_t B, int cin, float plane4, float *partial, float *gw,
+                       hipStream_t st, int64_t *ws_need)
+{
+    const int cus = device_cus();
+    int per_cu = (160 * 1024) / C::LDS;
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    int64_t grid = (int64_t)cus * per_cu;
+    if (grid > B * C::NBAND) grid = B * C::NBAND;
+    if (ws_need) { *ws_need = (int64_t)cus * 4 * 32 * C::NCOL * (int64_t)sizeof(float); return TRON_OK; }
+    static uint64_t prepared = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_NO_DEVICE; }
+    if (!(prepared & (1ull << (dev & 63)))) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1_wgrad_px<C>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
+            (void)hipGetLastError();
+        prepared |= 1ull << (dev & 63);
+    }
+    hipLaunchKernelGGL(k_conv1_wgrad_px<C>, dim3((unsigned)grid), dim3(256), C::LDS, st, codes, reinterpret_cast<const unsigned char *>(gimg), (int)B, partial);
+    hipLaunchKernelGGL(k_conv1_wgrad_finish, dim3(32), dim3(768), 0, st, partial, (int)grid, cin, plane4, ginfo, gw);
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
 }  // namespace
+
+extern "C" int64_t tron_conv1_wgrad_px16_workspace(int64_t batch, int32_t side)
+{
+    int64_t need = 0;
+    if (batch < 1 || batch >= (1ll << 30)) return 0;
+    if (side == 12) launch_conv1_wgrad<C1W<12>>(nullptr, nullptr, nullptr, batch, 3, 0.0f, nullptr, nullptr, nullptr, &need);
+    else if (side == 26) launch_conv1_wgrad<C1W<26>>(nullptr, nullptr, nullptr, batch, 3, 0.0f, nullptr, nullptr, nullptr, &need);
+    return need;
+}
+
+extern "C" int tron_conv1_wgrad_px16(const int8_t *codes, const void *grad_px16, const float *grad_info, int64_t batch, int32_t side,
+                                     int32_t cin, float plane4, float *grad_weight, void *workspace, void *stream)
+{
+    if (!codes || !grad_px16 || !grad_info || !grad_weight || !workspace || batch < 0 || (cin != 3 && cin != 4)) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(grad_px16) | reinterpret_cast<uintptr_t>(workspace)) & 15u) return TRON_ERR_BAD_ARG;
+    if (batch >= (1ll << 30)) return TRON_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (batch == 0)
+        return hipMemsetAsync(grad_weight, 0, (size_t)32 * cin * 9 * sizeof(float), st) == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+    float *partial = reinterpret_cast<float *>(workspace);
+    if (side == 12) return launch_conv1_wgrad<C1W<12>>(codes, grad_px16, grad_info, batch, cin, plane4, partial, grad_weight, st, nullptr);
+    if (side == 26) return launch_conv1_wgrad<C1W<26>>(codes, grad_px16, grad_info, batch, cin, plane4, partial, grad_weight, st, nullptr);
+    return TRON_ERR_UNSUPPORTED;
+}
 
 extern "C" int tron_conv1_px16_train(const int8_t *codes, const float *weight, const float *bias, int32_t cin, float plane4,
                                      int64_t batch, int32_t side, void *out_px16, void *pre_px16, void *stream)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TRON_ABI_VERSION 10
+#define TRON_ABI_VERSION 11
 
 typedef enum {
     TRON_OK = 0,
@@ -576,6 +576,13 @@ int tron_conv3x3_ws_dgrad(const void *grad_px16, const float *grad_info, const v
 int64_t tron_conv3x3_wgrad_px16_workspace(int64_t batch, int32_t cin, int32_t cout, int32_t side);
 int tron_conv3x3_wgrad_px16(const void *in_px16, const void *grad_px16, const float *grad_info, float *grad_weight,
                             int64_t batch, int32_t cin, int32_t cout, int32_t side, void *workspace, void *stream);
+/* conv1's weight gradient (DDQN.py:148 on DQNNet.py:10,34) straight from the int8 observation codes and the gradient image at
+ * conv1's pre-activation (32 channels, PX16 of g * s with its record grad_info): grad_weight f32[32][cin][3][3], cin = 3 or 4
+ * (the fourth plane = plane4 on every cell, game.py:124-132).  The f32 planes util.pop_up would build are never written.
+ * side 12 or 26; workspace: tron_conv1_wgrad_px16_workspace(batch, side) bytes (0: unsupported).                             */
+int64_t tron_conv1_wgrad_px16_workspace(int64_t batch, int32_t side);
+int tron_conv1_wgrad_px16(const int8_t *codes, const void *grad_px16, const float *grad_info, int64_t batch, int32_t side,
+                          int32_t cin, float plane4, float *grad_weight, void *workspace, void *stream);
 
 int tron_abi_version(void);
 

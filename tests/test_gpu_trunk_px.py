@@ -220,6 +220,47 @@ def test_weight_gradient_from_px16_images(fused, S, cin, cout, B, mag):
             assert torch.equal(got, want), (b, co, ci, y, xx, ky, kx)
 
 
+@pytest.mark.parametrize("S", [12, 26])
+@pytest.mark.parametrize("cin", [3, 4])
+@pytest.mark.parametrize("B,mag", [(37, 1.0), (600, 1e-6), (1, 1.0)])
+def test_conv1_weight_gradient_from_the_codes(fused, S, cin, B, mag):
+    """conv1's weight gradient (DQNNet.py:10,34 in DDQN.py:148) from the int8 codes and the gradient image against a float64
+    convolution backward on util.pop_up's planes (+ the constant fourth plane): batches smaller and larger than the grid,
+    1e-6-sized gradients, and one-hot cases (a single unit gradient pixel beside a single head / wall cell: exactly the
+    taps that see it, at image corners, row ends and both bands of a 26x26 board)."""
+    from tron.vec import pop_up_planes
+    torch.manual_seed(S + cin + B)
+    codes = _codes(B, S, S + B)
+    plane4 = 0.37
+    planes = pop_up_planes(codes)
+    if cin == 4:
+        planes = torch.cat([planes, torch.full_like(planes[:, :1], plane4)], 1)
+    g = torch.randn(B, 32, S, S, device="cuda") * mag
+    gw = fused.conv1_wgrad_px(codes, _grad_px(fused, g), cin, plane4)
+    wd = torch.zeros(32, cin, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    (F.conv2d(planes.double(), wd, padding=1) * g.double()).sum().backward()
+    assert (gw.double() - wd.grad).abs().max().item() < 3e-6 * wd.grad.abs().max().item()
+    assert torch.equal(gw, fused.conv1_wgrad_px(codes, _grad_px(fused, g), cin, plane4))
+    if mag == 1.0 and B > 1:
+        rs = np.random.RandomState(S + cin)
+        for code, plane, val in ((-1, 0, 1.0), (10, 1, 10.0), (-2, 1, 1.0), (-10, 2, 10.0), (-3, 2, 1.0)):
+            b, co = rs.randint(B), rs.randint(32)
+            y, xx = rs.choice([0, S // 2 - 1, S // 2, S - 1]), rs.choice([0, 3, S - 1])
+            ky, kx = rs.randint(3), rs.randint(3)
+            iy, ix = y + ky - 1, xx + kx - 1
+            c1 = torch.ones(B, S, S, dtype=torch.int8, device="cuda")       # EMPTY everywhere: no plane of the first three is set
+            if 0 <= iy < S and 0 <= ix < S:
+                c1[b, iy, ix] = code
+            c1[(b + 1) % B, (iy + 1) % S, ix % S] = code                    # another image must not leak in
+            g1 = torch.zeros(B, 32, S, S, device="cuda")
+            g1[b, co, y, xx] = 1.0
+            got = fused.conv1_wgrad_px(c1, _grad_px(fused, g1), 3, 0.0)
+            want = torch.zeros(32, 3, 3, 3, device="cuda")
+            if 0 <= iy < S and 0 <= ix < S:
+                want[co, plane, ky, kx] = val
+            assert torch.equal(got, want), (code, b, co, y, xx, ky, kx)
+
+
 @pytest.mark.parametrize("body", ["1", "0"])
 @pytest.mark.parametrize("W,B", [(10, 64), (24, 12), (10, 1), (24, 3)])
 def test_trunk_node_matches_float64_and_the_previous_node(fused, W, B, body, monkeypatch):
