@@ -112,6 +112,10 @@ class Net(nn.Module):
         return self._after_conv7(x)
 
     def _after_conv7(self, x):
+        if self.fuse_trunk and (self.activation is Net.mish or self.activation is self.mish):
+            from Net.activations import tail_mlp, tail_mlp_supported
+            if tail_mlp_supported(self, x):
+                return tail_mlp(self, x)                                  # fc1 .. actor2 as one autograd node
         x = self.dropout(self.activation(_linear(self.fc1, x)))
         x = self.dropout(self.activation(_linear(self.fc2, x)))
         return _linear(self.actor2, self.activation(_linear(self.actor1, x)))

@@ -836,6 +836,93 @@ def linear(layer, x):
     return layer(x)
 
 
+class _TailMLP(torch.autograd.Function):
+    """The DQN net's tail after conv7 — fc1, mish, dropout, fc2, mish, dropout, actor1, mish, actor2 (DQNNet.py:55-63) — as ONE
+    autograd node.  The kernels are the ones the layer-by-layer graph runs (library GEMMs for outputs and input gradients,
+    tron_linear_wgrad, tron_mish_fwd / _bwd, torch's fused dropout and its masked scale: same random stream); what goes is the
+    autograd engine's trip through a dozen Python nodes between launches of 5-10 us each — the device waited ~150 us per learn
+    step for the host there (scripts/learn_timeline.py: the only gaps of a step)."""
+
+    @staticmethod
+    def forward(ctx, x, p, training, w1, b1, w2, b2, w3, b3, w4, b4):
+        from tron import _native as nat
+        L = nat.lib()
+        dev = x.device
+
+        def act(y):
+            a = torch.empty_like(y)
+            nat.check(L.tron_mish_fwd(nat.ptr(y), nat.ptr(a), y.numel(), nat.stream_ptr()), "tron_mish_fwd")
+            return a
+        drop = training and p > 0.0
+        with torch.cuda.device(dev):
+            y1 = torch.addmm(b1, x, w1.t())
+            a1 = act(y1)
+            d1, m1 = torch._fused_dropout(a1, 1.0 - p) if drop else (a1, None)
+            y2 = torch.addmm(b2, d1, w2.t())
+            a2 = act(y2)
+            d2, m2 = torch._fused_dropout(a2, 1.0 - p) if drop else (a2, None)
+            y3 = torch.addmm(b3, d2, w3.t())
+            a3 = act(y3)
+            q = torch.addmm(b4, a3, w4.t())
+        ctx.save_for_backward(x, y1, d1, y2, d2, y3, a3, w1, w2, w3, w4, *([m1, m2] if drop else []))
+        ctx.drop, ctx.p = drop, p
+        return q
+
+    @staticmethod
+    def backward(ctx, gq):
+        from tron import _native as nat
+        L = nat.lib()
+        x, y1, d1, y2, d2, y3, a3, w1, w2, w3, w4, *masks = ctx.saved_tensors
+        dev = x.device
+        need = ctx.needs_input_grad                 # (x, p, training, w1, b1, ..., w4, b4)
+        B = x.shape[0]
+        gq = gq.contiguous()
+
+        def wgrad(gy, inp, w):
+            O, I = w.shape
+            gw, gb = torch.empty_like(w), torch.empty(O, dtype=torch.float32, device=dev)
+            ws = torch.empty(max(16, int(L.tron_linear_wgrad_workspace(B, O, I))), dtype=torch.uint8, device=dev)
+            nat.check(L.tron_linear_wgrad(nat.ptr(gy), nat.ptr(inp), B, O, I, nat.ptr(gw), nat.ptr(gb), nat.ptr(ws), nat.stream_ptr()), "tron_linear_wgrad")
+            return gw, gb
+
+        def act_bwd(y, g):
+            gy = torch.empty_like(y)
+            nat.check(L.tron_mish_bwd(nat.ptr(y), nat.ptr(g), nat.ptr(gy), y.numel(), nat.stream_ptr()), "tron_mish_bwd")
+            return gy
+        scale = 1.0 / (1.0 - ctx.p) if ctx.drop else 1.0
+        with torch.cuda.device(dev):
+            gw4, gb4 = wgrad(gq, a3, w4)
+            gy3 = act_bwd(y3, gq @ w4)
+            gw3, gb3 = wgrad(gy3, d2, w3)
+            g2 = gy3 @ w3
+            gy2 = act_bwd(y2, torch._masked_scale(g2, masks[1], scale) if ctx.drop else g2)
+            gw2, gb2 = wgrad(gy2, d1, w2)
+            g1 = gy2 @ w2
+            gy1 = act_bwd(y1, torch._masked_scale(g1, masks[0], scale) if ctx.drop else g1)
+            gw1, gb1 = wgrad(gy1, x, w1)
+            gx = gy1 @ w1 if need[0] else None
+        return gx, None, None, gw1, gb1, gw2, gb2, gw3, gb3, gw4, gb4
+
+
+def tail_mlp_supported(net, x):
+    """Can `_TailMLP` run fc1 .. actor2 of a DQN `Net` on x [B, flat]?"""
+    if not (_use_linear_hip and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 256 and torch.is_grad_enabled()
+            and x.is_contiguous() and _aligned16(x) and hasattr(torch, "_fused_dropout") and hasattr(torch, "_masked_scale")
+            and isinstance(net.dropout, torch.nn.Dropout) and not net.dropout.inplace and 0.0 <= net.dropout.p < 1.0):
+        return False
+    for l in (net.fc1, net.fc2, net.actor1, net.actor2):
+        if not (isinstance(l, torch.nn.Linear) and type(l).forward is torch.nn.Linear.forward and l.bias is not None and l.weight.requires_grad
+                and l.bias.requires_grad and l.weight.dtype == torch.float32 and l.weight.is_contiguous() and l.weight.device == x.device
+                and not l._forward_hooks and not l._forward_pre_hooks and not l._backward_hooks):
+            return False
+    return net.fc1.in_features == x.shape[1]
+
+
+def tail_mlp(net, x):
+    return _TailMLP.apply(x, float(net.dropout.p), bool(net.dropout.training), net.fc1.weight, net.fc1.bias, net.fc2.weight, net.fc2.bias,
+                          net.actor1.weight, net.actor1.bias, net.actor2.weight, net.actor2.bias)
+
+
 class _PoolS2(torch.autograd.Function):
     """AvgPool2d(3, stride 2, padding 1) (DQNNet.py:20,52) of even-sided planes, both directions on csrc/tron_head.hip's
     row kernels: torch's avg_pool2d backward takes 1.5 ms for 4 096 x 64 planes of 26x26 (one thread per INPUT element

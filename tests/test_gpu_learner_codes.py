@@ -148,6 +148,36 @@ def test_flat_gradient_buffer_and_deferred_update():
         assert torch.equal(p, q)
 
 
+@pytest.mark.parametrize("W,p", [(10, 0.2), (24, 0.2), (10, 0.0)])
+def test_tail_mlp_node_is_the_layer_by_layer_graph(W, p, monkeypatch):
+    """fc1 .. actor2 with mish and dropout (DQNNet.py:55-63) as one autograd node (`_TailMLP`) against the same layers as
+    separate nodes: the same kernels and the same dropout draws, so outputs and every gradient agree bit for bit."""
+    from Net import activations
+    from Net.DQNNet import Net
+    torch.manual_seed(W)
+    net = Net(3, W).cuda().train()
+    net.dropout.p = p
+    B = 512
+    x0 = torch.randn(B, net.flat, device="cuda")
+    gq = torch.randn(B, 4, device="cuda")
+    res = []
+    for fused_tail in (True, False):
+        if not fused_tail:
+            monkeypatch.setattr(activations, "tail_mlp_supported", lambda net, x: False)
+        x = x0.clone().requires_grad_(True)
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(123)
+        q = net._after_conv7(x)
+        assert (type(q.grad_fn).__name__ == "_TailMLPBackward") == fused_tail
+        q.backward(gq)
+        res.append([q.detach(), x.grad] + [l.grad.clone() for m in (net.fc1, net.fc2, net.actor1, net.actor2) for l in (m.weight, m.bias)])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    with torch.no_grad():                          # eval / no-grad calls keep the modules
+        net.eval()
+        assert net._after_conv7(x0).grad_fn is None
+
+
 def test_adam_soft_is_adam_then_soft_update():
     """DDQN.AdamSoft (one launch: Adam's step of every tensor + the target net's soft update, DDQN.py:52,149-165) against
     torch.optim.Adam + the reference's soft-update formula over five steps: parameters with gradients that are views of one flat
