@@ -86,14 +86,18 @@ class Net(nn.Module):
     def _trunk(self, x):
         """conv1..conv7 + fc1 with dropout; returns the [B, 256] feature."""
         a = self.activation
-        x = self._conv_act(self.conv1, x)
-        idx = x
-        x = self._conv_act(self.conv2, x)
-        x = self._conv_act(self.conv3, x, idx)
-        x = self._conv_act(self.conv4, x)
-        idx = x
-        x = self._conv_act(self.conv5, x)
-        x = self._conv_act(self.conv6, x, idx)
+        fused_trunk = self._trunk_px(x) if (a is Net.mish or a is self.mish) else None
+        if fused_trunk is not None:
+            x = fused_trunk
+        else:
+            x = self._conv_act(self.conv1, x)
+            idx = x
+            x = self._conv_act(self.conv2, x)
+            x = self._conv_act(self.conv3, x, idx)
+            x = self._conv_act(self.conv4, x)
+            idx = x
+            x = self._conv_act(self.conv5, x)
+            x = self._conv_act(self.conv6, x, idx)
         if ((a is Net.mish or a is self.mish) and isinstance(self.conv7, nn.Conv2d) and torch.is_grad_enabled()
                 and _pool_conv7_cl_supported(self.pool, self.conv7, x)):
             x = _pool_conv7_cl_mish(self.pool, self.conv7, x)   # 24x24 / 32x32 boards, plain A2C: tron_pool_conv7_fwd / _bwd
@@ -102,6 +106,28 @@ class Net(nn.Module):
             x = self._conv_act(self.conv7, x)
             x = x.reshape(-1, self.flat)
         return self.dropout(a(self.fc1(x)))
+
+    def _trunk_px(self, x):
+        """conv1 .. conv6 as one autograd node on the weight-stationary kernels (Net/activations.py::_ACTrunkPX) where they cover
+        the shapes — with K-FAC's hooks of the six layers fed by hand when the optimizer has split the biases; None otherwise."""
+        from Net import activations
+        convs = [self.conv1, self.conv2, self.conv3, self.conv4, self.conv5, self.conv6]
+        split = [isinstance(c, _SplitBias) for c in convs]
+        if all(split):
+            mods = [c.module for c in convs]
+            if not all(isinstance(m, _Conv3x3) and not m._forward_hooks for m in mods):
+                return None
+            wb = [t for c in convs for t in (c.module.weight, c.add_bias._bias)]
+            hooks = activations.TrunkHooks(convs)
+        elif not any(split) and all(isinstance(c, nn.Conv2d) and c.bias is not None and not c._forward_hooks and not c._forward_pre_hooks
+                                    and not c._backward_hooks for c in convs):
+            wb = [t for c in convs for t in (c.weight, c.bias)]
+            hooks = None
+        else:
+            return None
+        if not activations.ac_trunk_px_supported(x, wb[0::2]):
+            return None
+        return activations._ACTrunkPX.apply(x.contiguous(), hooks, *wb)
 
     def _heads(self, x):
         a = self.activation

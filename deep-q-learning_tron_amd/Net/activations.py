@@ -396,6 +396,139 @@ class _TrunkPX(torch.autograd.Function):
         return tuple(grads)
 
 
+class TrunkHooks:
+    """K-FAC's statistics hooks of the six trunk layers, fed by hand by `_ACTrunkPX` (the modules themselves are not called):
+    per layer the convolution module and its split-off bias layer (Net/kfac.py::SplitBias) — they would have seen the layer's
+    input on the way in and the gradient at its pre-activation on the way back (kfac.py:156-189)."""
+
+    def __init__(self, convs):
+        self.convs = list(convs)
+
+    def _opt(self, k):
+        return getattr(self.convs[k].add_bias, "_kfac", None)
+
+    def inputs(self, k, a, batch_like):
+        opt = self._opt(k)
+        if opt is not None:
+            opt._save_input(self.convs[k].module, (a,))
+            opt._save_input(self.convs[k].add_bias, (batch_like,))        # (an AddBias's input factor takes the batch size only)
+
+    def grads(self, k, g):
+        opt = self._opt(k)
+        if opt is not None:
+            opt._save_grad_output(self.convs[k].module, None, (g,))
+            opt._save_grad_output(self.convs[k].add_bias, None, (g,))
+
+    def wants_grads(self):
+        return any(self._opt(k) is not None and self._opt(k).acc_stats for k in range(len(self.convs)))
+
+
+class _ACTrunkPX(torch.autograd.Function):
+    """conv1 .. conv6 with their two residual connections — the trunk every actor-critic net shares (ACNet.py:97-111) — from f32
+    planes, as ONE autograd node on the weight-stationary kernels (csrc/tron_conv_ws_train.hip; 12x12, 26x26 and 34x34): conv1 on
+    the chunked kernel (3 or 4 planes in), its output and pre-activation turned into PX16 images once, conv2 .. conv6 as the
+    learner's chain (`_BodyPX`), the backward as that chain with every gradient also written as f32 for K-FAC's gradient
+    factors.  hooks (TrunkHooks or None): K-FAC's statistics, fed by hand."""
+
+    @staticmethod
+    def forward(ctx, x, hooks, *wb):
+        from Net import fused
+        w, b = wb[0::2], [t.reshape(-1) for t in wb[1::2]]
+        y1, z1f = fused.conv3x3_raw(x, w[0], b[0], None, act=True, want_pre=True)
+        a1, z1 = fused.PX16.from_f32(y1), fused.PX16.from_f32(z1f)
+        del y1, z1f
+        frag = fused._split_jobs(list(w[1:6]), "tron_conv3x3_ws_split_weights", False)
+        a2, z2 = fused.conv_ws_train(a1, 32, frag[0], b[1])
+        a3, z3 = fused.conv_ws_train(a2, 32, frag[1], b[2], residual=a1)
+        a4, z4 = fused.conv_ws_train(a3, 64, frag[2], b[3])
+        a5, z5 = fused.conv_ws_train(a4, 64, frag[3], b[4])
+        out, z6 = fused.conv_ws_train(a5, 64, frag[4], b[5], residual=a4, want_f32=True)
+        if hooks is not None:
+            like = x.new_empty((x.shape[0], 0))
+            with torch.enable_grad():                               # (the hooks skip gradient-free forwards; a Function's forward runs as one)
+                for k, a in enumerate((x, a1, a2, a3, a4, a5)):
+                    hooks.inputs(k, a, like)
+        ctx.save_for_backward(x, a1.buf, a2.buf, a3.buf, a4.buf, a5.buf, z1.buf, z2.buf, z3.buf, z4.buf, z5.buf, z6.buf, *w)
+        ctx.hooks, ctx.bias_shapes, ctx.grad_scope = hooks, [tuple(t.shape) for t in wb[1::2]], _current_scope()
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from Net import fused
+        x, a1, a2, a3, a4, a5, z1, z2, z3, z4, z5, z6, *w = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if not _aligned16(g):
+            g = g.clone(memory_format=torch.contiguous_format)
+        B, S = g.shape[0], g.shape[-1]
+        px = lambda buf, c: fused._px((B, c, S, S), buf)
+        need = ctx.needs_input_grad                                 # (x, hooks, w1, b1, ..., w6, b6)
+        skip = _skips_weight_gradient(ctx)                          # the sampled-Fisher pass: statistics only
+        want = lambda k: need[2 + 2 * k] and not skip
+        hooks = ctx.hooks
+        stats = hooks is not None and hooks.wants_grads()
+        gp6, gb6 = fused.grad_px_from_f32(g, px(z6, 64))
+        del g
+        if stats:
+            hooks.grads(5, gp6.float())
+        rot, wn = fused._split_jobs(list(w[1:6]), "tron_conv3x3_ws_split_weights_bwd", True)
+        gw, gb = [None] * 6, [None] * 6
+        gb[5] = gb6
+        gw[5] = fused.conv3x3_wgrad_px(px(a5, 64), gp6) if want(5) else None
+        gp5, f5, gb[4] = fused.conv_ws_dgrad(gp6, 64, rot[4], wn[4:5], px(z5, 64), want_f32=stats)
+        if stats:
+            hooks.grads(4, f5)
+        del f5
+        gw[4] = fused.conv3x3_wgrad_px(px(a4, 64), gp5) if want(4) else None
+        gp4, f4, gb[3] = fused.conv_ws_dgrad(gp5, 64, rot[3], wn[3:4], px(z4, 64), extra=gp6, want_f32=stats)   # a4 also feeds conv6's residual
+        del gp5, gp6
+        if stats:
+            hooks.grads(3, f4)
+        del f4
+        gw[3] = fused.conv3x3_wgrad_px(px(a3, 32), gp4) if want(3) else None
+        gp3, f3, gb[2] = fused.conv_ws_dgrad(gp4, 32, rot[2], wn[2:3], px(z3, 32), want_f32=stats)
+        del gp4
+        if stats:
+            hooks.grads(2, f3)
+        del f3
+        gw[2] = fused.conv3x3_wgrad_px(px(a2, 32), gp3) if want(2) else None
+        gp2, f2, gb[1] = fused.conv_ws_dgrad(gp3, 32, rot[1], wn[1:2], px(z2, 32), want_f32=stats)
+        if stats:
+            hooks.grads(1, f2)
+        del f2
+        gw[1] = fused.conv3x3_wgrad_px(px(a1, 32), gp2) if want(1) else None
+        _, f1, gb[0] = fused.conv_ws_dgrad(gp2, 32, rot[0], wn[0:1], px(z1, 32), extra=gp3, want_px=False, want_f32=True)   # a1 also feeds conv3's residual
+        del gp2, gp3
+        if stats:
+            hooks.grads(0, f1)
+        if need[2]:                                                 # conv1's weight (3 or 4 planes in: a cheap product, also in the statistics pass)
+            if fused.wgrad_supported(w[0], S):
+                gw[0] = fused.conv3x3_wgrad(x, f1)
+            else:
+                gw[0] = torch.ops.aten.convolution_backward(f1, x, w[0], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        gx = None
+        if need[0]:                                                 # the planes asked for their gradient (saliency): the library
+            gx = torch.ops.aten.convolution_backward(f1, x, w[0], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        grads = [gx, None]
+        for k in range(6):
+            grads += [gw[k], gb[k].reshape(ctx.bias_shapes[k]) if need[3 + 2 * k] else None]
+        return tuple(grads)
+
+
+def ac_trunk_px_supported(x, weights):
+    """Can `_ACTrunkPX` run conv1 .. conv6 (weights: the six convolution weights) on the f32 planes x?"""
+    from Net import fused
+    import os
+    if os.environ.get("TRON_AC_TRUNK_PX", "1") == "0" or not fused.use_trunk_px:
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] > 0 and x.shape[-1] == x.shape[-2] and x.shape[-1] in (12, 26, 34)
+            and x.shape[1] in (3, 4) and _aligned16(x) and torch.is_grad_enabled() and fused.default_math == "f16x3"
+            and bias_mish_supported(x)):                     # (the switch the tests use to get the module-by-module graph)
+        return False
+    chans = [(w.shape[1], w.shape[0]) for w in weights]
+    return (chans == [(x.shape[1], 32), (32, 32), (32, 32), (32, 64), (64, 64), (64, 64)]
+            and all(tuple(w.shape[2:]) == (3, 3) and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() for w in weights))
+
+
 class _BodyPX(torch.autograd.Function):
     """The whole convolutional body of the DQN net — conv1 .. conv6, AvgPool2d(3, 2, 1), conv7, mish, flatten (DQNNet.py:33-55) —
     from the env's int8 codes as one node: `_TrunkPX` with the head's first two layers taken in, so that conv6's output goes into

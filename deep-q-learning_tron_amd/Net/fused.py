@@ -161,6 +161,28 @@ class PX16:
         self.shape = (batch, channels, side, side)
         self.buf = torch.empty(batch * channels * side * side * 4, dtype=torch.uint8, device=device)
 
+    @classmethod
+    def from_f32(cls, x):
+        """The PX16 image of an f32 NCHW tensor (tron_px16_from_f32)."""
+        B, C, S, _ = x.shape
+        out = cls(B, C, S, x.device)
+        with torch.cuda.device(x.device):
+            nat.check(nat.lib().tron_px16_from_f32(nat.ptr(x.contiguous()), nat.ptr(out.buf), B, C, S, nat.stream_ptr()), "tron_px16_from_f32")
+        return out
+
+    def kfac_input_gram(self, scale):
+        """scale * P^T P of a 3x3 / pad 1 / stride 1 layer whose input this image is (tron_kfac_gram_px16); None: shape not covered."""
+        B, C, S, _ = self.shape
+        L, dev = nat.lib(), self.buf.device
+        nbytes = int(L.tron_kfac_gram_px16_workspace(B, C, S))
+        if nbytes <= 0:
+            return None
+        gram = torch.empty(9 * C, 9 * C, dtype=torch.float32, device=dev)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(L.tron_kfac_gram_px16(nat.ptr(self.buf), B, C, S, float(scale), nat.ptr(gram), nat.ptr(ws), nat.stream_ptr()), "tron_kfac_gram_px16")
+        return gram
+
     def float(self):
         """The f32 NCHW tensor (tron_px16_to_f32)."""
         B, C, S, _ = self.shape
@@ -378,7 +400,7 @@ def conv_ws_dgrad(gp, cin, wfrag_rot, wnorm, z_below, extra=None, want_px=True, 
 
 
 def wgrad_px_supported(cin, cout, side):
-    return side in (12, 26) and (cin, cout) in _WS_SHAPES
+    return side in (12, 26, 34) and (cin, cout) in _WS_SHAPES
 
 
 def conv3x3_wgrad_px(a, gp):

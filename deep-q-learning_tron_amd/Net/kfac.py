@@ -208,6 +208,10 @@ def _pow2_scale(g):
 def cov_inputs(a, module, batch=None):
     """A-factor sample of one batch (kfac.py:41-58).  `batch` = size of the WHOLE batch when `a` is
     only a micro-batch of it (the result is then this micro-batch's additive share)."""
+    if not torch.is_tensor(a):                      # a PX16 image (Net/fused.py): the weight-stationary trunk's layer inputs (3x3 / pad 1 / stride 1)
+        n = a.shape[0]
+        got = a.kfac_input_gram(1.0 / ((n if batch is None else batch) * float(a.shape[2] * a.shape[3]) ** 2))
+        return got if got is not None else cov_inputs(a.float(), module, batch)
     share = 1.0 if batch is None else a.size(0) / batch
     batch = a.size(0) if batch is None else batch
     if isinstance(module, nn.Conv2d):
@@ -312,10 +316,11 @@ class KFACOptimizer(optim.Optimizer):
     def _save_input(self, module, inputs):
         if torch.is_grad_enabled() and self.steps % self.Ts == 0:
             with torch.no_grad():
+                a = inputs[0].detach() if torch.is_tensor(inputs[0]) else inputs[0]
                 if self._whole_batch is None:
-                    self._running(self.m_aa, module, self._mean_over_ranks(cov_inputs(inputs[0].detach(), module)))
+                    self._running(self.m_aa, module, self._mean_over_ranks(cov_inputs(a, module)))
                 else:
-                    part = cov_inputs(inputs[0].detach(), module, self._whole_batch)
+                    part = cov_inputs(a, module, self._whole_batch)
                     self._sum_aa[module] = part if module not in self._sum_aa else self._sum_aa[module].add_(part)
 
     def _save_grad_output(self, module, grad_input, grad_output):

@@ -457,6 +457,10 @@ int dispatch_wgrad_px(int side, int cin, int cout, F &&f)
         if (cin == 64 && cout == 64) return f(WCfg<26, 1, 6, 64, 64, 64, 32, 2>{});
         if (cin == 32 && cout == 64) return f(WCfg<26, 1, 6, 64, 32, 64, 32, 2>{});
         if (cin == 32 && cout == 32) return f(WCfg<26, 1, 6, 32, 32, 32, 32, 4>{});
+    } else if (side == 34) {                                             // (32 + 32 channels of both operands per workgroup kind: 2 x 59 KB of LDS)
+        if (cin == 64 && cout == 64) return f(WCfg<34, 1, 5, 64, 64, 32, 32, 4>{});
+        if (cin == 32 && cout == 64) return f(WCfg<34, 1, 5, 64, 32, 32, 32, 4>{});
+        if (cin == 32 && cout == 32) return f(WCfg<34, 1, 5, 32, 32, 32, 32, 4>{});
     }
     return TRON_ERR_UNSUPPORTED;
 }
@@ -743,7 +747,10 @@ extern "C" int tron_conv1_px16_train(const int8_t *codes, const float *weight, c
     TRON_WST_CASE(12, 12, 64, 64, 1, 8, MODE_, ARGS_)                                                                   \
     TRON_WST_CASE(26, 13, 32, 32, 1, 12, MODE_, ARGS_)                                                                  \
     TRON_WST_CASE(26, 13, 32, 64, 1, 12, MODE_, ARGS_)                                                                  \
-    TRON_WST_CASE(26, 7, 64, 64, 1, 8, MODE_, ARGS_)
+    TRON_WST_CASE(26, 7, 64, 64, 1, 8, MODE_, ARGS_)                                                                    \
+    TRON_WST_CASE(34, 12, 32, 32, 1, 8, MODE_, ARGS_)     /* 32x32 boards (the ACKTR nets): bands of 12 + 12 + 10 rows, eight waves (LDS) */ \
+    TRON_WST_CASE(34, 12, 32, 64, 1, 8, MODE_, ARGS_)                                                                   \
+    TRON_WST_CASE(34, 5, 64, 64, 1, 8, MODE_, ARGS_)      /* seven bands of 5 (4) rows: 2 x 66 KB of LDS */
 
 extern "C" int tron_conv3x3_ws_train_fwd(const void *in_px16, const void *wfrag, const float *bias, const void *res_px16,
                                          void *out_px16, float *out_f32, void *pre_px16, int64_t batch, int32_t cin,
@@ -869,6 +876,9 @@ extern "C" int tron_conv3x3_ws_dgrad(const void *grad_px16, const float *grad_in
     TRON_WSB_CASE(26, 13, 32, 32, 1, 8)
     TRON_WSB_CASE(26, 7, 64, 32, 1, 8)
     TRON_WSB_CASE(26, 7, 64, 64, 1, 8)
+    TRON_WSB_CASE(34, 12, 32, 32, 1, 8)
+    TRON_WSB_CASE(34, 5, 64, 32, 1, 8)
+    TRON_WSB_CASE(34, 5, 64, 64, 1, 8)
 #undef TRON_WSB_CASE
     if (rc != TRON_OK) return rc;
     hipLaunchKernelGGL(k_wsb_finish, dim3((unsigned)cin), dim3(256), 0, st, stats, grid, cin, bias_grad_below, out_info + 4);

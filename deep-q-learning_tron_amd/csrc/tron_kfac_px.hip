@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_kfac_px_finish(const float *__restrict_
 }
 
 template <class C>
-int64_t kfac_px_run(const float *x, int64_t B, float scale, float *gram, void *workspace, hipStream_t st, bool size_only)
+int64_t kfac_px_run(const float *x, const unsigned char *x_px16, int64_t B, float scale, float *gram, void *workspace, hipStream_t st, bool size_only)
 {
     static_assert(C::NB <= 8, "bands");
     const int cus = device_cus();
@@ -308,7 +308,7 @@ int64_t kfac_px_run(const float *x, int64_t B, float scale, float *gram, void *w
     const int64_t px_bytes = (B * C::C * C::SS * 4 + 255) / 256 * 256;
     const int64_t part_bytes = (int64_t)5 * parts * 9 * C::C * C::C * (int64_t)sizeof(float);
     if (size_only) return px_bytes + part_bytes + 256;
-    unsigned char *px = reinterpret_cast<unsigned char *>(workspace);
+    unsigned char *px = reinterpret_cast<unsigned char *>(workspace);      // (x_px16 given: the image is read where it is; the slot stays unused)
     float *partial = reinterpret_cast<float *>(px + px_bytes);
     static uint64_t prepared = 0;
     int dev = 0;
@@ -320,9 +320,10 @@ int64_t kfac_px_run(const float *x, int64_t B, float scale, float *gram, void *w
     }
     if (wgs != used && hipMemsetAsync(partial, 0, (size_t)part_bytes, st) != hipSuccess) { (void)hipGetLastError(); return TRON_ERR_LAUNCH; }
     const int64_t total = B * (C::C / 8) * C::SS;
-    hipLaunchKernelGGL(k_nchw_to_px16, dim3((unsigned)((total + 255) / 256 < (1 << 20) ? (total + 255) / 256 : (1 << 20))), dim3(256), 0, st, x, B,
-                       C::C, C::SS, px);
-    hipLaunchKernelGGL(k_kfac_px<C>, dim3((unsigned)(wgs * 5)), dim3(512), C::LDS, st, px, (int)B, bands, parts, partial);
+    if (!x_px16)
+        hipLaunchKernelGGL(k_nchw_to_px16, dim3((unsigned)((total + 255) / 256 < (1 << 20) ? (total + 255) / 256 : (1 << 20))), dim3(256), 0, st, x, B,
+                           C::C, C::SS, px);
+    hipLaunchKernelGGL(k_kfac_px<C>, dim3((unsigned)(wgs * 5)), dim3(512), C::LDS, st, x_px16 ? x_px16 : px, (int)B, bands, parts, partial);
     hipLaunchKernelGGL(k_kfac_px_finish, dim3((unsigned)((45 * C::C * C::C + 255) / 256)), dim3(256), 0, st, partial, parts, C::C, scale, gram);
     return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
 }
@@ -353,12 +354,42 @@ bool tron_kfac_px_supported(int64_t batch, int C, int H, int W, int kh, int kw, 
 
 int64_t tron_kfac_px_workspace(int64_t batch, int C, int S)
 {
-    const int64_t n = kfac_px_dispatch(C, S, [&](auto cfg) { return kfac_px_run<decltype(cfg)>(nullptr, batch, 0.0f, nullptr, nullptr, nullptr, true); });
+    const int64_t n = kfac_px_dispatch(C, S, [&](auto cfg) { return kfac_px_run<decltype(cfg)>(nullptr, nullptr, batch, 0.0f, nullptr, nullptr, nullptr, true); });
     return n == INT64_MIN || n < 0 ? 0 : n;
 }
 
 int tron_kfac_px_gram(const float *x, int64_t batch, int C, int S, float scale, float *gram, void *workspace, hipStream_t st)
 {
-    const int64_t rc = kfac_px_dispatch(C, S, [&](auto cfg) { return kfac_px_run<decltype(cfg)>(x, batch, scale, gram, workspace, st, false); });
+    const int64_t rc = kfac_px_dispatch(C, S, [&](auto cfg) { return kfac_px_run<decltype(cfg)>(x, nullptr, batch, scale, gram, workspace, st, false); });
+    return rc == INT64_MIN ? TRON_ERR_UNSUPPORTED : (int)rc;
+}
+
+// ---- public entries on PX16 images (include/tron_hip.h) ---------------------------------------------------------------------
+extern "C" int tron_px16_from_f32(const float *x, void *out_px16, int64_t batch, int32_t channels, int32_t side, void *stream)
+{
+    if (!x || !out_px16 || batch < 0 || channels < 8 || channels % 8 || side < 1) return TRON_ERR_BAD_ARG;
+    if (reinterpret_cast<uintptr_t>(out_px16) & 15u) return TRON_ERR_BAD_ARG;
+    if (batch == 0) return TRON_OK;
+    const int64_t total = batch * (channels / 8) * side * side;
+    hipLaunchKernelGGL(k_nchw_to_px16, dim3((unsigned)((total + 255) / 256 < (1 << 20) ? (total + 255) / 256 : (1 << 20))), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, batch, channels, side * side, reinterpret_cast<unsigned char *>(out_px16));
+    return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+}
+
+extern "C" int64_t tron_kfac_gram_px16_workspace(int64_t batch, int32_t channels, int32_t side)
+{
+    return tron_kfac_px_supported(batch, channels, side, side, 3, 3, 1, 1) ? tron_kfac_px_workspace(batch, channels, side) : 0;
+}
+
+extern "C" int tron_kfac_gram_px16(const void *x_px16, int64_t batch, int32_t channels, int32_t side, float scale, float *gram,
+                                   void *workspace, void *stream)
+{
+    if (!x_px16 || !gram || !workspace || batch < 1) return TRON_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(x_px16) | reinterpret_cast<uintptr_t>(workspace)) & 15u) return TRON_ERR_BAD_ARG;
+    if (!tron_kfac_px_supported(batch, channels, side, side, 3, 3, 1, 1)) return TRON_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t rc = kfac_px_dispatch(channels, side, [&](auto cfg) {
+        return kfac_px_run<decltype(cfg)>(nullptr, reinterpret_cast<const unsigned char *>(x_px16), batch, scale, gram, workspace, st, false);
+    });
     return rc == INT64_MIN ? TRON_ERR_UNSUPPORTED : (int)rc;
 }

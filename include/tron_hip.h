@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TRON_ABI_VERSION 11
+#define TRON_ABI_VERSION 12
 
 typedef enum {
     TRON_OK = 0,
@@ -414,6 +414,15 @@ int tron_conv3x3_ws_fwd(const void *in_px16, const void *wfrag, const float *bia
                         void *out_px16, float *out_f32, float *pre_f32, int64_t batch, int32_t cin, int32_t cout,
                         int32_t side, int32_t apply_mish, void *stream);
 int tron_px16_to_f32(const void *in_px16, float *out, int64_t batch, int32_t channels, int32_t side, void *stream);
+/* tron_px16_from_f32: the inverse — f32[batch][channels][side][side] (channels % 8 == 0) -> a PX16 image (tron_px16_bytes). */
+int tron_px16_from_f32(const float *x, void *out_px16, int64_t batch, int32_t channels, int32_t side, void *stream);
+/* K-FAC's input factor of a 3x3 / pad 1 / stride 1 convolution (kfac.py:28-58) from the layer's input as a PX16 image — what the
+ * weight-stationary training chain holds anyway: gram f32[9 C][9 C] = scale * P^T P in the reference's patch order (channel major),
+ * bitwise symmetric, without the patch matrix (csrc/tron_kfac_px.hip).  channels 32 or 64, side 12, 26 or 34;
+ * workspace: tron_kfac_gram_px16_workspace(batch, channels, side) bytes (0: shape not covered).                                */
+int64_t tron_kfac_gram_px16_workspace(int64_t batch, int32_t channels, int32_t side);
+int tron_kfac_gram_px16(const void *x_px16, int64_t batch, int32_t channels, int32_t side, float scale, float *gram, void *workspace,
+                        void *stream);
 
 /* The weight gradient of the same convolutions (loss.backward() through conv1..conv6, DDQN.py:148):
  * grad_weight[co][ci][ky][kx] = sum over b, y, x of grad_pre[b][co][y][x] * in[b][ci][y+ky-1][x+kx-1], overwritten (not

@@ -59,7 +59,7 @@ def _grad_px(fused, g):
     return out
 
 
-@pytest.mark.parametrize("S", [12, 26])
+@pytest.mark.parametrize("S", [12, 26, 34])
 @pytest.mark.parametrize("cin,cout,res", [(32, 32, False), (32, 32, True), (32, 64, False), (64, 64, False), (64, 64, True)])
 def test_training_forward_keeps_the_pre_activation(fused, S, cin, cout, res):
     torch.manual_seed(cin + cout + S)
@@ -76,8 +76,8 @@ def test_training_forward_keeps_the_pre_activation(fused, S, cin, cout, res):
     assert (z.float().double() - zref).abs().max().item() < 1e-5
     assert (a.float().double() - aref).abs().max().item() < 1e-5
     assert (a32.double() - aref).abs().max().item() < 1e-5 and torch.equal(z.buf, z2.buf)
-    # the gradient-free chain's kernel computes the same output bits
-    assert torch.equal(fused.conv_ws(xp, conv, frag, residual=rp).buf, a.buf)
+    if S != 34:                                     # the gradient-free chain's kernel (12x12 / 26x26 boards) computes the same output bits
+        assert torch.equal(fused.conv_ws(xp, conv, frag, residual=rp).buf, a.buf)
 
 
 @pytest.mark.parametrize("S,cin", [(12, 3), (26, 4)])
@@ -125,7 +125,7 @@ def test_gradient_image_entry_from_the_pooled_gradient(fused, S, mag):
     assert abs(info[4:4 + C].max() - scale) <= 2e-6 * scale and info[4:4 + C].max() * info[0] < 2.0 ** 15
 
 
-@pytest.mark.parametrize("S,C,mag", [(12, 64, 1.0), (26, 64, 1e-6), (12, 32, 3e-8)])
+@pytest.mark.parametrize("S,C,mag", [(12, 64, 1.0), (26, 64, 1e-6), (12, 32, 3e-8), (34, 64, 1.0)])
 def test_gradient_image_entry(fused, S, C, mag):
     torch.manual_seed(S + C)
     B = 23
@@ -147,7 +147,7 @@ def test_gradient_image_entry(fused, S, C, mag):
 DG = [(32, 32, False), (32, 32, True), (32, 64, False), (64, 64, False), (64, 64, True)]
 
 
-@pytest.mark.parametrize("S", [12, 26])
+@pytest.mark.parametrize("S", [12, 26, 34])
 @pytest.mark.parametrize("cin,cout,extra", DG)
 @pytest.mark.parametrize("mag", [1.0, 1e-6])
 def test_input_gradient_with_fused_activation_backward(fused, S, cin, cout, extra, mag):
@@ -184,7 +184,7 @@ def test_input_gradient_with_fused_activation_backward(fused, S, cin, cout, extr
     assert torch.equal(out.buf, out2.buf) and torch.equal(gb, gb2)
 
 
-@pytest.mark.parametrize("S", [12, 26])
+@pytest.mark.parametrize("S", [12, 26, 34])
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64)])
 @pytest.mark.parametrize("B,mag", [(37, 1.0), (6, 1e-6), (1, 1.0)])
 def test_weight_gradient_from_px16_images(fused, S, cin, cout, B, mag):
