@@ -400,9 +400,12 @@ def main():
             conv = net.conv2.module if hasattr(net.conv2, "module") else net.conv2
             side = width + 2
             paths = {
-                "trunk_convolutions": ("csrc/tron_conv_f16.hip (forward, input gradient)" if fused.supported(conv, side) else "MIOpen")
-                                      + ("; weight gradient csrc/tron_conv_wgrad*.hip" if fused.wgrad_supported(conv.weight, side)
-                                         else "; weight gradient MIOpen"),
+                "trunk_convolutions": ("csrc/tron_conv_ws_train.hip (the updates: conv2 .. conv6 forward, input gradient and weight gradient on the "
+                                       "weight-stationary chain, one autograd node; the rollouts' gradient-free forwards on the same kernels); csrc/tron_conv_f16.hip (conv1)"
+                                       if activations.ac_trunk_px_supported(torch.empty(1, 3, side, side, device="cuda"),
+                                                                            [getattr(net, f"conv{i}").module.weight if hasattr(getattr(net, f"conv{i}"), "module")
+                                                                             else getattr(net, f"conv{i}").weight for i in range(1, 7)])
+                                       else "csrc/tron_conv_f16.hip (forward, input gradient); weight gradient csrc/tron_conv_wgrad*.hip"),
                 "conv7": ("csrc/tron_head.hip (tron_conv7_fwd / _bwd)" if (side // 2 in (13, 17) and activations._use_pool_conv7_cl
                                                                               and fused.default_math == "f16x3") else "MIOpen"),
                 "kfac_factors": "csrc/tron_kfac_px.hip (3x3 input factors from one haloed PX16 window, no patch matrix) + csrc/tron_kfac.hip Gram kernels" if kfac.use_gram else "extract_patches + library GEMM",

@@ -125,6 +125,10 @@ class Net(nn.Module):
             hooks = None
         else:
             return None
+        if not torch.is_grad_enabled():                                  # the rollouts' acting: nothing to hook
+            if not activations.ac_trunk_px_supported(x, wb[0::2], need_grad=False):
+                return None
+            return activations.ac_trunk_infer(x.contiguous(), wb[0::2], wb[1::2])
         if not activations.ac_trunk_px_supported(x, wb[0::2]):
             return None
         return activations._ACTrunkPX.apply(x.contiguous(), hooks, *wb)

@@ -514,14 +514,31 @@ class _ACTrunkPX(torch.autograd.Function):
         return tuple(grads)
 
 
-def ac_trunk_px_supported(x, weights):
-    """Can `_ACTrunkPX` run conv1 .. conv6 (weights: the six convolution weights) on the f32 planes x?"""
+def ac_trunk_infer(x, weights, biases):
+    """conv1 .. conv6 of the actor-critic trunk, gradient-free (the rollouts' acting, ACKTR.py:285-289), on the weight-stationary
+    chain: conv1 on the chunked kernel, one f32 -> PX16 conversion, conv2 .. conv6 with their weights in registers and the
+    activations as PX16 images, conv6 writing f32 for the pooling.  The caller checked ac_trunk_px_supported(..., need_grad=False)."""
+    from Net import fused
+    b = [t.reshape(-1) for t in biases]
+    a1 = fused.PX16.from_f32(fused.conv3x3_raw(x, weights[0], b[0], None, act=True))
+    frag = fused._split_jobs(list(weights[1:6]), "tron_conv3x3_ws_split_weights", False)
+    a2 = fused.conv_ws_infer(a1, 32, frag[0], b[1])
+    a3 = fused.conv_ws_infer(a2, 32, frag[1], b[2], residual=a1)
+    del a1, a2
+    a4 = fused.conv_ws_infer(a3, 64, frag[2], b[3])
+    del a3
+    a5 = fused.conv_ws_infer(a4, 64, frag[3], b[4])
+    return fused.conv_ws_infer(a5, 64, frag[4], b[5], residual=a4, want_f32=True)
+
+
+def ac_trunk_px_supported(x, weights, need_grad=True):
+    """Can `_ACTrunkPX` (need_grad) / `ac_trunk_infer` run conv1 .. conv6 (weights: the six convolution weights) on the f32 planes x?"""
     from Net import fused
     import os
     if os.environ.get("TRON_AC_TRUNK_PX", "1") == "0" or not fused.use_trunk_px:
         return False
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] > 0 and x.shape[-1] == x.shape[-2] and x.shape[-1] in (12, 26, 34)
-            and x.shape[1] in (3, 4) and _aligned16(x) and torch.is_grad_enabled() and fused.default_math == "f16x3"
+            and x.shape[1] in (3, 4) and _aligned16(x) and torch.is_grad_enabled() == need_grad and fused.default_math == "f16x3"
             and bias_mish_supported(x)):                     # (the switch the tests use to get the module-by-module graph)
         return False
     chans = [(w.shape[1], w.shape[0]) for w in weights]

@@ -261,6 +261,20 @@ def conv_ws(x, conv, wfrag, residual=None, act=True, want_px=True, want_f32=Fals
     return ret[0] if len(ret) == 1 else tuple(ret)
 
 
+def conv_ws_infer(x, cout, wfrag, bias, residual=None, want_f32=False):
+    """mish(conv3x3(x) + bias + residual), gradient-free, from tensors instead of a module: x PX16 -> PX16, or (want_f32) the f32
+    NCHW tensor (tron_conv3x3_ws_fwd)."""
+    B, cin, S, _ = x.shape
+    dev = x.buf.device
+    out = None if want_f32 else PX16(B, cout, S, dev)
+    o32 = torch.empty(B, cout, S, S, dtype=torch.float32, device=dev) if want_f32 else None
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().tron_conv3x3_ws_fwd(nat.ptr(x.buf), nat.ptr(wfrag), nat.ptr(bias.detach()), nat.ptr(None if residual is None else residual.buf),
+                                                nat.ptr(None if out is None else out.buf), nat.ptr(o32), None, B, cin, cout, S, 1, nat.stream_ptr()),
+                  "tron_conv3x3_ws_fwd")
+    return o32 if want_f32 else out
+
+
 def trunk_px(net, codes, plane4=0.0, want="f32"):
     """conv1..conv6 with their two residual links (DQNNet.py:34-50) from the env's int8 codes [B, S, S], the
     activations staying PX16 images from conv1's output to conv6's.  want: "f32" -> [B, 64, S, S], "px16" -> PX16."""

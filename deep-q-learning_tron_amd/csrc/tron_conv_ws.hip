@@ -80,6 +80,7 @@ extern "C" int tron_conv3x3_ws_fwd(const void *in_px16, const void *wfrag, const
 #ifndef TRON_WS_WAVES32      // waves of the 32-input-channel layers: 72 weight registers, so three waves per SIMD fit, and 12 waves
 #define TRON_WS_WAVES32 12   // deal a 12x12 item's 9 (18) tiles evenly; 1-4 % faster than 8 (profiles/r03_ws_layer_bench_*.txt)
 #endif
+    if (side == 34) return ws_fwd_side34(in_px16, wfrag, bias, res_px16, out_px16, out_f32, pre_f32, batch, cin, cout, apply_mish, st);
 #define TRON_WS_CASE(S_, R_, CI_, CO_, IPI_, WAVES_)                                                                  \
     if (side == S_ && cin == CI_ && cout == CO_)                                                                      \
         return launch_ws<Geo<S_, R_, CI_, CO_, IPI_, WAVES_, TRON_WS_TPS>>(in_px16, wfrag, bias, res_px16, out_px16, out_f32, pre_f32, batch, apply_mish, st);

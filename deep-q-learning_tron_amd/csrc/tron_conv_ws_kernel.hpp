@@ -13,6 +13,11 @@
 
 #include "../../include/tron_hip.h"
 
+// 34x34 images (32x32 boards: the actor-critic nets): the gradient-free forward's instantiations live beside the training ones in
+// tron_conv_ws_train.hip (tron_conv_ws.hip keeps the tuned 12x12 / 26x26 inference variants to itself); tron_conv3x3_ws_fwd calls this
+int ws_fwd_side34(const void *in_px16, const void *wfrag, const float *bias, const void *res_px16, void *out_px16, float *out_f32,
+                  float *pre_f32, int64_t batch, int32_t cin, int32_t cout, int32_t apply_mish, hipStream_t st);
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -752,6 +752,17 @@ extern "C" int tron_conv1_px16_train(const int8_t *codes, const float *weight, c
     TRON_WST_CASE(34, 12, 32, 64, 1, 8, MODE_, ARGS_)                                                                   \
     TRON_WST_CASE(34, 5, 64, 64, 1, 8, MODE_, ARGS_)      /* seven bands of 5 (4) rows: 2 x 66 KB of LDS */
 
+int ws_fwd_side34(const void *in_px16, const void *wfrag, const float *bias, const void *res_px16, void *out_px16, float *out_f32,
+                  float *pre_f32, int64_t batch, int32_t cin, int32_t cout, int32_t apply_mish, hipStream_t st)
+{
+    const int side = 34;
+#define TRON_WST_CASE(S_, R_, CI_, CO_, IPI_, WAVES_, MODE_, ARGS_)                                                     \
+    if (S_ == 34 && side == S_ && cin == CI_ && cout == CO_) return launch_ws<Geo<S_, R_, CI_, CO_, IPI_, WAVES_, 1>, MODE_> ARGS_;
+    TRON_WST_CASES(WS_INFER, (in_px16, wfrag, bias, res_px16, out_px16, out_f32, pre_f32, batch, apply_mish, st))
+#undef TRON_WST_CASE
+    return TRON_ERR_UNSUPPORTED;
+}
+
 extern "C" int tron_conv3x3_ws_train_fwd(const void *in_px16, const void *wfrag, const float *bias, const void *res_px16,
                                          void *out_px16, float *out_f32, void *pre_px16, int64_t batch, int32_t cin,
                                          int32_t cout, int32_t side, void *stream)

@@ -263,6 +263,39 @@ def test_fused_bias_residual_mish_keeps_kfac_statistics(width, model, monkeypatc
             assert (a - b).abs().max().item() / (b.abs().max().item() + 1e-30) < 1e-4, (type(ma).__name__, store)
 
 
+@pytest.mark.parametrize("width", [10, 24, 32])
+@pytest.mark.parametrize("split", [False, True])
+def test_actor_critic_trunk_on_the_weight_stationary_chain(width, split, monkeypatch):
+    """The actor-critic nets' trunk as ONE node on the weight-stationary kernels (`_ACTrunkPX`; gradient-free: `ac_trunk_infer`)
+    against the layer-by-layer graph (ACNet.py:97-111), plain (A2C) and after KFACOptimizer split the biases: outputs within
+    1e-5, parameter gradients within 1e-4 of their scale, and the gradient-free forward (the rollouts' acting) within 1e-5."""
+    import copy
+    from Net import ACNet, activations, kfac
+    torch.manual_seed(width + split)
+    S, B = width + 2, 19
+    net = ACNet.Mulnet(width).cuda()
+    net.dropout.p = 0.0
+    ref = copy.deepcopy(net)
+    if split:
+        kfac.KFACOptimizer(net), kfac.KFACOptimizer(ref)
+    x = torch.randn(B, 3, S, S, device="cuda")
+    extra = torch.rand(B, 2, device="cuda")
+    acts = torch.randint(0, 4, (B, 1), device="cuda")
+    v, logp, ent = net.evaluate_actions(x, acts, extra)
+    (v.pow(2).mean() - logp.mean() - 0.01 * ent).backward()
+    with torch.no_grad():
+        v0, a0 = net(x, extra)
+    monkeypatch.setattr(activations, "ac_trunk_px_supported", lambda x, weights, need_grad=True: False)
+    vr, logpr, entr = ref.evaluate_actions(x, acts, extra)
+    (vr.pow(2).mean() - logpr.mean() - 0.01 * entr).backward()
+    with torch.no_grad():
+        v0r, a0r = ref(x, extra)
+    assert (v - vr).abs().max().item() < 1e-5 and (logp - logpr).abs().max().item() < 1e-5
+    assert (v0 - v0r).abs().max().item() < 1e-5 and (a0 - a0r).abs().max().item() < 1e-5 and (v0 - v).abs().max().item() < 1e-5
+    for (name, p), (_, r) in zip(net.named_parameters(), ref.named_parameters()):
+        assert (p.grad - r.grad).abs().max().item() / (r.grad.abs().max().item() + 1e-30) < 1e-4, name
+
+
 def test_mish_kernels_match_the_composed_form():
     """csrc/tron_nn.hip: mish forward / backward against x * tanh(softplus(x)) and its autograd gradient
     evaluated in float64, over the whole input range (incl. the > 20 cut-over and deep negatives)."""
