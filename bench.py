@@ -424,7 +424,7 @@ def main():
                 "config": {"workload": f"{envs} parallel {width}x{width} self-play envs (temper mode), Mulnet actor-critic, "
                                        f"ACKTR: Fisher statistics every update (Ts = 1), eigendecompositions every tenth (Tf = 10, kfac.py:107-110,217: "
                                        f"a run starts at update 0, so each player's first update of the timed run pays one), "
-                                       f"micro-batches of 8 192", "parallelism": f"env-shard x{world}" + ("; one net: gradients and K-FAC factor samples "
+                                       f"micro-batches of 16 384 (69 GB of HBM at its peak)", "parallelism": f"env-shard x{world}" + ("; one net: gradients and K-FAC factor samples "
                                        "averaged over the ranks per update" if world > 1 else "")}}), flush=True)
         if world > 1:
             dist.destroy_process_group()

@@ -199,7 +199,7 @@ def _fails_the_job(fn):
 @_fails_the_job
 def train(n_envs=NUM_PROCESSES, width=MAP_WIDTH, model="mul", reward="3", iterations=100, acktr=True,
           num_steps=NUM_ADVANCED_STEP, gamemode=None, seed=0x5EED, log_every=0, save_path=None, args=None,
-          micro_batch=8192, act_batch=16384, ai_p1=True, ai_p2=True, trace=None):
+          micro_batch=16384, act_batch=16384, ai_p1=True, ai_p2=True, trace=None):
     """Batched self-play ACKTR/A2C on VecTron.  Returns counters and the Brain.
     trace (tests): called as trace("step", it, step, actions) after every env step and trace("collected", it, rollouts, returns
     bootstrap values) once an iteration's rollouts are complete, before the two updates consume them.
