@@ -335,7 +335,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="DQN record: learn batch")
     ap.add_argument("--dqn-steps", type=int, default=40, help="DQN record: env steps per timed region")
     ap.add_argument("--acktr", action="store_true", help="print the ACKTR record instead (BASELINE configs[4]: 16 384 envs 32x32)")
-    ap.add_argument("--acktr-iterations", type=int, default=2)
+    ap.add_argument("--acktr-iterations", type=int, default=5, help="ACKTR record: timed iterations (5 = 10 updates = one period of the eigendecompositions, Tf = 10)")
     ap.add_argument("--dqn3-steps", type=int, default=8, help="config-3 DQN record (65 536 envs x 24x24): env steps per timed region")
     ap.add_argument("--settle-steps", type=int, default=6400,
                     help="untimed steps (in launches of --steps) run after the --warmup steps and before the timed regions, so that "
@@ -423,7 +423,7 @@ def main():
                 "samples_per_update": 5 * envs, "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9,
                 "config": {"workload": f"{envs} parallel {width}x{width} self-play envs (temper mode), Mulnet actor-critic, "
                                        f"ACKTR: Fisher statistics every update (Ts = 1), eigendecompositions every tenth (Tf = 10, kfac.py:107-110,217: "
-                                       f"a run starts at update 0, so each player's first update of the timed run pays one), "
+                                       f"a run starts at update 0: {2 * o['iterations']} timed updates hold {(2 * o['iterations'] + 9) // 10} round(s) of them), "
                                        f"micro-batches of 16 384 (69 GB of HBM at its peak)", "parallelism": f"env-shard x{world}" + ("; one net: gradients and K-FAC factor samples "
                                        "averaged over the ranks per update" if world > 1 else "")}}), flush=True)
         if world > 1:
