@@ -456,7 +456,7 @@ def main():
     nonrev = args.actions == "nonreversing"
     walls, dev_ms = [], []
     per_step_ms, two_stream_ms, resident_ms = [], [], []
-    obs_is_state_cfg = args.mode == "none" and args.obs == "codes" and args.width % 2 == 0
+    obs_is_state_cfg = args.obs == "codes" and args.width % 2 == 0      # (every mode: the sliding modes keep their slide tiles in a log)
     with torch.cuda.stream(side):
         if args.incremental:                       # the in-place variant has no rollout entry point: launch loop
             step = env.step_fn(autoreset=True, nonreversing=nonrev)
@@ -531,7 +531,7 @@ def main():
     step_ms = ev_ms / args.steps
     kern_ms = ev_ms / n_launches                   # avg launch of the step kernel
 
-    # a sliding mode beside the headline ("temper" as a secondary row): the same K steps on k_tile_roll
+    # a sliding mode beside the headline ("temper" as a secondary row): the same K steps on k_obs_roll_slide
     temper = None
     if args.mode == "none" and args.obs == "codes" and not args.incremental and not args.only_rollout and not nonrev:
         tenv = VecTron(args.envs, args.width, mode="temper", seed=0x5EED, rank=rank, obs_format="codes")
@@ -556,7 +556,8 @@ def main():
                   "value": args.envs * world / (tm * 1e-3), "ms_per_step": tm, "ms_per_step_min_max": [min(t_ms), max(t_ms)],
                   "roofline": {"bound": "hbm", "achieved": t_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": t_ach / HBM_PEAK_GBS,
                                "frac_of_achievable": t_ach / HBM_COPY_GBS, "alg_bytes_per_env_step": alg_bytes_per_env_step(args.width),
-                               "kernel": "k_tile_roll (persistent rollout, board-owning layout)"}}
+                               "kernel": ("k_obs_roll_slide (persistent rollout of the observation-is-state step; slide tiles in a per-env log)"
+                                          if args.width % 2 == 0 else "k_tile_roll (persistent rollout, board-owning layout)")}}
 
     dqn = dqn3 = None
     if not args.no_dqn and not args.incremental and not args.only_rollout:
@@ -585,7 +586,7 @@ def main():
         if args.obs != "codes":                    # f32 planes: 2 players x C planes x 4 B per cell
             g = (args.width + 2) ** 2
             b_alg = g + 32 + 2 * (3 if args.obs == "planes3" else 4) * g * 4
-        obs_is_state = args.mode == "none" and args.obs == "codes" and args.width % 2 == 0
+        obs_is_state = args.obs == "codes" and args.width % 2 == 0
         if args.incremental:
             # bytes this variant needs per env-step: state words + outputs (~70 B), 2 cells read, 8 written,
             # and both planes (2G) for the ~36 % of envs that restart under random play
@@ -628,7 +629,8 @@ def main():
                                           (hbm_src or "no committed PMC pass for this workload / steps-per-launch")),
                          "kernel": ("k_inc (in-place update: touched cells + restarted boards only)" if args.incremental
                                     else "k_obs / k_tile (one launch per step)" if not persistent
-                                    else "k_obs_roll (persistent rollout of the observation-is-state step, int8 codes)"
+                                    else ("k_obs_roll (persistent rollout of the observation-is-state step, int8 codes)" if args.mode == "none"
+                                          else "k_obs_roll_slide (persistent rollout of the observation-is-state step, int8 codes; slide tiles in a per-env log)")
                                     if obs_is_state else "k_tile_roll (persistent rollout, board-owning layout)"),
                          "kernel_ms": kern_ms, "kernel_ms_min_max": [min(dev_ms) / n_launches, max(dev_ms) / n_launches],
                          "launches": n_launches, "steps_per_launch": args.steps / n_launches,

@@ -671,14 +671,161 @@ __device__ inline void lane_move_codes(const Params &P, unsigned char *g, const 
     rec_out = make_uint4(res | ((uint32_t)winner << 4), __float_as_uint(rw0), __float_as_uint(rw1), restart);
 }
 
+// ---- the sliding modes ("ice", "temper") on the observation-is-state layout ---------------------------------------------
+// A slide leaves a P1_slide / P2_slide tile behind (game.py:163-178) that Map.color shows as that player's body
+// (map.py:67-81): the dynamics never tell the two apart (a cell is EMPTY or it is not), only the board image does
+// (tron_get_grid).  So the player-1 code plane carries the game here too, and the slide marks go to a per-env LOG —
+// entry = cell | player << 15, appended by the step that makes the mark (2 bytes, only when somebody slides), their
+// number in st4.meta bits 16-25 (a restart rewrites meta: the log empties by itself) — which tron_get_grid replays:
+// a logged cell that still holds its player's body code is a slide tile.  The board-owning layout wrote every
+// dirty 16-byte chunk of the board back as a partial line instead: 153 MB per step against 121 (profiles/r04_temper_pmc.txt).
+constexpr uint32_t SLIDE_CNT_SHIFT = 16u, SLIDE_CNT_MASK = 0x3FFu;
+__device__ __forceinline__ uint16_t *slide_log(const Params &P)
+{
+    return reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(P.slide) + (((size_t)P.N * 8u + 255u) & ~(size_t)255u));
+}
+__host__ __device__ __forceinline__ int slide_log_len(int W) { return W * W; }   // a mark takes a cell of its own
+
+// lane_move (the board-owning layout's move, above) in code space; marks out: (cell + 1) of player 1's slide mark | (cell + 1)
+// << 14 of player 2's, 0 = none (rec_out.w when the env does not restart: a restarting env's marks die with its board)
+__device__ inline void lane_move_codes_slide(const Params &P, unsigned char *g, const EnvRegs &R, const int a[2], const float u[2],
+                                             uint32_t flags, uint4 &rec_st, uint4 &rec_out)
+{
+    constexpr int C_EMPTY = 1, C_WALL = -1, C_P1_BODY = -2, C_P2_BODY = -3, C_P1_HEAD = 10, C_P2_HEAD = -10;
+    const int S = P.S, W = P.W;
+    uint32_t m = R.meta;
+    int r[2] = {(int)(int8_t)(R.pos), (int)(int8_t)(R.pos >> 16)};
+    int c[2] = {(int)(int8_t)(R.pos >> 8), (int)(int8_t)(R.pos >> 24)};
+    bool done = (m & META_DONE) != 0;
+    int winner = (int)((m >> 4) & 3u);
+    float rw0 = 0.0f, rw1 = 0.0f;
+    uint32_t res = 0u, marks = 0u;
+    rec_st = make_uint4(R.pos, R.meta, R.eplen, R.tick);
+
+    float thr[2] = {0.0f, 0.0f};
+    bool thr_ok[2] = {false, false};
+    if (P.mode == TRON_MODE_TEMPER) {
+        const uint32_t di = (uint32_t)((int)(int8_t)(R.envp >> 16) + 30);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const uint32_t wi = ((R.envp >> (8 * p)) & 0xFFu) - 40u;
+            thr_ok[p] = di < (uint32_t)RATE_DEG && wi < (uint32_t)RATE_W;
+            thr[p] = g_rate_thr[thr_ok[p] ? di * RATE_W + wi : 0u];
+        }
+    }
+    if (!done) {
+        res |= RES_STEPPED;
+        int dr[2], dc[2], n[2], sl[2], tn[2], ts[2];
+        bool inb[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            dr[p] = (a[p] == 0) ? -1 : (a[p] == 2) ? 1 : 0;   // UP / DOWN
+            dc[p] = (a[p] == 1) ? 1 : (a[p] == 3) ? -1 : 0;   // RIGHT / LEFT
+            const int nr = r[p] + dr[p], nc = c[p] + dc[p];
+            inb[p] = nr >= 0 && nc >= 0 && nr < W && nc < W;
+            n[p] = cell_index(S, nr, nc);
+            sl[p] = inb[p] ? cell_index(S, nr + dr[p], nc + dc[p]) : n[p];
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            tn[p] = (int)(int8_t)g[n[p]];
+            ts[p] = (int)(int8_t)g[sl[p]];
+        }
+        int cells[6], vals[6];
+        cells[0] = cell_index(S, r[0], c[0]); vals[0] = C_P1_BODY;       // game.py:155-156: heads -> bodies first
+        cells[1] = cell_index(S, r[1], c[1]); vals[1] = C_P2_BODY;
+#pragma unroll
+        for (int k = 2; k < 6; ++k) { cells[k] = cells[k & 1]; vals[k] = vals[k & 1]; }
+        auto code_at = [&](int idx, int before, int upto) {
+            int v = before;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (k < upto && cells[k] == idx) v = vals[k];
+            return v;
+        };
+        int f[2], tf[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f[p] = n[p];
+            tf[p] = tn[p];
+            int nr = r[p] + dr[p], nc = c[p] + dc[p];
+            if (inb[p] && code_at(n[p], tn[p], 2 + p) == C_EMPTY) {       // the uniform is consulted only for an in-bounds EMPTY target (game.py:164-165)
+                bool slides;                                             // game.py:169: random.random() <= rate
+                if (P.mode == TRON_MODE_ICE) {
+                    slides = (double)u[p] <= R.slide;
+                } else if (thr_ok[p]) {
+                    slides = u[p] <= thr[p];
+                } else {
+                    slides = (double)u[p] <= get_rate((int)(int8_t)(R.envp >> 16), (int)((R.envp >> (8 * p)) & 0xFFu));
+                }
+                if (slides) {
+                    cells[2 + p] = n[p];
+                    vals[2 + p] = (p == 0) ? C_P1_BODY : C_P2_BODY;      // the slide tile, as Map.color shows it
+                    marks |= (uint32_t)(n[p] + 1) << (14 * p);
+                    f[p] = sl[p];
+                    tf[p] = ts[p];
+                    nr += dr[p];
+                    nc += dc[p];
+                }
+            }
+            r[p] = nr;
+            c[p] = nc;
+        }
+        uint32_t alive = m & 3u;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const bool oob = r[p] < 0 || c[p] < 0 || r[p] >= W || c[p] >= W;
+            if (oob || code_at(f[p], tf[p], 4 + p) != C_EMPTY)
+                alive &= ~(1u << p);
+            cells[4 + p] = f[p];
+            vals[4 + p] = (p == 0) ? C_P1_HEAD : C_P2_HEAD;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g[cells[k]] = (unsigned char)vals[k];
+
+        const int n_alive = (int)(alive & 1u) + (int)((alive >> 1) & 1u);
+        if (n_alive <= 1) {
+            if (n_alive == 1 && (r[0] != r[1] || c[0] != c[1]))
+                winner = (alive & 1u) ? 1 : 2;
+            done = true;
+        }
+        if (!done) {
+            rw0 = rw1 = P.r_index ? (float)R.eplen : P.r_step;
+        } else if (winner == 0) {
+            rw0 = rw1 = P.r_draw;
+        } else {
+            rw0 = (winner == 1) ? P.r_win : P.r_lose;
+            rw1 = (winner == 2) ? P.r_win : P.r_lose;
+        }
+        const uint32_t cnt = ((m >> SLIDE_CNT_SHIFT) & SLIDE_CNT_MASK) + ((marks & 0x3FFFu) ? 1u : 0u) + ((marks >> 14) ? 1u : 0u);
+        rec_st = make_uint4(pack_pos(r[0], c[0], r[1], c[1]),
+                            alive | (done ? META_DONE : 0u) | ((uint32_t)winner << 4) | ((uint32_t)(a[0] + 1) << 8) |
+                                ((uint32_t)(a[1] + 1) << 12) | (cnt << SLIDE_CNT_SHIFT),
+                            R.eplen + 1u, R.tick + 1u);
+        res |= RES_STORE_ST;
+    }
+    if (done) res |= RES_DONE;
+
+    uint32_t restart = 0u;
+    if (done && (flags & TRON_STEP_AUTORESET)) {                      // ACKTR.py:307-310
+        rec_st = make_uint4(R.nstart, META_ALIVE0 | META_ALIVE1, 0u, rec_st.w);
+        res |= RES_STORE_ST | RES_RESET;
+        const int h1 = cell_index(S, (int)(int8_t)(R.nstart), (int)(int8_t)(R.nstart >> 8));
+        const int h2 = cell_index(S, (int)(int8_t)(R.nstart >> 16), (int)(int8_t)(R.nstart >> 24));
+        restart = 0x80000000u | (uint32_t)h1 | ((uint32_t)h2 << 14);
+    }
+    rec_out = make_uint4(res | ((uint32_t)winner << 4), __float_as_uint(rw0), __float_as_uint(rw1), restart ? restart : marks);
+}
+
 // One tile of E envs through one step; `smem` is the workgroup's dynamic LDS.  Shared by k_obs (one
 // tile per workgroup per launch) and k_obs_roll (workgroups that keep stepping their own tiles).
 // keep_tile (persistent rollout, TRON_ROLLOUT_RESIDENT): the tile's LDS copy is left exactly as the next step needs
 // it (restarted boards are written back to it); have_tile: it already is, so the tile is not loaded again.
-template <bool DO_STEP>
+template <bool DO_STEP, bool SLIDING = false>
 __device__ __forceinline__ void obs_tile(const Params &P, int E, uint32_t cpe, uint32_t cpe_magic,
                                          const int8_t *__restrict__ actions, uint32_t flags, const StepOut &out,
-                                         int tile_idx, unsigned char *smem, bool have_tile = false, bool keep_tile = false)
+                                         int tile_idx, unsigned char *smem, bool have_tile = false, bool keep_tile = false,
+                                         const float *__restrict__ uniforms = nullptr)
 {
     const int G = P.G;
     uint4 *tile = reinterpret_cast<uint4 *>(smem);                  // [E*cpe] player-1 codes
@@ -707,6 +854,15 @@ __device__ __forceinline__ void obs_tile(const Params &P, int E, uint32_t cpe, u
             const uint4 st = P.st4[env];
             R.pos = st.x; R.meta = st.y; R.eplen = st.z; R.tick = st.w;
             if (actions) R.act = reinterpret_cast<const uint16_t *>(actions)[env];
+            if (SLIDING) {                                            // the slide's rate: this env's scalars (game.py:83-88,100-112)
+                R.envp = P.rs4[env].x;
+                R.slide = P.slide[env];
+                if (uniforms) {
+                    const float2 uu = reinterpret_cast<const float2 *>(uniforms)[env];
+                    R.u0 = uu.x;
+                    R.u1 = uu.y;
+                }
+            }
         } else if (wave == 1 && autoreset) {
             rs = P.rs4[env];
         }
@@ -716,6 +872,7 @@ __device__ __forceinline__ void obs_tile(const Params &P, int E, uint32_t cpe, u
             reinterpret_cast<int8_t *>(tmpl)[d] = (d < (uint32_t)G) ? (P.fresh[d] == TRON_EMPTY ? (int8_t)1 : (int8_t)-1) : (int8_t)0;
 
     int a[2] = {0, 0};
+    float u[2] = {R.u0, R.u1};
     for (uint32_t base = 0; base < nchunks; base += DK * BLOCK) {
         uint4 v[DK];
 #pragma unroll
@@ -726,14 +883,19 @@ __device__ __forceinline__ void obs_tile(const Params &P, int E, uint32_t cpe, u
             if (i < nchunks && !have_tile) v[k] = load_chunk<true>(otile + (size_t)le * 2u * G + c);   // player-1 plane
         }
         if (base == 0u && DO_STEP && mine) {
-            // random-number work in the shadow of the tile load: wave 0 the actions, wave 1 the next start
+            // random-number work in the shadow of the tile load: wave 0 the actions (and slide uniforms), wave 1 the next start
             if (wave == 0) {
-                if (!actions) {
+                if (!actions || (SLIDING && !uniforms)) {
                     uint32_t x[4];
                     philox4x32_10((uint32_t)env, R.tick, RNG_STEP, 0u, P.seed, P.stream, x);
                     a[0] = draw_action(x[0], (R.meta >> 8) & 0xFu, nonrev);
                     a[1] = draw_action(x[1], (R.meta >> 12) & 0xFu, nonrev);
-                } else {
+                    if (SLIDING && !uniforms) {
+                        u[0] = (float)(x[2] >> 8) * (1.0f / 16777216.0f);
+                        u[1] = (float)(x[3] >> 8) * (1.0f / 16777216.0f);
+                    }
+                }
+                if (actions) {
                     a[0] = (int)(R.act & 3u);
                     a[1] = (int)((R.act >> 8) & 3u);
                 }
@@ -760,7 +922,8 @@ __device__ __forceinline__ void obs_tile(const Params &P, int E, uint32_t cpe, u
             uint4 rst = make_uint4(0u, 0u, 0u, 0u), ro = make_uint4(0u, 0u, 0u, 0u);
             if (mine) {
                 if (autoreset) R.nstart = rs_in[lane].z;
-                lane_move_codes(P, reinterpret_cast<unsigned char *>(tile + (size_t)lane * cpe), R, a, flags, rst, ro);
+                if (SLIDING) lane_move_codes_slide(P, reinterpret_cast<unsigned char *>(tile + (size_t)lane * cpe), R, a, u, flags, rst, ro);
+                else lane_move_codes(P, reinterpret_cast<unsigned char *>(tile + (size_t)lane * cpe), R, a, flags, rst, ro);
             }
             if (lane < E) {
                 rec_st[lane] = rst;
@@ -783,6 +946,13 @@ __device__ __forceinline__ void obs_tile(const Params &P, int E, uint32_t cpe, u
             } else {
                 if (out.reward)
                     reinterpret_cast<float2 *>(out.reward)[env] = make_float2(__uint_as_float(ro.y), __uint_as_float(ro.z));
+                if (SLIDING && ro.w && !(ro.w >> 31)) {               // this step's slide marks go to the env's log (see lane_move_codes_slide)
+                    const uint32_t m0 = ro.w & 0x3FFFu, m1 = ro.w >> 14;
+                    uint32_t at = ((rec_st[lane].y >> SLIDE_CNT_SHIFT) & SLIDE_CNT_MASK) - (m0 ? 1u : 0u) - (m1 ? 1u : 0u);
+                    uint16_t *lg = slide_log(P) + (size_t)env * slide_log_len(P.W);
+                    if (m0) lg[at++] = (uint16_t)(m0 - 1u);
+                    if (m1) lg[at] = (uint16_t)((m1 - 1u) | 0x8000u);
+                }
             }
         }
 #ifndef TRON_STAMPS
@@ -839,6 +1009,13 @@ __global__ __launch_bounds__(BLOCK) void k_obs(Params P, int E, uint32_t cpe, ui
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     obs_tile<DO_STEP>(P, E, cpe, cpe_magic, actions, flags, out, (int)blockIdx.x + tile0, smem);
 }
+// ... and in the sliding modes (own kernels: mode None's stay as they were, instruction for instruction)
+__global__ __launch_bounds__(BLOCK) void k_obs_slide(Params P, int E, uint32_t cpe, uint32_t cpe_magic, const int8_t *__restrict__ actions,
+                                                     const float *__restrict__ uniforms, uint32_t flags, StepOut out, int tile0)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    obs_tile<true, true>(P, E, cpe, cpe_magic, actions, flags, out, (int)blockIdx.x + tile0, smem, false, false, uniforms);
+}
 
 // The random-action rollout as ONE launch for k_steps steps (tron_rollout_random): envs never interact,
 // so a workgroup can step its own tiles k_steps times without waiting for anybody else — there is no
@@ -889,6 +1066,29 @@ static_assert(std::is_same<first_kernel_arg<decltype(&k_obs_roll)>::type, Params
               "k_obs_roll re-reads Params from kernarg offset 0: Params must stay its first parameter");
 static_assert(std::is_trivially_copyable<Params>::value && alignof(Params) <= 8 && sizeof(Params) % 4 == 0,
               "Params is block-copied from the kernel-argument segment with scalar loads");
+
+// the sliding modes' persistent rollout: k_obs_roll's loop on obs_tile<true, true> (Params kept live: the kernel-argument re-read
+// pays off for mode None's register budget, not measured here)
+__global__ __launch_bounds__(BLOCK) void k_obs_roll_slide(Params P, int E, uint32_t cpe, uint32_t cpe_magic, uint32_t flags,
+                                                         StepOut out, int k_steps, int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long acc[4];           // see k_obs_roll
+    StepOut lo = out;
+    if (out.totals) {
+        if (threadIdx.x < 4) acc[threadIdx.x] = 0ull;
+        lo.totals = acc;
+        __syncthreads();
+    }
+    const bool resident = (flags & TRON_ROLLOUT_RESIDENT) != 0u && (int)gridDim.x == ntiles;
+    flags &= ~TRON_ROLLOUT_RESIDENT;
+    for (int s = 0; s < k_steps; ++s)
+        for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
+            obs_tile<true, true>(P, E, cpe, cpe_magic, nullptr, flags, lo, t, smem, resident && s > 0, resident);
+            __syncthreads();
+        }
+    if (out.totals && threadIdx.x < 4 && acc[threadIdx.x]) atomicAdd(&out.totals[threadIdx.x], acc[threadIdx.x]);
+}
 
 // ------------------------------------------------------------ incremental step --
 // Observation-is-state, TRON_STEP_INCREMENTAL: the attached planes already hold the previous
@@ -1074,6 +1274,35 @@ __global__ void k_obs_to_grid(Params P, int8_t *__restrict__ grid_out)
         const size_t e = i / (size_t)P.G, cidx = i - e * (size_t)P.G;
         grid_out[i] = tile_of_code(P.obs_state[e * 2u * P.G + cidx]);
     }
+}
+// ... and the slide tiles (sliding modes): a logged cell that still holds its player's body code is that player's slide tile
+__global__ void k_obs_grid_marks(Params P, int8_t *__restrict__ grid_out)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= P.N) return;
+    const uint32_t cnt = (P.st4[env].y >> SLIDE_CNT_SHIFT) & SLIDE_CNT_MASK;
+    const uint16_t *lg = slide_log(P) + (size_t)env * slide_log_len(P.W);
+    const int8_t *o = P.obs_state + (size_t)env * 2u * P.G;
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t e = lg[k], cell = e & 0x7FFFu, pl = e >> 15;
+        if (o[cell] == (pl ? (int8_t)-3 : (int8_t)-2)) grid_out[(size_t)env * P.G + cell] = pl ? TRON_P2_SLIDE : TRON_P1_SLIDE;
+    }
+}
+// attaching to boards that already hold slide tiles (steps were made on the board-owning layout): their log, from the grid
+__global__ void k_obs_attach_marks(Params P)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= P.N) return;
+    const int8_t *g = P.grid + (size_t)env * P.G;
+    uint16_t *lg = slide_log(P) + (size_t)env * slide_log_len(P.W);
+    uint32_t cnt = 0u;
+    for (int i = 0; i < P.G; ++i) {
+        const int8_t t = g[i];
+        if (t == TRON_P1_SLIDE || t == TRON_P2_SLIDE) lg[cnt++] = (uint16_t)((uint32_t)i | (t == TRON_P2_SLIDE ? 0x8000u : 0u));
+    }
+    uint4 st = P.st4[env];
+    st.y = (st.y & ~(SLIDE_CNT_MASK << SLIDE_CNT_SHIFT)) | (cnt << SLIDE_CNT_SHIFT);
+    P.st4[env] = st;
 }
 __global__ void k_obs_reset(Params P, const int8_t *__restrict__ mask)
 {
@@ -1337,14 +1566,22 @@ int launch_fmt(tron_env *h, int fmt, const int8_t *a, const float *u, uint32_t f
 }
 
 template <bool DO_STEP>
-int launch_obs(tron_env *h, const int8_t *actions, uint32_t flags, StepOut out, hipStream_t st)
+int launch_obs(tron_env *h, const int8_t *actions, uint32_t flags, StepOut out, hipStream_t st, const float *uniforms = nullptr)
 {
-    auto kern = k_obs<DO_STEP>;
-    static uint64_t prepared = 0;    // per instantiation, one bit per device
-    allow_big_lds(reinterpret_cast<const void *>(kern), h->device, prepared);
     int tile0, blocks;
     part_tiles(h, tile0, blocks);
     const size_t smem = ((size_t)h->E + 1u) * h->cpe * 16u + 4u * (size_t)h->E * 16u;
+    if (DO_STEP && h->P.mode != TRON_MODE_NONE) {                       // the sliding modes' kernel
+        static uint64_t prepared_s = 0;
+        allow_big_lds(reinterpret_cast<const void *>(k_obs_slide), h->device, prepared_s);
+        if (blocks > 0)
+            hipLaunchKernelGGL(k_obs_slide, dim3(blocks), dim3(BLOCK), smem, st, h->P, h->E, h->cpe, h->cpe_magic, actions, uniforms, flags,
+                               out, tile0);
+        return launch_status();
+    }
+    auto kern = k_obs<DO_STEP>;
+    static uint64_t prepared = 0;    // per instantiation, one bit per device
+    allow_big_lds(reinterpret_cast<const void *>(kern), h->device, prepared);
     if (blocks > 0)
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, h->P, h->E, h->cpe, h->cpe_magic, actions, flags, out,
                            tile0);
@@ -1444,8 +1681,10 @@ int tron_create(int32_t n_envs, int32_t W, int32_t mode, int32_t fair, uint32_t 
     // one blob: grid (padded for 16-byte over-read) + state words + fresh template
     const size_t N = (size_t)n_envs;
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // (sliding modes: the slide-mark log of the observation-is-state layout sits right behind the slide rates: slide_log())
+    const size_t log_bytes = P.mode != TRON_MODE_NONE ? N * (size_t)slide_log_len(P.W) * sizeof(uint16_t) : 0;
     const size_t o_grid = 0, o_st4 = align(o_grid + N * P.G + 64), o_rs4 = align(o_st4 + 16 * N),
-                 o_slide = align(o_rs4 + 16 * N), o_fresh = align(o_slide + 8 * N),
+                 o_slide = align(o_rs4 + 16 * N), o_log = align(o_slide + 8 * N), o_fresh = align(o_log + log_bytes),
                  total = align(o_fresh + (size_t)P.G + 16);
     char *blob = nullptr;
     if (hipMalloc(reinterpret_cast<void **>(&blob), total) != hipSuccess) {
@@ -1533,12 +1772,14 @@ int tron_attach_obs_state(tron_handle h, int8_t *obs_codes, void *stream)
 {
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
     if (!obs_codes || (reinterpret_cast<uintptr_t>(obs_codes) & 15u)) return TRON_ERR_BAD_ARG;
-    if (h->P.mode != TRON_MODE_NONE || !h->aligned) return TRON_ERR_UNSUPPORTED;   // slide tiles are not codable
+    if (!h->aligned || h->P.G > 0x7FFF) return TRON_ERR_UNSUPPORTED;
     if (h->P.obs_state) return TRON_ERR_BAD_ARG;                                      // already attached
     h->P.obs_state = obs_codes;
     const int per = BLOCK / 64;     // derive the planes from the boards as they are now
     hipLaunchKernelGGL(k_obs_reset, dim3((h->P.N + per - 1) / per), dim3(BLOCK), 0, S_(stream), h->P,
                        (const int8_t *)nullptr);
+    if (h->P.mode != TRON_MODE_NONE)  // slide tiles are not codable (Map.color shows them as bodies): they go to the log (lane_move_codes_slide)
+        hipLaunchKernelGGL(k_obs_attach_marks, dim3((h->P.N + 255) / 256), dim3(256), 0, S_(stream), h->P);
     return launch_status();
 }
 
@@ -1548,7 +1789,7 @@ int tron_step_encode(tron_handle h, const int8_t *actions, const float *uniforms
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
     if ((obs_fmt != TRON_OBS_NONE) != (obs != nullptr)) return TRON_ERR_BAD_ARG;
     if (flags & ~(TRON_STEP_AUTORESET | TRON_STEP_INCREMENTAL | TRON_STEP_NONREVERSING)) return TRON_ERR_BAD_ARG;
-    if ((flags & TRON_STEP_INCREMENTAL) && !h->P.obs_state) return TRON_ERR_UNSUPPORTED;
+    if ((flags & TRON_STEP_INCREMENTAL) && (!h->P.obs_state || h->P.mode != TRON_MODE_NONE)) return TRON_ERR_UNSUPPORTED;
     StepOut out{out_done, out_winner, out_reward, nullptr};
     if (h->P.obs_state) {
         if (obs_fmt == TRON_OBS_CODES_I8 && obs != h->P.obs_state) return TRON_ERR_BAD_ARG;   // the attached buffer is the output
@@ -1559,7 +1800,7 @@ int tron_step_encode(tron_handle h, const int8_t *actions, const float *uniforms
                                actions, flags, out);
             rc = launch_status();
         } else {
-            rc = launch_obs<true>(h, actions, flags, out, S_(stream));
+            rc = launch_obs<true>(h, actions, flags, out, S_(stream), uniforms);
         }
         if (rc != TRON_OK || obs_fmt == TRON_OBS_NONE || obs_fmt == TRON_OBS_CODES_I8) return rc;
         return obs_planes(h, obs_fmt, obs, S_(stream));
@@ -1628,6 +1869,8 @@ int tron_get_grid(tron_handle h, int8_t *grid_out, void *stream)
     if (!grid_out) return TRON_ERR_BAD_ARG;
     if (h->P.obs_state) {
         hipLaunchKernelGGL(k_obs_to_grid, dim3(2048), dim3(256), 0, S_(stream), h->P, grid_out);
+        if (h->P.mode != TRON_MODE_NONE)
+            hipLaunchKernelGGL(k_obs_grid_marks, dim3((h->P.N + 255) / 256), dim3(256), 0, S_(stream), h->P, grid_out);
         return launch_status();
     }
     const size_t nbytes = (size_t)h->P.N * h->P.G;
@@ -1706,9 +1949,18 @@ int rollout_persistent(tron_env *h, int32_t k_steps, uint32_t flags, StepOut out
     if (smem > 160u * 1024u) return TRON_ERR_BAD_ARG;
     const int ntiles = (h->P.N + E - 1) / E;
     const int grid = (env_grid > 0 && env_grid < ntiles) ? env_grid : ntiles;
+    const bool sliding = h->P.mode != TRON_MODE_NONE;
+    if (sliding) {
+        static uint64_t prepared_s = 0;
+        allow_big_lds(reinterpret_cast<const void *>(k_obs_roll_slide), h->device, prepared_s);
+    }
     for (int left = k_steps; left > 0; left -= chunk) {
-        hipLaunchKernelGGL(k_obs_roll, dim3(grid), dim3(BLOCK), smem, st, h->P, E, h->cpe, h->cpe_magic, flags, out,
-                           left < chunk ? left : chunk, ntiles);
+        if (sliding)
+            hipLaunchKernelGGL(k_obs_roll_slide, dim3(grid), dim3(BLOCK), smem, st, h->P, E, h->cpe, h->cpe_magic, flags, out,
+                               left < chunk ? left : chunk, ntiles);
+        else
+            hipLaunchKernelGGL(k_obs_roll, dim3(grid), dim3(BLOCK), smem, st, h->P, E, h->cpe, h->cpe_magic, flags, out,
+                               left < chunk ? left : chunk, ntiles);
         if (launch_status() != TRON_OK) return TRON_ERR_LAUNCH;
     }
     return TRON_OK;

@@ -45,13 +45,13 @@ class VecTron:
         self.done = torch.zeros(self.N, dtype=torch.int8, device=dev)
         self.winner = torch.zeros(self.N, dtype=torch.int8, device=dev)
         self.reward = torch.zeros(self.N, 2, dtype=torch.float32, device=dev)
-        # mode None + int8 codes + even side: let self.obs BE the env state (tron_attach_obs_state);
-        # it is then read-only for the caller — clone what must outlive the next step
-        self.obs_is_state = bool(obs_is_state and mode in (None, "none") and self._fmt == nat.OBS_CODES_I8
-                                 and self.W % 2 == 0)
-        # incremental=True (needs obs_is_state): steps write only the cells a move touches and the boards
+        # int8 codes + even side: let self.obs BE the env state (tron_attach_obs_state); it is then read-only for the
+        # caller — clone what must outlive the next step.  (The sliding modes too: their slide tiles, which the codes show
+        # as bodies, are kept in a per-env log for grid().)
+        self.obs_is_state = bool(obs_is_state and self._fmt == nat.OBS_CODES_I8 and self.W % 2 == 0)
+        # incremental=True (needs obs_is_state, mode None): steps write only the cells a move touches and the boards
         # that restart, instead of rewriting both planes — same observations, far less traffic
-        self.incremental = bool(incremental and self.obs_is_state)
+        self.incremental = bool(incremental and self.obs_is_state and mode in (None, "none"))
         if self.obs_is_state:
             with torch.cuda.device(self.device):
                 nat.check(self._lib.tron_attach_obs_state(self._h, nat.ptr(self.obs), nat.stream_ptr()),

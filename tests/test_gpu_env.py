@@ -144,7 +144,7 @@ def test_hip_vs_oracle_philox(T, N, W, mode, fair, autoreset, reward):
     table = {"ddqn": oracle.REWARD_DDQN, "dqn": oracle.REWARD_DQN, "acktr": oracle.REWARD_ACKTR}[reward]
     env = tv.VecTron(N, W, mode=mode, fair=fair, seed=1234, rank=3, obs_format="codes", reward=reward, slide=0.3,
                      obs_is_state=ois, incremental=inc)
-    assert env.obs_is_state == (ois and mode is None and W % 2 == 0) and env.incremental == inc
+    assert env.obs_is_state == (ois and W % 2 == 0) and env.incremental == inc
     ref = oracle.VecOracle(N, W, mode=mode, seed=1234, stream=3, fair=fair, reward=table, slide=0.3)
     obs0 = env.reset()
     ref.reset_all()
@@ -325,14 +325,16 @@ def test_step_without_obs_and_totals(T):
 
 
 @pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("mode,slide", [(None, 0.15), ("temper", 0.15), ("ice", 0.4)])
 @pytest.mark.parametrize("N,W,K", [(300, 10, 37), (5000, 24, 70), (33, 2, 9), (70, 16, 130)])
-def test_persistent_rollout_equals_stepwise(T, N, W, K, resident):
+def test_persistent_rollout_equals_stepwise(T, N, W, K, resident, mode, slide):
     """tron_rollout_random on the observation-is-state path is ONE launch in which every workgroup steps
-    its own tiles K times (k_obs_roll): same state, observations and totals as K oracle steps."""
+    its own tiles K times (k_obs_roll; the sliding modes: k_obs_roll_slide, their slide tiles kept in the per-env log that
+    grid() replays): same state — board image included —, observations and totals as K oracle steps."""
     tv, oracle = T
-    env = tv.VecTron(N, W, seed=2024, rank=6, obs_format="codes")
+    env = tv.VecTron(N, W, mode=mode, slide=slide, seed=2024, rank=6, obs_format="codes")
     assert env.obs_is_state
-    ref = oracle.VecOracle(N, W, seed=2024, stream=6)
+    ref = oracle.VecOracle(N, W, mode=mode, slide=slide, seed=2024, stream=6)
     env.reset()
     ref.reset_all()
     totals = torch.zeros(4, dtype=torch.int64, device="cuda")
@@ -343,6 +345,9 @@ def test_persistent_rollout_equals_stepwise(T, N, W, K, resident):
         exp += [N, int(((d == 1) & (w == 1)).sum()), int(((d == 1) & (w == 2)).sum()), int(((d == 1) & (w == 0)).sum())]
     assert np.array_equal(np_(totals), exp)
     assert np.array_equal(np_(env.obs).reshape(N, 2, -1), o)
+    assert np.array_equal(np_(env.grid()).reshape(N, -1), ref.grid)       # slide tiles as slide tiles
+    if mode is not None and K > 30 and W >= 10:
+        assert int(np.isin(ref.grid, (5, 6)).sum()) > 0                  # (and there are some)
     _compare_state(env, ref, "persistent rollout")
     env.step()                                      # and the per-step kernel carries on from there
     ref.step(autoreset=True)
@@ -398,7 +403,7 @@ def test_two_stream_rollout_equals_oracle(T, N, W, mode, K):
     _compare_state(env, ref, "two-stream rollout")
 
 
-@pytest.mark.parametrize("N,W,K,kw", [(260, 10, 70, dict(mode="temper")), (90, 7, 33, dict(mode="ice", slide=0.4)),
+@pytest.mark.parametrize("N,W,K,kw", [(260, 10, 70, dict(mode="temper", obs_is_state=False)), (90, 7, 33, dict(mode="ice", slide=0.4)),
                                       (150, 9, 20, dict(obs_format="planes3")), (64, 12, 65, dict(obs_format="planes4", mode="temper")),
                                       (100, 10, 40, dict(obs_is_state=False))])
 def test_persistent_rollout_board_layout(T, N, W, K, kw):

@@ -49,7 +49,7 @@ def test_persistent_rollout_at_benchmarked_size(T, N, W, mode, K, resident):
     the flag is ignored elsewhere)."""
     tv, oracle = T
     env = tv.VecTron(N, W, mode=mode, seed=0x5EED, rank=3, obs_format="codes")
-    assert env.obs_is_state == (mode is None)
+    assert env.obs_is_state                         # every mode on the observation-is-state layout (k_obs_roll / k_obs_roll_slide)
     ref = oracle.VecOracle(N, W, mode=mode, seed=0x5EED, stream=3)
     env.reset()
     ref.reset_all()
