@@ -1067,8 +1067,10 @@ static_assert(std::is_same<first_kernel_arg<decltype(&k_obs_roll)>::type, Params
 static_assert(std::is_trivially_copyable<Params>::value && alignof(Params) <= 8 && sizeof(Params) % 4 == 0,
               "Params is block-copied from the kernel-argument segment with scalar loads");
 
-// the sliding modes' persistent rollout: k_obs_roll's loop on obs_tile<true, true> (Params kept live: the kernel-argument re-read
-// pays off for mode None's register budget, not measured here)
+// the sliding modes' persistent rollout: k_obs_roll's loop on obs_tile<true, true>
+#ifndef TRON_SLIDE_KERNARG_REREAD
+#define TRON_SLIDE_KERNARG_REREAD 1   // as k_obs_roll: Params re-read from the kernel-argument segment per step (69 -> 41 SGPR spills; temper 0.750 -> 0.757, 0.720 -> 0.734 at 20 steps per launch)
+#endif
 __global__ __launch_bounds__(BLOCK) void k_obs_roll_slide(Params P, int E, uint32_t cpe, uint32_t cpe_magic, uint32_t flags,
                                                          StepOut out, int k_steps, int ntiles)
 {
@@ -1082,13 +1084,25 @@ __global__ __launch_bounds__(BLOCK) void k_obs_roll_slide(Params P, int E, uint3
     }
     const bool resident = (flags & TRON_ROLLOUT_RESIDENT) != 0u && (int)gridDim.x == ntiles;
     flags &= ~TRON_ROLLOUT_RESIDENT;
+#if TRON_SLIDE_KERNARG_REREAD
+    kernarg_t *kp = (kernarg_t *)__builtin_amdgcn_kernarg_segment_ptr();       // (Params is the first argument: see k_obs_roll)
+#endif
     for (int s = 0; s < k_steps; ++s)
         for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
+#if TRON_SLIDE_KERNARG_REREAD
+            kernarg_t *q = kp;
+            asm volatile("" : "+s"(q));
+            Params Pl;
+            load_params(Pl, q);
+            obs_tile<true, true>(Pl, E, cpe, cpe_magic, nullptr, flags, lo, t, smem, resident && s > 0, resident);
+#else
             obs_tile<true, true>(P, E, cpe, cpe_magic, nullptr, flags, lo, t, smem, resident && s > 0, resident);
+#endif
             __syncthreads();
         }
     if (out.totals && threadIdx.x < 4 && acc[threadIdx.x]) atomicAdd(&out.totals[threadIdx.x], acc[threadIdx.x]);
 }
+static_assert(std::is_same<first_kernel_arg<decltype(&k_obs_roll_slide)>::type, Params>::value, "k_obs_roll_slide may re-read Params from kernarg offset 0");
 
 // ------------------------------------------------------------ incremental step --
 // Observation-is-state, TRON_STEP_INCREMENTAL: the attached planes already hold the previous

@@ -112,13 +112,14 @@ int tron_set_weight_degree(tron_handle h, const int16_t *weight, const int16_t *
 int tron_reset(tron_handle h, const int8_t *env_mask, const int8_t *start_pos,
                const int16_t *weight, const int16_t *degree, void *stream);
 
-/* Observation-is-state storage (mode None, even W, TRON_OBS_CODES_I8).  With no slide tiles the
- * player-1 code plane is a lossless image of the board, so the caller's observation buffer
- * int8[N][2][G] can BE the env state: each step reads the player-1 plane and rewrites both
- * planes — the algorithmic 3G bytes per env-step, with no separate board write-back.
+/* Observation-is-state storage (even W, TRON_OBS_CODES_I8; every mode).  The player-1 code plane carries the game — a cell is
+ * EMPTY or it is not — so the caller's observation buffer int8[N][2][G] can BE the env state: each step reads the player-1 plane
+ * and rewrites both planes — the algorithmic 3G bytes per env-step, with no separate board write-back.  In mode None the plane
+ * is a lossless image of the board; in ice / temper a slide tile shows as its player's body (map.py:67-81), so the env keeps the
+ * slide tiles in a per-env log (2 bytes appended per slide) that tron_get_grid replays: the board image stays exact.
  * After attaching, the buffer belongs to the env until tron_destroy: read it, never write it;
  * pass it (or NULL with TRON_OBS_NONE) as `obs` to tron_step_encode.  tron_get_grid, tron_encode
- * and tron_reset keep working.  Returns TRON_ERR_UNSUPPORTED for ice/temper or odd W. */
+ * and tron_reset keep working.  Returns TRON_ERR_UNSUPPORTED for odd W (TRON_STEP_INCREMENTAL: mode None only). */
 int tron_attach_obs_state(tron_handle h, int8_t *obs_codes, void *stream);
 
 /* --- step (+ observation encode), the hot path --------------------------------
