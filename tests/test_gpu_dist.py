@@ -66,6 +66,24 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
 
 
 @pytest.mark.timeout(900)
+def test_driver_invocation_two_ranks_with_the_dqn_records():
+    """The driver's own multi-rank command line (`bench.py --gpus N --steps 20 --warmup 5`: headline, cold / settled regions, temper,
+    and the two DDQN records with their per-learn-step gradient all-reduce, deferred update and the one-launch optimizer) with two
+    ranks on one GPU: both ranks exit 0, rank 0 prints the one line, no record carries an error."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    outs = _spawn(2, ["bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5"], timeout=800)
+    lines = [ln for ln in outs[0][1].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][1].splitlines() if ln.startswith("{")]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 20 and rec["warmup"] == 5 and rec["settle_steps"] >= 6400
+    assert "cold_start" in rec and "temper" in rec and "cpu_baseline" not in rec          # (the CPU baseline is an N = 1 record)
+    for k in ("dqn", "dqn_config3"):
+        assert "error" not in rec[k] and rec[k]["value"] > 0 and rec[k]["learner_saturated"]["value"] > 0
+        assert rec[k]["config"]["parallelism"].startswith("env-shard + replay-shard x2")
+
+
+@pytest.mark.timeout(900)
 def test_trainer_two_ranks_on_one_gpu(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
