@@ -314,9 +314,18 @@ def main():
     parser.add_argument('--width', type=int, default=MAP_WIDTH)
     parser.add_argument('--iterations', type=int, default=1000)
     a = parser.parse_args()
-    out = train(a.envs, a.width, a.m, a.r, a.iterations, log_every=20, args=a,
-                save_path=f"{folderName}/ACKTR_player{a.m}{a.u}.bak" if a.u else None)
-    print({k: v for k, v in out.items() if k != "brain"})
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:                                   # one rank per GPU (python -m torch.distributed.run --nproc-per-node N ACKTR.py ...)
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+        dist.init_process_group(os.environ.get("TRON_DIST_BACKEND", "nccl"))
+    rank = dist.get_rank() if world > 1 else 0
+    out = train(a.envs, a.width, a.m, a.r, a.iterations, log_every=20 if rank == 0 else 0, args=a,
+                save_path=(f"{folderName}/ACKTR_player{a.m}{a.u}.bak" if a.u and rank == 0 else None))   # (the ranks hold the same weights)
+    if rank == 0:
+        print({k: v for k, v in out.items() if k != "brain"})
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
