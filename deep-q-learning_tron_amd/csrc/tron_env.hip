@@ -676,10 +676,10 @@ __device__ inline void lane_move_codes(const Params &P, unsigned char *g, const 
 // (map.py:67-81): the dynamics never tell the two apart (a cell is EMPTY or it is not), only the board image does
 // (tron_get_grid).  So the player-1 code plane carries the game here too, and the slide marks go to a per-env LOG —
 // entry = cell | player << 15, appended by the step that makes the mark (2 bytes, only when somebody slides), their
-// number in st4.meta bits 16-25 (a restart rewrites meta: the log empties by itself) — which tron_get_grid replays:
+// number in st4.meta bits 16-29 (a restart rewrites meta: the log empties by itself) — which tron_get_grid replays:
 // a logged cell that still holds its player's body code is a slide tile.  The board-owning layout wrote every
 // dirty 16-byte chunk of the board back as a partial line instead: 153 MB per step against 121 (profiles/r04_temper_pmc.txt).
-constexpr uint32_t SLIDE_CNT_SHIFT = 16u, SLIDE_CNT_MASK = 0x3FFu;
+constexpr uint32_t SLIDE_CNT_SHIFT = 16u, SLIDE_CNT_MASK = 0x3FFFu;      // (a mark takes a cell and so does the head behind it: <= W W / 2 marks; 14 bits cover every side the 15-bit cell index allows)
 __device__ __forceinline__ uint16_t *slide_log(const Params &P)
 {
     return reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(P.slide) + (((size_t)P.N * 8u + 255u) & ~(size_t)255u));
@@ -1786,7 +1786,7 @@ int tron_attach_obs_state(tron_handle h, int8_t *obs_codes, void *stream)
 {
     if (bad_handle(h)) return h ? TRON_ERR_NO_DEVICE : TRON_ERR_BAD_ARG;
     if (!obs_codes || (reinterpret_cast<uintptr_t>(obs_codes) & 15u)) return TRON_ERR_BAD_ARG;
-    if (!h->aligned || h->P.G > 0x7FFF) return TRON_ERR_UNSUPPORTED;
+    if (!h->aligned || h->P.G >= 0x3FFF) return TRON_ERR_UNSUPPORTED;                 // (cell + 1 travels in 14 bits: restart word, slide marks)
     if (h->P.obs_state) return TRON_ERR_BAD_ARG;                                      // already attached
     h->P.obs_state = obs_codes;
     const int per = BLOCK / 64;     // derive the planes from the boards as they are now
