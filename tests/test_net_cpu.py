@@ -310,3 +310,25 @@ def test_conv_modules_are_plain_conv2d_off_the_gpu():
     plain = torch.nn.Conv2d(64, 64, 7, padding=3, stride=2)
     plain.load_state_dict(net.conv7.state_dict())                       # same parameter names and shapes
     assert torch.equal(plain(x), want)
+
+
+def test_adam_soft_on_host_tensors_is_optim_adam():
+    """DDQN.AdamSoft (the device path is one HIP launch: tests/test_gpu_learner_codes.py) on host tensors takes optim.Adam's own
+    step and leaves the soft update to the caller (returns False): same parameters and state bit for bit, and the state dicts
+    interchange — what the CPU facade and the gloo tests run."""
+    import DDQN
+    torch.manual_seed(2)
+    ps = [torch.nn.Parameter(torch.randn(7, 5)), torch.nn.Parameter(torch.randn(11))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    mine, ref = DDQN.AdamSoft(ps), torch.optim.Adam(qs)
+    tgt = [torch.zeros_like(p) for p in ps]
+    for _ in range(3):
+        for p, q in zip(ps, qs):
+            p.grad = torch.randn_like(p)
+            q.grad = p.grad.clone()
+        assert mine.step(targets=tgt, tau=0.1) is False               # host tensors: the caller applies Agent.soft_update
+        ref.step()
+    assert all(torch.equal(p, q) for p, q in zip(ps, qs)) and all(float(t.abs().max()) == 0.0 for t in tgt)
+    other = torch.optim.Adam(qs)
+    other.load_state_dict(mine.state_dict())
+    assert all(torch.equal(other.state[q]["exp_avg"], mine.state[p]["exp_avg"]) for p, q in zip(ps, qs))
