@@ -186,7 +186,7 @@ class Net(nn.Module):
                     self.train(was_training)
             if codes and fused.default_math == "f16x3" and fused.ws_supported(self, side) and fused.head_supported(self, side):
                 # the weight-stationary chain: PX16 images from conv1's output to the head's pooling, no f32 activation tensor
-                x = fused.trunk_px(self, x.reshape(-1, side, side), plane4, want="px16")
+                x = fused.trunk_px(self, x.reshape(-1, side, side), plane4, want="head")
                 return fused.head(self, x, want_q=False, want_greedy=True)[1] if greedy else fused.head(self, x)
             x = fused.trunk(self, x.reshape(-1, side, side) if codes else x, codes=codes, plane4=plane4)
             if fused.default_math == "f16x3" and fused.head_supported(self, side):

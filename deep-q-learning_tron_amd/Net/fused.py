@@ -261,6 +261,31 @@ def conv_ws(x, conv, wfrag, residual=None, act=True, want_px=True, want_f32=Fals
     return ret[0] if len(ret) == 1 else tuple(ret)
 
 
+use_pool_fused = _os.environ.get("TRON_POOL_FUSED", "1") != "0"      # 12x12: conv6 and the head's pooling as one launch (0: two)
+
+
+class Pooled12:
+    """conv6's output of a 12x12 observation batch after AvgPool2d(3, 2, 1) (DQNNet.py:52), as the split-f16 rows conv7's GEMM
+    reads: what tron_conv3x3_ws_fwd_pool12 writes and tron_dqn_head_fwd_pooled takes."""
+
+    def __init__(self, batch, device):
+        self.shape = (batch, 64, 6, 6)
+        self.buf = torch.empty(int(nat.lib().tron_pooled12_bytes(batch)), dtype=torch.uint8, device=device)
+
+
+def conv_ws_pool12(x, conv, wfrag, residual):
+    """AvgPool2d(3, 2, 1)(mish(conv3x3(x) + bias + residual)) of 64-channel 12x12 PX16 images in one launch (tron_conv3x3_ws_fwd_pool12):
+    the convolution's output stays in LDS.  Returns a Pooled12."""
+    B, cin, S, _ = x.shape
+    if (cin, conv.in_channels, conv.out_channels, S) != (64, 64, 64, 12) or residual is None or residual.shape != x.shape:
+        raise TypeError("conv_ws_pool12: 64 -> 64 channels at 12x12 with a residual")
+    out = Pooled12(B, x.buf.device)
+    with torch.cuda.device(x.buf.device):
+        nat.check(nat.lib().tron_conv3x3_ws_fwd_pool12(nat.ptr(x.buf), nat.ptr(wfrag), nat.ptr(conv.bias.detach()), nat.ptr(residual.buf),
+                                                       nat.ptr(out.buf), B, nat.stream_ptr()), "tron_conv3x3_ws_fwd_pool12")
+    return out
+
+
 def conv_ws_infer(x, cout, wfrag, bias, residual=None, want_f32=False):
     """mish(conv3x3(x) + bias + residual), gradient-free, from tensors instead of a module: x PX16 -> PX16, or (want_f32) the f32
     NCHW tensor (tron_conv3x3_ws_fwd)."""
@@ -277,7 +302,8 @@ def conv_ws_infer(x, cout, wfrag, bias, residual=None, want_f32=False):
 
 def trunk_px(net, codes, plane4=0.0, want="f32"):
     """conv1..conv6 with their two residual links (DQNNet.py:34-50) from the env's int8 codes [B, S, S], the
-    activations staying PX16 images from conv1's output to conv6's.  want: "f32" -> [B, 64, S, S], "px16" -> PX16."""
+    activations staying PX16 images from conv1's output to conv6's.  want: "f32" -> [B, 64, S, S], "px16" -> PX16, "head" -> what
+    `head` takes with the least traffic: at 12x12 the pooled rows (conv6 and the pooling in one launch), else the PX16 image."""
     w = ws_split_weights([net.conv2, net.conv3, net.conv4, net.conv5, net.conv6])          # one launch for all five
     a = conv1_px16(codes, net.conv1, plane4)
     b = conv_ws(a, net.conv2, w[0])
@@ -286,7 +312,9 @@ def trunk_px(net, codes, plane4=0.0, want="f32"):
     d = conv_ws(c, net.conv4, w[2])
     del c
     e = conv_ws(d, net.conv5, w[3])
-    if want == "px16":
+    if want == "head" and use_pool_fused and e.shape[-1] == 12 and e.shape[0] > 0:
+        return conv_ws_pool12(e, net.conv6, w[4], d)
+    if want in ("px16", "head"):
         return conv_ws(e, net.conv6, w[4], residual=d)
     return conv_ws(e, net.conv6, w[4], residual=d, want_px=False, want_f32=True)
 
@@ -546,7 +574,9 @@ def head(net, x, want_q=True, want_greedy=False):
     L = nat.lib()
     px = isinstance(x, PX16)                      # conv6's output as the PX16 image: the pooling reads it as it is
     B, side = x.shape[0], x.shape[-1]
-    if px:
+    if isinstance(x, Pooled12):                   # ... or already pooled (tron_conv3x3_ws_fwd_pool12)
+        dev, fn, xp, side = x.buf.device, L.tron_dqn_head_fwd_pooled, x.buf.data_ptr(), 12
+    elif px:
         assert tuple(x.shape[1:]) == (64, side, side), x.shape
         dev, fn, xp = x.buf.device, L.tron_dqn_head_fwd_px16, x.buf.data_ptr()
     else:

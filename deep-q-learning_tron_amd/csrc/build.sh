@@ -5,7 +5,7 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC"
-SRCS="tron_env.hip tron_replay.hip tron_minimax.hip tron_kfac.hip tron_kfac_px.hip tron_nn.hip tron_conv.hip tron_conv_f16.hip tron_conv_ws.hip tron_conv_ws_train.hip tron_conv_wgrad.hip tron_conv_wgrad_rows.hip tron_head.hip tron_dqn.hip"
+SRCS="tron_env.hip tron_replay.hip tron_minimax.hip tron_kfac.hip tron_kfac_px.hip tron_nn.hip tron_conv.hip tron_conv_f16.hip tron_conv_ws.hip tron_conv_ws_pool.hip tron_conv_ws_train.hip tron_conv_wgrad.hip tron_conv_wgrad_rows.hip tron_head.hip tron_dqn.hip"
 OBJDIR=build
 mkdir -p "$OBJDIR"
 STAMP="$OBJDIR/.flags"

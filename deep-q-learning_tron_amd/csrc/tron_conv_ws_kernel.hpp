@@ -145,7 +145,13 @@ __device__ unsigned long long g_ws_stamps[256 * 12 * 8];         // [workgroup][
 //             — res the gradient that reaches the same tensor along a residual connection, zb the pre-activation of the
 //             layer below — with the per-channel sums of out (that layer's bias gradient) and the largest |out| left in
 //             `stats` per workgroup (k_wsb_finish adds them up in a fixed order).  F32OUT also writes out as f32 NCHW.
-enum { WS_INFER = 0, WS_TRAIN = 1, WS_BWD = 2 };
+//   WS_POOL   WS_INFER whose output never leaves the CU as an image: the epilogue writes the item's PX16 values into an LDS
+//             image O ([channel quad][pixel][4 values: hi + lo 2^-11 as f32]); once an item's last epilogue is in (flushed at the item's end),
+//             the workgroup average-pools it (3x3 / stride 2 / pad 1, DQNNet.py:20,52 — the arithmetic of tron_head.hip's
+//             px16_window_sum on the same values, so the result has the bits of the two-kernel path) and stores the
+//             pooled rows the head's conv7 GEMM reads: `out` = hi rows, `pre_px` = lo rows, [B][(octet, pooled pixel, channel)].
+//             Whole 12x12 images per item only (tron_conv_ws_pool.hip).
+enum { WS_INFER = 0, WS_TRAIN = 1, WS_BWD = 2, WS_POOL = 3 };
 // A gradient image's device record: info = {s, 1 / s, -, -, max |g| per channel [<= 64]} (include/tron_hip.h).
 struct WsBwd {
     const unsigned char *zb;     // PX16 pre-activation of the layer below [B][COUT][S][S] (COUT = this launch's output channels)
@@ -168,10 +174,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
     const unsigned char *__restrict__ res, unsigned char *__restrict__ out, float *__restrict__ out_f32,
     float *__restrict__ pre_f32, int B, int apply_mish, int nitems, unsigned char *__restrict__ pre_px, WsBwd bw)
 {
-    constexpr bool TRAIN = MODE == WS_TRAIN, BWD = MODE == WS_BWD;
+    constexpr bool TRAIN = MODE == WS_TRAIN, BWD = MODE == WS_BWD, POOL = MODE == WS_POOL;
     static_assert(!BWD || G::TPS == 1, "the gradient epilogue is written for one tile per step");
+    static_assert(!POOL || (G::S == 12 && G::R == 12 && G::IPI == 1 && G::TPS == 1 && G::COUT == 64 && !F32OUT), "pooled output: whole 12x12 images");
     constexpr int S = G::S, NS = G::NS, NCB = G::NCB, TPS = G::TPS, THREADS = G::THREADS;
-    constexpr int NST = G::NST * (TRAIN ? 2 : 1);                        // stores per step: (hi, lo) of the output, and of the pre-activation
+    constexpr int NST = POOL ? 0 : G::NST * (TRAIN ? 2 : 1);             // stores per step: (hi, lo) of the output, and of the pre-activation
+    // (POOL) the LDS output image behind the sink: quad q of pixel p at O_OFF + q O_QS + 16 p; lanes without a pixel write O_DUMP
+    constexpr int O_OFF = G::SINK_OFF + 1024, O_QS = G::SS * 16 + 16, O_DUMP = O_OFF + (G::COUT / 4) * O_QS;
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
@@ -290,8 +299,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
     bool pok[TPS];                                                       // (BWD) the pending tile's pixel exists: it counts in the sums
     int64_t pfo[TPS];                                                    // (F32OUT) element offset of its four f32 values, or -1
     int pt[TPS], p_ip = 0, p_par = 0;                                    // tile indices, image (pair) index, residual-stage parity
+    int plo[TPS];                                                        // (POOL) where this lane's 16 bytes go in the LDS output image
 #pragma unroll
     for (int k = 0; k < TPS; ++k) {
+        plo[k] = O_DUMP + lane * 16;
         pv[k] = pe[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (BWD) pz[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
         phh[k] = (f16x4){0, 0, 0, 0};
@@ -323,6 +334,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
             unsigned char *po = out + (size_t)img * 2 * G::HALFG_OUT + poff;      // (img, pixg are 0 when !ok: a valid address either way)
             pp[k] = (ok && out && TRON_WS_ABLATE != 7) ? po : g_ws_dump + lane * 16;
             asm volatile("" : "+v"(pp[k]));
+            if (POOL) {
+                plo[k] = ok ? O_OFF + (4 * ct + g) * O_QS + pixg * 16 : O_DUMP + lane * 16;
+                asm volatile("" : "+v"(plo[k]));
+            }
             if (TRAIN) {
                 unsigned char *pz = pre_px + (size_t)img * 2 * G::HALFG_OUT + poff;
                 ppz[k] = (ok && pre_px) ? pz : g_ws_dump + lane * 16;
@@ -408,6 +423,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
         } else {
             const f16x4 ll = __builtin_convertvector(pv[k], f16x4);
             if (TRON_WS_ABLATE == 4) { asm volatile("" ::"v"(ll), "v"(phh[k]), "v"(pp[k])); return; }
+            if (POOL) {                                                  // the value the PX16 image would have carried: hi + lo 2^-11
+                *reinterpret_cast<f32x4 *>(lds + plo[k]) = __builtin_convertvector(phh[k], f32x4) + __builtin_convertvector(ll, f32x4) * LO_UNSCALE;
+                return;
+            }
             *reinterpret_cast<f16x4 *>(pp[k]) = phh[k];
             *reinterpret_cast<f16x4 *>(pp[k] + G::HALFG_OUT) = ll;
         }
@@ -426,6 +445,30 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
         }
     };
 
+    // (POOL) image `img`'s pooled rows from the LDS output image: a unit = (channel quad, pooled pixel) — four channels, the window's
+    // taps in px16_window_sum's order and arithmetic; 576 units: one per thread, and 64 more for wave 0
+    auto pool_pass = [&](int img) {
+        for (int u = tid; u < 16 * 36; u += THREADS) {
+            const int q = u / 36, pq = u - q * 36, py = pq / 6, px = pq - py * 6;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = 2 * py + t / 3 - 1, xx = 2 * px + t % 3 - 1;
+                const bool in_img = yy >= 0 && yy < S && xx >= 0 && xx < S;
+                const int yc = yy < 0 ? 0 : (yy >= S ? S - 1 : yy), xc = xx < 0 ? 0 : (xx >= S ? S - 1 : xx);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(lds + O_OFF + q * O_QS + (yc * S + xc) * 16);
+                acc += v * (in_img ? 1.0f : 0.0f);
+            }
+            const f32x4 sum = acc * (1.0f / 9.0f);
+            const f16x4 hh = __builtin_convertvector(sum, f16x4);
+            const f16x4 ll = __builtin_convertvector((sum - __builtin_convertvector(hh, f32x4)) * LO_SCALE, f16x4);
+            const size_t o = ((size_t)img * 288 + (q >> 1) * 36 + pq) * 16 + (q & 1) * 8;
+            *reinterpret_cast<f16x4 *>(out + o) = hh;
+            *reinterpret_cast<f16x4 *>(pre_px + o) = ll;
+        }
+    };
+    int pooled_img = -1;                                                 // (POOL) the image whose output sits in O, waiting for its pass
+
     __builtin_amdgcn_s_waitcnt(0);                                       // (the builtin, not asm: the compiler's own wait insertion then
     __syncthreads();                                                     //  knows the weight loads are done and adds no vmcnt(0) in the loop)
     int item = blockIdx.x, cur = 0, par = 0;
@@ -442,7 +485,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
 #ifdef TRON_WS_STAMPS
         const unsigned long long st_a = __builtin_amdgcn_s_memtime();
 #endif
-        if (first || F32OUT || !dma_in_loop) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (POOL) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (and this wave's writes of the previous item's output image)
+        else if (first || F32OUT || !dma_in_loop) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
         first = false;
 #ifdef TRON_WS_STAMPS
@@ -452,6 +496,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
 #ifdef TRON_WS_STAMPS
         const unsigned long long st_c = __builtin_amdgcn_s_memtime();
 #endif
+        if (POOL && pooled_img >= 0) {                                   // the previous item's image is complete: pool it, then O is free again
+            pool_pass(pooled_img);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         const int nxt = item + (int)gridDim.x;
         if (nxt < nitems && !dma_in_loop)
             for (int j = 0; j < G::DMA_PER_WAVE; ++j) dma_piece(nxt, cur ^ 1, j);
@@ -573,6 +621,14 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
             p_ip = ip;
             p_par = par;
         }
+        if (POOL) {                                                      // the item's last epilogue now, not under the next item's first step:
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the image must be whole at the next barrier
+#pragma unroll
+            for (int s = 0; s < NS; ++s) epi_at_slab(s);
+#pragma unroll
+            for (int k = 0; k < TPS; ++k) pt[k] = -1;                    // (nothing pending: the next step's stages write to the dump)
+            pooled_img = ip;
+        }
 #ifdef TRON_WS_STAMPS
         st_steps += __builtin_amdgcn_s_memtime() - st_d;
 #endif
@@ -588,6 +644,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
     if (RES || BWD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int s = 0; s < NS; ++s) epi_at_slab(s);
+    if (POOL) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (pooled_img >= 0) pool_pass(pooled_img);
+    }
     if (BWD) {
         // this workgroup's column sums / maxima: over the 16 pixels of a tile row (lanes with equal g), then over the waves
         // that share an M tile, in a fixed order; k_wsb_finish adds the workgroups up

@@ -332,13 +332,11 @@ __device__ __forceinline__ void px16_window_sum(const unsigned char *img, int S,
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        float hs = 0.0f, ls = 0.0f;
+        // (tap by tap in f32: the arithmetic tron_conv_ws_kernel.hpp's WS_POOL pass repeats on the same values, bit for bit)
+        float acc = 0.0f;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            hs += wgt[t] * (float)h[t][j];
-            ls += wgt[t] * (float)l[t][j];
-        }
-        sum[j] = hs + ls * LO_UNSCALE;
+        for (int t = 0; t < 9; ++t) acc += wgt[t] * ((float)h[t][j] + (float)l[t][j] * LO_UNSCALE);
+        sum[j] = acc;
     }
 }
 
@@ -1234,7 +1232,8 @@ extern "C" int64_t tron_dqn_head_workspace(int64_t batch, int32_t side)
     return plan(batch, 64 * 6 * 6, 64 * 3 * 3).total;
 }
 
-static int head_fwd(const void *trunk, bool px16, int64_t batch, int32_t side, const float *conv7_w,
+// src: 0 = f32 planes, 1 = PX16 image, 2 = the pooled rows tron_conv3x3_ws_fwd_pool12 wrote (12x12 only)
+static int head_fwd(const void *trunk, int src, int64_t batch, int32_t side, const float *conv7_w,
                     const float *conv7_b, const float *fc1_w, const float *fc1_b, const float *fc2_w,
                     const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,
                     const float *actor2_b, void *workspace, float *q_out, int8_t *greedy_out, void *stream)
@@ -1245,7 +1244,8 @@ static int head_fwd(const void *trunk, bool px16, int64_t batch, int32_t side, c
         !actor2_w || !actor2_b || !workspace || (!q_out && !greedy_out) || batch < 0)
         return TRON_ERR_BAD_ARG;
     if (batch == 0) return TRON_OK;
-    if ((side != 12 && side != 26) || batch > (side == 12 ? (1ll << 24) : (1ll << 22))) return TRON_ERR_UNSUPPORTED;
+    if ((side != 12 && side != 26) || batch > (side == 12 ? (1ll << 24) : (1ll << 22)) || (src == 2 && side != 12)) return TRON_ERR_UNSUPPORTED;
+    const bool px16 = src != 0;
     if ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(trunk_out) | reinterpret_cast<uintptr_t>(q_out)) & 15u)
         return TRON_ERR_BAD_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1276,13 +1276,17 @@ static int head_fwd(const void *trunk, bool px16, int64_t batch, int32_t side, c
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
     auto H = [&](int64_t off) { return reinterpret_cast<f16 *>(ws + off); };
     const int64_t nrows = batch * C * PS;
-    if (px16) hipLaunchKernelGGL(k_pool_split12_px, dim3((unsigned)((batch * 288 + 255) / 256 < (1 << 20) ? (batch * 288 + 255) / 256 : (1 << 20))), dim3(256), 0, st, trunk_px, batch, H(p.a7h), H(p.a7l));
+    const f16 *a7h = H(p.a7h), *a7l = H(p.a7l);
+    if (src == 2) {
+        a7h = reinterpret_cast<const f16 *>(trunk_px);
+        a7l = reinterpret_cast<const f16 *>(trunk_px + align256(batch * K7 * 2));
+    } else if (px16) hipLaunchKernelGGL(k_pool_split12_px, dim3((unsigned)((batch * 288 + 255) / 256 < (1 << 20) ? (batch * 288 + 255) / 256 : (1 << 20))), dim3(256), 0, st, trunk_px, batch, H(p.a7h), H(p.a7l));
     else hipLaunchKernelGGL(k_pool_split12, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, trunk_out, nrows, H(p.a7h), H(p.a7l));
     const HeadWeights hw{conv7_w, fc1_w, fc2_w, actor1_w, H(p.d7h), H(p.d7l), H(p.w1h), H(p.w1l), H(p.w2h), H(p.w2l), H(p.w3h), H(p.w3l),
                          0, px16 ? 1 : 0, 256 * N7};
     hipLaunchKernelGGL(k_head_weights, dim3(1024, 4), dim3(256), 0, st, hw);
     if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
-    int rc = gemm<G_PLAIN>(H(p.a7h), H(p.a7l), H(p.d7h), H(p.d7l), conv7_b, OS * OS, batch, N7, K7, 1, nullptr, H(p.c7h), H(p.c7l), st);
+    int rc = gemm<G_PLAIN>(a7h, a7l, H(p.d7h), H(p.d7l), conv7_b, OS * OS, batch, N7, K7, 1, nullptr, H(p.c7h), H(p.c7l), st);
     if (rc == TRON_OK) rc = gemm<G_PLAIN>(H(p.c7h), H(p.c7l), H(p.w1h), H(p.w1l), fc1_b, 1, batch, 256, N7, 1, nullptr, H(p.c1h), H(p.c1l), st);
     if (rc == TRON_OK) rc = gemm<G_PLAIN>(H(p.c1h), H(p.c1l), H(p.w2h), H(p.w2l), fc2_b, 1, batch, 128, 256, 1, nullptr, H(p.c2h), H(p.c2l), st);
     float *c3 = reinterpret_cast<float *>(ws + p.c3);
@@ -1298,7 +1302,7 @@ extern "C" int tron_dqn_head_fwd(const float *trunk_out, int64_t batch, int32_t 
                                  const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,
                                  const float *actor2_b, void *workspace, float *q_out, int8_t *greedy_out, void *stream)
 {
-    return head_fwd(trunk_out, false, batch, side, conv7_w, conv7_b, fc1_w, fc1_b, fc2_w, fc2_b, actor1_w, actor1_b, actor2_w,
+    return head_fwd(trunk_out, 0, batch, side, conv7_w, conv7_b, fc1_w, fc1_b, fc2_w, fc2_b, actor1_w, actor1_b, actor2_w,
                     actor2_b, workspace, q_out, greedy_out, stream);
 }
 
@@ -1308,7 +1312,18 @@ extern "C" int tron_dqn_head_fwd_px16(const void *trunk_px16, int64_t batch, int
                                       const float *actor2_w, const float *actor2_b, void *workspace, float *q_out,
                                       int8_t *greedy_out, void *stream)
 {
-    return head_fwd(trunk_px16, true, batch, side, conv7_w, conv7_b, fc1_w, fc1_b, fc2_w, fc2_b, actor1_w, actor1_b, actor2_w,
+    return head_fwd(trunk_px16, 1, batch, side, conv7_w, conv7_b, fc1_w, fc1_b, fc2_w, fc2_b, actor1_w, actor1_b, actor2_w,
+                    actor2_b, workspace, q_out, greedy_out, stream);
+}
+
+// the head from the pooled rows of tron_conv3x3_ws_fwd_pool12 (10x10 boards: conv6 + pooling were one launch); workspace as above
+extern "C" int tron_dqn_head_fwd_pooled(const void *pooled, int64_t batch, int32_t side, const float *conv7_w,
+                                        const float *conv7_b, const float *fc1_w, const float *fc1_b, const float *fc2_w,
+                                        const float *fc2_b, const float *actor1_w, const float *actor1_b,
+                                        const float *actor2_w, const float *actor2_b, void *workspace, float *q_out,
+                                        int8_t *greedy_out, void *stream)
+{
+    return head_fwd(pooled, 2, batch, side, conv7_w, conv7_b, fc1_w, fc1_b, fc2_w, fc2_b, actor1_w, actor1_b, actor2_w,
                     actor2_b, workspace, q_out, greedy_out, stream);
 }
 

@@ -14,7 +14,7 @@ MODE = {None: 0, "none": 0, "ice": 1, "temper": 2}                 # tron/game.p
 OBS_NONE, OBS_CODES_I8, OBS_PLANES3_F32, OBS_PLANES4_F32 = 0, 1, 2, 3
 OBS = {None: OBS_NONE, "none": OBS_NONE, "codes": OBS_CODES_I8, "planes3": OBS_PLANES3_F32,
        "planes4": OBS_PLANES4_F32}
-ABI_VERSION = 12                                                    # include/tron_hip.h TRON_ABI_VERSION
+ABI_VERSION = 13                                                    # include/tron_hip.h TRON_ABI_VERSION
 STEP_AUTORESET = 1
 STEP_INCREMENTAL = 2
 STEP_NONREVERSING = 4
@@ -115,6 +115,9 @@ SIGNATURES = {
     "tron_kfac_gram_px16": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _vp, _vp, _vp]),
     "tron_dqn_head_fwd": (C.c_int, [_vp, _i64, _i32] + [_vp] * 10 + [_vp, _vp, _vp, _vp]),
     "tron_dqn_head_fwd_px16": (C.c_int, [_vp, _i64, _i32] + [_vp] * 10 + [_vp, _vp, _vp, _vp]),
+    "tron_dqn_head_fwd_pooled": (C.c_int, [_vp, _i64, _i32] + [_vp] * 10 + [_vp, _vp, _vp, _vp]),
+    "tron_pooled12_bytes": (C.c_int64, [_i64]),
+    "tron_conv3x3_ws_fwd_pool12": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tron_dqn_head_workspace": (C.c_int64, [_i64, _i32]),
     "tron_pool12": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "tron_pool_s2": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),

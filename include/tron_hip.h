@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TRON_ABI_VERSION 12
+#define TRON_ABI_VERSION 13
 
 typedef enum {
     TRON_OK = 0,
@@ -485,6 +485,19 @@ int tron_dqn_head_fwd_px16(const void *trunk_px16, int64_t batch, int32_t side, 
                            const float *conv7_b, const float *fc1_w, const float *fc1_b, const float *fc2_w,
                            const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,
                            const float *actor2_b, void *workspace, float *q_out, int8_t *greedy_out, void *stream);
+/* 10x10 boards (side 12): conv6 and the pooling as ONE launch (csrc/tron_conv_ws_pool.hip; DQNNet.py:48-52: mish(conv6(x) + res),
+ * AvgPool2d(3, 2, 1)) — conv6's 64 x 12 x 12 output stays in LDS, what reaches memory are the pooled rows conv7's GEMM reads:
+ * `pooled` = tron_pooled12_bytes(batch) bytes, [hi rows | lo rows], a row = 64 x 6 x 6 split f16.  in_px16, res_px16: PX16
+ * images [batch][64][12][12]; wfrag: conv6's fragment image (tron_conv3x3_ws_split_weights).  Same bits as
+ * tron_conv3x3_ws_fwd followed by the pooling inside tron_dqn_head_fwd_px16.  tron_dqn_head_fwd_pooled: the head from those rows
+ * (side must be 12; workspace tron_dqn_head_workspace(batch, 12)).                                                        */
+int64_t tron_pooled12_bytes(int64_t batch);
+int tron_conv3x3_ws_fwd_pool12(const void *in_px16, const void *wfrag, const float *bias, const void *res_px16,
+                               void *pooled, int64_t batch, void *stream);
+int tron_dqn_head_fwd_pooled(const void *pooled, int64_t batch, int32_t side, const float *conv7_w,
+                             const float *conv7_b, const float *fc1_w, const float *fc1_b, const float *fc2_w,
+                             const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,
+                             const float *actor2_b, void *workspace, float *q_out, int8_t *greedy_out, void *stream);
 /* The same two layers on the training path (their products are library GEMMs on conv7's dense form):
  * tron_pool12: AvgPool2d(3, stride 2, padding 1) (Net/DQNNet.py:20,52) of `planes` 12x12 f32 planes -> 6x6 (backward 0),
  * or its gradient 6x6 -> 12x12 (backward 1).  tron_conv7_dense: fold 0: conv7's weight f32[cout][cin][7][7] -> the

@@ -38,7 +38,7 @@ def test_header_symbols_exported_and_bound(native):
 
 def test_abi_version_and_strerror(native):
     L = native.lib()
-    assert L.tron_abi_version() == native.ABI_VERSION == 12
+    assert L.tron_abi_version() == native.ABI_VERSION == 13
     assert L.tron_strerror(0) == b"ok"
     assert b"argument" in L.tron_strerror(-1)
 

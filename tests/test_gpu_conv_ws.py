@@ -176,3 +176,66 @@ def test_infer_from_codes_takes_the_ws_chain(fused, W, monkeypatch):
     assert net.infer_path(codes, codes=True) == "layer-kernels"
     q_old = net.infer(codes, codes=True)
     assert (q - q_old).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("B", [1, 2, 255, 256, 257, 777, 4096, 8192 + 3])
+def test_conv6_with_the_pooling_in_one_launch_has_the_bits_of_two(fused, B, monkeypatch):
+    """tron_conv3x3_ws_fwd_pool12 (conv6's output stays in LDS, DQNNet.py:48-52) against tron_conv3x3_ws_fwd followed by the head's own
+    pooling: the pooled rows, Q and the greedy action bit for bit; and against float64 through Net.infer.  Batches below, at and
+    above one image per workgroup (256 CUs), and several images per workgroup with a ragged last round."""
+    from Net.DQNNet import Net
+    from tron import _native as nat
+    torch.manual_seed(B)
+    net = Net(3, 10).cuda()
+    x = _to_px16(fused, torch.randn(B, 64, 12, 12, device="cuda") * 1.5)
+    r = _to_px16(fused, torch.randn(B, 64, 12, 12, device="cuda"))
+    w = fused.ws_split_weights([net.conv6])[0]
+    pooled = fused.conv_ws_pool12(x, net.conv6, w, r)
+    assert pooled.buf.numel() == nat.lib().tron_pooled12_bytes(B) == 2 * ((B * 2304 * 2 + 255) // 256 * 256)
+    y = fused.conv_ws(x, net.conv6, w, residual=r)                        # the PX16 image the two-launch path writes
+    # the head's pooling of that image, by the definition: the window's values hi + lo 2^-11 added in tap order, / 9, split again
+    img = y.buf.view(torch.float16).reshape(B, 2, 8, 12, 12, 8).float()   # [b, half, octet, y, x, channel]
+    pad = torch.nn.functional.pad(img[:, 0] + img[:, 1] * (1.0 / 2048.0), (0, 0, 1, 1, 1, 1))
+    acc = torch.zeros(B, 8, 6, 6, 8, device="cuda")
+    for t in range(9):
+        acc = acc + pad[:, :, t // 3:t // 3 + 12:2, t % 3:t % 3 + 12:2, :]
+    s = acc * (1.0 / 9.0)
+    hi = s.to(torch.float16)
+    lo = ((s - hi.float()) * 2048.0).to(torch.float16)
+    half = (B * 2304 * 2 + 255) // 256 * 256
+    got = pooled.buf.view(torch.float16)
+    assert torch.equal(got[:B * 2304].reshape(B, 8, 6, 6, 8), hi)
+    assert torch.equal(got[half // 2:half // 2 + B * 2304].reshape(B, 8, 6, 6, 8), lo)
+    q1, g1 = fused.head(net, pooled, want_greedy=True)
+    q2, g2 = fused.head(net, y, want_greedy=True)
+    assert torch.equal(q1, q2) and torch.equal(g1, g2)
+
+
+@pytest.mark.parametrize("B", [300, 5000])
+def test_infer_at_12x12_pools_inside_conv6(fused, B, monkeypatch):
+    """Net.infer(codes) at 12x12 takes the one-launch conv6 + pooling; TRON_POOL_FUSED=0 (two launches) gives the same bits."""
+    from Net.DQNNet import Net
+    torch.manual_seed(B)
+    net = Net(3, 10).cuda()
+    codes = _codes(B, 12, B)
+    calls = []
+    real = fused.conv_ws_pool12
+    monkeypatch.setattr(fused, "conv_ws_pool12", lambda *a: (calls.append(1), real(*a))[1])
+    q, g = net.infer(codes, codes=True), net.infer(codes, codes=True, greedy=True)
+    assert len(calls) == 2
+    monkeypatch.setattr(fused, "use_pool_fused", False)
+    assert torch.equal(net.infer(codes, codes=True), q) and torch.equal(net.infer(codes, codes=True, greedy=True), g)
+    assert len(calls) == 2
+
+
+def test_pool12_bad_args(fused):
+    from tron import _native as nat
+    L = nat.lib()
+    assert L.tron_pooled12_bytes(-1) == 0 and L.tron_pooled12_bytes(0) == 0 and L.tron_pooled12_bytes(1) == 2 * 4608
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    p = buf.data_ptr()
+    assert L.tron_conv3x3_ws_fwd_pool12(p, p, p, None, p, 1, None) == nat.ERR_BAD_ARG      # conv6 always has its residual
+    assert L.tron_conv3x3_ws_fwd_pool12(p + 8, p, p, p, p, 1, None) == nat.ERR_BAD_ARG
+    assert L.tron_conv3x3_ws_fwd_pool12(p, p, p, p, p, 0, None) == nat.OK
+    net_w = [buf.data_ptr()] * 10
+    assert L.tron_dqn_head_fwd_pooled(p, 1, 26, *net_w, p, p, None, None) == nat.ERR_UNSUPPORTED
