@@ -25,6 +25,9 @@ typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef TRON_WS_POOL_FLUSH  // WS_POOL: 1 = an item's last epilogue runs at the item's end and the pooling pass right after the next
+#define TRON_WS_POOL_FLUSH 0 // item's barrier; 0 = the epilogue rides on the next item's first step as everywhere else, the pass follows that step
+#endif
 #ifndef TRON_WS_ABLATE      // diagnostic builds only (wrong results; scripts/ws_ablate.sh): 1 = no epilogue arithmetic, 2 = B fragments
 #define TRON_WS_ABLATE 0    // not re-read from LDS, 3 = no image DMA, 4 = no stores, 5 = no MFMAs, 6 = no item barrier
 #endif
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
 #ifdef TRON_WS_STAMPS
         const unsigned long long st_c = __builtin_amdgcn_s_memtime();
 #endif
-        if (POOL && pooled_img >= 0) {                                   // the previous item's image is complete: pool it, then O is free again
+        if (POOL && TRON_WS_POOL_FLUSH && pooled_img >= 0) {             // the previous item's image is complete: pool it, then O is free again
             pool_pass(pooled_img);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -620,8 +623,16 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
             }
             p_ip = ip;
             p_par = par;
+            if (POOL && !TRON_WS_POOL_FLUSH && st == 0 && pooled_img >= 0) {
+                // the previous item's last epilogue rode on this step: once everybody's has, its image is whole — pool it; the
+                // image is free again before this item's first epilogue (under step 1) writes it
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                pool_pass(pooled_img);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
         }
-        if (POOL) {                                                      // the item's last epilogue now, not under the next item's first step:
+        if (POOL && !TRON_WS_POOL_FLUSH) pooled_img = ip;
+        if (POOL && TRON_WS_POOL_FLUSH) {                                // the item's last epilogue now, not under the next item's first step:
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the image must be whole at the next barrier
 #pragma unroll
             for (int s = 0; s < NS; ++s) epi_at_slab(s);
