@@ -265,7 +265,7 @@ def dqn_record(envs, width, steps, warmup, batch, repeats, world, rank):
                                  "Whole-loop time incl. env step, replay push / sample, optimizer; forward and input gradient of "
                                  "the learner's four linear layers are f32 library GEMMs (their weight gradients: "
                                  "tron_linear_wgrad; conv7: tron_gemm_f16x3 on its dense form at 12x12, tron_pool_conv7 at "
-                                 "26x26); per-kernel rows: profiles/r03_learn_*_kernel_rows.txt, r03_infer_*"}}
+                                 "26x26); per-kernel rows: profiles/r04_learn_*_kernel_rows.txt, r04_infer_*"}}
 
 
 class _RandomModel:

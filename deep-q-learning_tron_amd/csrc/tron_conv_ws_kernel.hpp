@@ -25,8 +25,8 @@ typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-#ifndef TRON_WS_POOL_FLUSH  // WS_POOL: 1 = an item's last epilogue runs at the item's end and the pooling pass right after the next
-#define TRON_WS_POOL_FLUSH 0 // item's barrier; 0 = the epilogue rides on the next item's first step as everywhere else, the pass follows that step
+#ifndef TRON_WS_POOL_ABLATE // diagnostic builds only (wrong results; scripts/ws_ablate.sh poolflags): 1 = WS_POOL without its pooling pass,
+#define TRON_WS_POOL_ABLATE 0 // 2 = and without the barrier in front of it, 3 = and the epilogue's LDS write goes to the dump
 #endif
 #ifndef TRON_WS_ABLATE      // diagnostic builds only (wrong results; scripts/ws_ablate.sh): 1 = no epilogue arithmetic, 2 = B fragments
 #define TRON_WS_ABLATE 0    // not re-read from LDS, 3 = no image DMA, 4 = no stores, 5 = no MFMAs, 6 = no item barrier
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
     constexpr int NST = POOL ? 0 : G::NST * (TRAIN ? 2 : 1);             // stores per step: (hi, lo) of the output, and of the pre-activation
     // (POOL) the LDS output image behind the sink: quad q of pixel p at O_OFF + q O_QS + 16 p; lanes without a pixel write O_DUMP
     constexpr int O_OFF = G::SINK_OFF + 1024, O_QS = G::SS * 16 + 16, O_DUMP = O_OFF + (G::COUT / 4) * O_QS;
+    constexpr int O_FLAG = O_DUMP + 1024;                                // a word per wave: pooling passes it has finished
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
     float cmax = 0.0f;                                                   //       and the largest magnitude among them
 
     for (int i = tid; i < (BWD ? G::TAB_OFF : 2 * G::BUF) / 16; i += THREADS) reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (POOL && tid < G::WAVES) reinterpret_cast<int *>(lds + O_FLAG)[tid] = 0;
 
     // the band this workgroup serves (the grid is a multiple of NB, so it is always the same one)
     const int band = blockIdx.x % G::NB;
@@ -303,6 +305,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
     int64_t pfo[TPS];                                                    // (F32OUT) element offset of its four f32 values, or -1
     int pt[TPS], p_ip = 0, p_par = 0;                                    // tile indices, image (pair) index, residual-stage parity
     int plo[TPS];                                                        // (POOL) where this lane's 16 bytes go in the LDS output image
+    bool pend_b = false;                                                 // (POOL) this wave has yet to see the last pooling pass finished (below)
+    int npass = 0;                                                       // (POOL) pooling passes started so far
 #pragma unroll
     for (int k = 0; k < TPS; ++k) {
         plo[k] = O_DUMP + lane * 16;
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
             pp[k] = (ok && out && TRON_WS_ABLATE != 7) ? po : g_ws_dump + lane * 16;
             asm volatile("" : "+v"(pp[k]));
             if (POOL) {
-                plo[k] = ok ? O_OFF + (4 * ct + g) * O_QS + pixg * 16 : O_DUMP + lane * 16;
+                plo[k] = (ok && TRON_WS_POOL_ABLATE < 3) ? O_OFF + (4 * ct + g) * O_QS + pixg * 16 : O_DUMP + lane * 16;
                 asm volatile("" : "+v"(plo[k]));
             }
             if (TRAIN) {
@@ -427,6 +431,17 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
             const f16x4 ll = __builtin_convertvector(pv[k], f16x4);
             if (TRON_WS_ABLATE == 4) { asm volatile("" ::"v"(ll), "v"(phh[k]), "v"(pp[k])); return; }
             if (POOL) {                                                  // the value the PX16 image would have carried: hi + lo 2^-11
+                if (pend_b) {                                            // (the previous image's pooling pass must be over: its waves say so)
+                    for (;;) {
+                        const volatile __attribute__((address_space(3))) int *f = (const volatile __attribute__((address_space(3))) int *)(lds + O_FLAG);
+                        int done = f[0];
+#pragma unroll
+                        for (int w = 1; w < G::WAVES; ++w) { const int d = f[w]; done = d < done ? d : done; }
+                        if (__builtin_amdgcn_readfirstlane(done) >= npass) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    pend_b = false;
+                }
                 *reinterpret_cast<f32x4 *>(lds + plo[k]) = __builtin_convertvector(phh[k], f32x4) + __builtin_convertvector(ll, f32x4) * LO_UNSCALE;
                 return;
             }
@@ -448,26 +463,45 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
         }
     };
 
-    // (POOL) image `img`'s pooled rows from the LDS output image: a unit = (channel quad, pooled pixel) — four channels, the window's
-    // taps in px16_window_sum's order and arithmetic; 576 units: one per thread, and 64 more for wave 0
-    auto pool_pass = [&](int img) {
-        for (int u = tid; u < 16 * 36; u += THREADS) {
+    // (POOL) image `img`'s pooled rows from the LDS output image.  A unit = (channel quad, pooled pixel): four channels, the window's
+    // nine values added in px16_window_sum's order, / 9, split.  12 is even, so only the row above and the column left of the image
+    // are padding: such a tap reads 16 bytes of zeros (the zero zone at the start of LDS) instead, every other tap is the unit's
+    // base + a constant.  576 units: one per thread, and the 64 left over go to the first wave of the last pixel group (which has a
+    // tile fewer per item than the first group's).  What a thread needs of its units is computed once per launch — the pass costs
+    // vector issue slots and LDS round trips, the scarce things in this kernel (with the indices worked out in place a unit was 130
+    // instructions; three units one after the other in the waves of one pixel group left the other group waiting at the item's end).
+    constexpr int PUNITS = 2;
+    int pbase[POOL ? PUNITS : 1], pout[POOL ? PUNITS : 1];               // LDS base of the window; output byte offset in the row | top | left << 1, or -1
+    if (POOL) {
+#pragma unroll
+        for (int k = 0; k < PUNITS; ++k) {
+            const int u = k == 0 ? tid : THREADS + tid - (G::PG - 1) * 64 * G::NCT;
+            const bool mine = k == 0 || (wave == (G::PG - 1) * G::NCT);
             const int q = u / 36, pq = u - q * 36, py = pq / 6, px = pq - py * 6;
+            pbase[k] = O_OFF + q * O_QS + ((2 * py - 1) * S + (2 * px - 1)) * 16;
+            pout[k] = (mine && u >= 0 && u < 16 * 36) ? ((((q >> 1) * 36 + pq) * 16 + (q & 1) * 8) | (py == 0 ? 1 : 0) | (px == 0 ? 2 : 0)) : -1;
+        }
+        static_assert(!POOL || (THREADS == 512 && G::NCT == 4 && G::PG == 2), "the units' deal");
+    }
+    auto pool_pass = [&](int img) {
+        unsigned char *oh = out + (size_t)img * 4608, *ol = pre_px + (size_t)img * 4608;
+#pragma unroll
+        for (int k = 0; k < PUNITS; ++k) {
+            if (pout[k] < 0) continue;
+            const int b = pbase[k];
+            const bool top = pout[k] & 1, left = pout[k] & 2;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int yy = 2 * py + t / 3 - 1, xx = 2 * px + t % 3 - 1;
-                const bool in_img = yy >= 0 && yy < S && xx >= 0 && xx < S;
-                const int yc = yy < 0 ? 0 : (yy >= S ? S - 1 : yy), xc = xx < 0 ? 0 : (xx >= S ? S - 1 : xx);
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(lds + O_OFF + q * O_QS + (yc * S + xc) * 16);
-                acc += v * (in_img ? 1.0f : 0.0f);
+                const int dy = t / 3, dx = t % 3, c = (dy * S + dx) * 16;
+                const bool pad = (dy == 0 && top) || (dx == 0 && left);
+                acc += *reinterpret_cast<const f32x4 *>(lds + ((dy > 0 && dx > 0) ? b + c : (pad ? 0 : b + c)));
             }
             const f32x4 sum = acc * (1.0f / 9.0f);
             const f16x4 hh = __builtin_convertvector(sum, f16x4);
             const f16x4 ll = __builtin_convertvector((sum - __builtin_convertvector(hh, f32x4)) * LO_SCALE, f16x4);
-            const size_t o = ((size_t)img * 288 + (q >> 1) * 36 + pq) * 16 + (q & 1) * 8;
-            *reinterpret_cast<f16x4 *>(out + o) = hh;
-            *reinterpret_cast<f16x4 *>(pre_px + o) = ll;
+            *reinterpret_cast<f16x4 *>(oh + (pout[k] & ~7)) = hh;
+            *reinterpret_cast<f16x4 *>(ol + (pout[k] & ~7)) = ll;
         }
     };
     int pooled_img = -1;                                                 // (POOL) the image whose output sits in O, waiting for its pass
@@ -499,10 +533,6 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
 #ifdef TRON_WS_STAMPS
         const unsigned long long st_c = __builtin_amdgcn_s_memtime();
 #endif
-        if (POOL && TRON_WS_POOL_FLUSH && pooled_img >= 0) {             // the previous item's image is complete: pool it, then O is free again
-            pool_pass(pooled_img);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
         const int nxt = item + (int)gridDim.x;
         if (nxt < nitems && !dma_in_loop)
             for (int j = 0; j < G::DMA_PER_WAVE; ++j) dma_piece(nxt, cur ^ 1, j);
@@ -623,23 +653,27 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
             }
             p_ip = ip;
             p_par = par;
-            if (POOL && !TRON_WS_POOL_FLUSH && st == 0 && pooled_img >= 0) {
-                // the previous item's last epilogue rode on this step: once everybody's has, its image is whole — pool it; the
-                // image is free again before this item's first epilogue (under step 1) writes it
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                pool_pass(pooled_img);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (POOL && st == 0 && pooled_img >= 0) {
+                // The previous item's last epilogue rode on this step: once everybody's has (the barrier) its image is whole and
+                // every wave pools its share.  Nobody may write the image again before all of it has been read: a wave looks at the
+                // others' pass counters in LDS before its first write of this item's output (stage 5 of the epilogue under step 1,
+                // some 15 slabs from here: the counters have long moved by then).  A second s_barrier instead would line the waves
+                // up once more per item.
+#ifdef TRON_WS_STAMPS
+                const unsigned long long st_p0 = __builtin_amdgcn_s_memtime();
+#endif
+                if (TRON_WS_POOL_ABLATE < 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                ++npass;
+                if (TRON_WS_POOL_ABLATE < 1) pool_pass(pooled_img);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the pass's reads have returned)
+                if (lane == 0) *(volatile __attribute__((address_space(3))) int *)(lds + O_FLAG + 4 * wave) = npass;
+                pend_b = true;
+#ifdef TRON_WS_STAMPS
+                st_res += __builtin_amdgcn_s_memtime() - st_p0;           // (the barrier and the pass)
+#endif
             }
         }
-        if (POOL && !TRON_WS_POOL_FLUSH) pooled_img = ip;
-        if (POOL && TRON_WS_POOL_FLUSH) {                                // the item's last epilogue now, not under the next item's first step:
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the image must be whole at the next barrier
-#pragma unroll
-            for (int s = 0; s < NS; ++s) epi_at_slab(s);
-#pragma unroll
-            for (int k = 0; k < TPS; ++k) pt[k] = -1;                    // (nothing pending: the next step's stages write to the dump)
-            pooled_img = ip;
-        }
+        if (POOL) pooled_img = ip;
 #ifdef TRON_WS_STAMPS
         st_steps += __builtin_amdgcn_s_memtime() - st_d;
 #endif

@@ -7,6 +7,13 @@
 // allocation (tron_conv_ws_kernel.hpp).
 #include "tron_conv_ws_kernel.hpp"
 
+#ifdef TRON_WS_STAMPS
+extern "C" int tron_conv_ws_pool_stamps(unsigned long long *host_dst)
+{
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_ws_stamps), sizeof(g_ws_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int64_t tron_pooled12_bytes(int64_t batch)
 {
     if (batch < 0 || batch > (1ll << 24)) return 0;
@@ -25,7 +32,7 @@ extern "C" int tron_conv3x3_ws_fwd_pool12(const void *in_px16, const void *wfrag
     if (batch == 0) return TRON_OK;
     if (batch > (1ll << 24)) return TRON_ERR_UNSUPPORTED;
     using G = Geo<12, 12, 64, 64, 1, 8, 1>;
-    constexpr size_t LDS_ALL = G::LDS_BYTES + (G::COUT / 4) * (G::SS * 16 + 16) + 1024;     // + the output image and its dump
+    constexpr size_t LDS_ALL = G::LDS_BYTES + (G::COUT / 4) * (G::SS * 16 + 16) + 1024 + 32;     // + the output image, its dump, the pass counters
     static_assert(LDS_ALL <= 160 * 1024, "LDS");
     auto kern = k_conv_ws<G, true, false, WS_POOL>;
     static uint64_t prepared = 0;

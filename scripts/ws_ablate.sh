@@ -12,6 +12,19 @@ if [ "${1:-}" = flags ]; then      # ws_ablate.sh flags <name> <-D...>: any othe
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o ../../scratch_bin/libtron_ws_$name.so $objs ../../scratch_bin/ws_$name.o && rm ../../scratch_bin/ws_$name.o
   exit 0
 fi
+if [ "${1:-}" = poolstamps ]; then   # the WS_POOL kernel (tron_conv_ws_pool.hip) with stamps: scripts/ws_stamps.py 8192 12 conv6pool
+  objs=$(ls build/*.o | grep -v tron_conv_ws_pool.o)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DTRON_WS_STAMPS -c tron_conv_ws_pool.hip -o ../../scratch_bin/ws_poolstamps.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o ../../scratch_bin/libtron_ws_poolstamps.so $objs ../../scratch_bin/ws_poolstamps.o && rm ../../scratch_bin/ws_poolstamps.o
+  exit 0
+fi
+if [ "${1:-}" = poolflags ]; then    # ws_ablate.sh poolflags <name> <-D...>: a diagnostic build of tron_conv_ws_pool.hip
+  name=$2; shift 2
+  objs=$(ls build/*.o | grep -v tron_conv_ws_pool.o)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC "$@" -c tron_conv_ws_pool.hip -o ../../scratch_bin/wsp_$name.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o ../../scratch_bin/libtron_wsp_$name.so $objs ../../scratch_bin/wsp_$name.o && rm ../../scratch_bin/wsp_$name.o
+  exit 0
+fi
 if [ "${1:-}" = stamps ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DTRON_WS_STAMPS -c tron_conv_ws.hip -o ../../scratch_bin/ws_stamps.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o ../../scratch_bin/libtron_ws_stamps.so $objs ../../scratch_bin/ws_stamps.o && rm ../../scratch_bin/ws_stamps.o
