@@ -319,9 +319,10 @@ class _TrunkHIP(torch.autograd.Function):
         return tuple(grads)
 
 
-def _trunk_px_forward(codes, plane4, w, b, last_f32):
+def _trunk_px_forward(codes, plane4, w, b, last_f32, pooled12=False):
     """conv1 .. conv6 on the weight-stationary chain with the pre-activations kept (csrc/tron_conv_ws_train.hip).  Returns conv6's
-    output (f32 NCHW if last_f32, else PX16) and the tensors the backward needs."""
+    output (f32 NCHW if last_f32, else PX16; pooled12 at 12x12: its AvgPool2d(3, 2, 1) as f32 [B, 64 * 36] instead — conv6 and the
+    pooling are then one launch and conv6's output is never stored) and the tensors the backward needs."""
     from Net import fused
     frag = fused._split_jobs(list(w[1:6]), "tron_conv3x3_ws_split_weights", False)
     a1, z1 = fused.conv1_px16_train(codes, w[0], b[0], plane4)
@@ -329,7 +330,10 @@ def _trunk_px_forward(codes, plane4, w, b, last_f32):
     a3, z3 = fused.conv_ws_train(a2, 32, frag[1], b[2], residual=a1)
     a4, z4 = fused.conv_ws_train(a3, 64, frag[2], b[3])
     a5, z5 = fused.conv_ws_train(a4, 64, frag[3], b[4])
-    out, z6 = fused.conv_ws_train(a5, 64, frag[4], b[5], residual=a4, want_f32=last_f32)
+    if pooled12 and fused.use_pool_fused_train and codes.shape[-1] == 12 and codes.shape[0] > 0 and not last_f32:
+        out, z6 = fused.conv_ws_train_pool12(a5, frag[4], b[5], a4)
+    else:
+        out, z6 = fused.conv_ws_train(a5, 64, frag[4], b[5], residual=a4, want_f32=last_f32)
     return out, (codes, a1.buf, a2.buf, a3.buf, a4.buf, a5.buf, z1.buf, z2.buf, z3.buf, z4.buf, z5.buf, z6.buf)
 
 
@@ -560,14 +564,17 @@ class _BodyPX(torch.autograd.Function):
         from Net import fused
         L = nat.lib()
         w, b = wb[0::2], wb[1::2]
-        a6, saved = _trunk_px_forward(codes, plane4, w, b, False)
+        a6, saved = _trunk_px_forward(codes, plane4, w, b, False, pooled12=True)
         B, S = codes.shape[0], codes.shape[-1]
         dev = codes.device
         st = nat.stream_ptr()
         with torch.cuda.device(dev):
             if S == 12:
-                pooled = torch.empty(B, 64 * 36, dtype=torch.float32, device=dev)
-                nat.check(L.tron_pool12_px16(nat.ptr(a6.buf), nat.ptr(pooled), B, st), "tron_pool12_px16")
+                if torch.is_tensor(a6):                                   # conv6 and the pooling were one launch
+                    pooled = a6
+                else:
+                    pooled = torch.empty(B, 64 * 36, dtype=torch.float32, device=dev)
+                    nat.check(L.tron_pool12_px16(nat.ptr(a6.buf), nat.ptr(pooled), B, st), "tron_pool12_px16")
                 dense = torch.empty(64 * 9, 64 * 36, dtype=torch.float32, device=dev)
                 nat.check(L.tron_conv7_dense(nat.ptr(w[6]), nat.ptr(dense), 64, 64, 0, st), "tron_conv7_dense")
                 pre = fused.gemm_f16x3(pooled, dense, b[6].repeat_interleave(9))

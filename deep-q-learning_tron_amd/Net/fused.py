@@ -261,7 +261,8 @@ def conv_ws(x, conv, wfrag, residual=None, act=True, want_px=True, want_f32=Fals
     return ret[0] if len(ret) == 1 else tuple(ret)
 
 
-use_pool_fused = _os.environ.get("TRON_POOL_FUSED", "1") != "0"      # 12x12: conv6 and the head's pooling as one launch (0: two)
+use_pool_fused = _os.environ.get("TRON_POOL_FUSED", "1") != "0"      # 12x12: conv6 and the pooling as one launch (0: two) — gradient-free forwards
+use_pool_fused_train = use_pool_fused                                  # ... and the learner's forward
 
 
 class Pooled12:
@@ -399,6 +400,22 @@ def conv_ws_train(x, cout, wfrag, bias, residual=None, want_f32=False):
                                                       nat.ptr(None if residual is None else residual.buf), nat.ptr(None if out is None else out.buf),
                                                       nat.ptr(o32), nat.ptr(z.buf), B, cin, cout, S, nat.stream_ptr()), "tron_conv3x3_ws_train_fwd")
     return (o32 if want_f32 else out), z
+
+
+def conv_ws_train_pool12(x, wfrag, bias, residual):
+    """The learner's conv6 + pooling at 12x12 in one launch (tron_conv3x3_ws_train_fwd_pool12): x, residual PX16 [B, 64, 12, 12] ->
+    (AvgPool2d(3, 2, 1)(mish(conv3x3(x) + bias + residual)) as f32 [B, 64 * 36], PX16 pre-activation).  The activation itself is
+    not stored: in the DQN net nothing but the pooling reads it (DQNNet.py:48-52)."""
+    B, cin, S, _ = x.shape
+    if (cin, S) != (64, 12) or residual is None or residual.shape != x.shape:
+        raise TypeError("conv_ws_train_pool12: 64 -> 64 channels at 12x12 with a residual")
+    dev = x.buf.device
+    z = PX16(B, 64, 12, dev)
+    pooled = torch.empty(B, 64 * 36, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().tron_conv3x3_ws_train_fwd_pool12(nat.ptr(x.buf), nat.ptr(wfrag), nat.ptr(bias.detach()), nat.ptr(residual.buf),
+                                                             nat.ptr(z.buf), nat.ptr(pooled), B, nat.stream_ptr()), "tron_conv3x3_ws_train_fwd_pool12")
+    return pooled, z
 
 
 def grad_px_from_f32(g, z):

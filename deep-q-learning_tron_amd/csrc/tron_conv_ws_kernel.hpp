@@ -154,7 +154,10 @@ __device__ unsigned long long g_ws_stamps[256 * 12 * 8];         // [workgroup][
 //             px16_window_sum on the same values, so the result has the bits of the two-kernel path) and stores the
 //             pooled rows the head's conv7 GEMM reads: `out` = hi rows, `pre_px` = lo rows, [B][(octet, pooled pixel, channel)].
 //             Whole 12x12 images per item only (tron_conv_ws_pool.hip).
-enum { WS_INFER = 0, WS_TRAIN = 1, WS_BWD = 2, WS_POOL = 3 };
+//   WS_POOL_TRAIN  WS_TRAIN the same way (the learner's forward, DDQN.py:127: conv6's output feeds nothing but the pooling): the
+//             pre-activation image is written as in WS_TRAIN, the output is pooled in LDS and leaves as the f32 planes
+//             [B][64][6 x 6] of tron_pool12_px16 (`out`), with its bits.
+enum { WS_INFER = 0, WS_TRAIN = 1, WS_BWD = 2, WS_POOL = 3, WS_POOL_TRAIN = 4 };
 // A gradient image's device record: info = {s, 1 / s, -, -, max |g| per channel [<= 64]} (include/tron_hip.h).
 struct WsBwd {
     const unsigned char *zb;     // PX16 pre-activation of the layer below [B][COUT][S][S] (COUT = this launch's output channels)
@@ -177,11 +180,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
     const unsigned char *__restrict__ res, unsigned char *__restrict__ out, float *__restrict__ out_f32,
     float *__restrict__ pre_f32, int B, int apply_mish, int nitems, unsigned char *__restrict__ pre_px, WsBwd bw)
 {
-    constexpr bool TRAIN = MODE == WS_TRAIN, BWD = MODE == WS_BWD, POOL = MODE == WS_POOL;
+    constexpr bool TRAIN = MODE == WS_TRAIN || MODE == WS_POOL_TRAIN, BWD = MODE == WS_BWD, POOL = MODE == WS_POOL || MODE == WS_POOL_TRAIN;
     static_assert(!BWD || G::TPS == 1, "the gradient epilogue is written for one tile per step");
     static_assert(!POOL || (G::S == 12 && G::R == 12 && G::IPI == 1 && G::TPS == 1 && G::COUT == 64 && !F32OUT), "pooled output: whole 12x12 images");
     constexpr int S = G::S, NS = G::NS, NCB = G::NCB, TPS = G::TPS, THREADS = G::THREADS;
-    constexpr int NST = POOL ? 0 : G::NST * (TRAIN ? 2 : 1);             // stores per step: (hi, lo) of the output, and of the pre-activation
+    constexpr int NST = G::NST * ((POOL ? 0 : 1) + (TRAIN ? 1 : 0));     // stores per step: (hi, lo) of the output (not POOL), and of the pre-activation
     // (POOL) the LDS output image behind the sink: quad q of pixel p at O_OFF + q O_QS + 16 p; lanes without a pixel write O_DUMP
     constexpr int O_OFF = G::SINK_OFF + 1024, O_QS = G::SS * 16 + 16, O_DUMP = O_OFF + (G::COUT / 4) * O_QS;
     constexpr int O_FLAG = O_DUMP + 1024;                                // a word per wave: pooling passes it has finished
@@ -479,12 +482,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
             const bool mine = k == 0 || (wave == (G::PG - 1) * G::NCT);
             const int q = u / 36, pq = u - q * 36, py = pq / 6, px = pq - py * 6;
             pbase[k] = O_OFF + q * O_QS + ((2 * py - 1) * S + (2 * px - 1)) * 16;
-            pout[k] = (mine && u >= 0 && u < 16 * 36) ? ((((q >> 1) * 36 + pq) * 16 + (q & 1) * 8) | (py == 0 ? 1 : 0) | (px == 0 ? 2 : 0)) : -1;
+            const int obytes = TRAIN ? (4 * q * 36 + pq) * 4 : ((q >> 1) * 36 + pq) * 16 + (q & 1) * 8;     // f32 planes | split rows
+            pout[k] = (mine && u >= 0 && u < 16 * 36) ? (obytes | (py == 0 ? 1 : 0) | (px == 0 ? 2 : 0)) : -1;
         }
         static_assert(!POOL || (THREADS == 512 && G::NCT == 4 && G::PG == 2), "the units' deal");
     }
     auto pool_pass = [&](int img) {
-        unsigned char *oh = out + (size_t)img * 4608, *ol = pre_px + (size_t)img * 4608;
+        unsigned char *oh = out + (size_t)img * (TRAIN ? 9216 : 4608), *ol = pre_px + (size_t)img * 4608;   // (TRAIN: `out` = f32 [B][64][36])
 #pragma unroll
         for (int k = 0; k < PUNITS; ++k) {
             if (pout[k] < 0) continue;
@@ -497,11 +501,17 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES / 4) void k_conv_ws(
                 const bool pad = (dy == 0 && top) || (dx == 0 && left);
                 acc += *reinterpret_cast<const f32x4 *>(lds + ((dy > 0 && dx > 0) ? b + c : (pad ? 0 : b + c)));
             }
+            if (TRAIN) {                                                 // k_pool12_from_px's planes: the image carries value / 64
+                float *po = reinterpret_cast<float *>(oh + (pout[k] & ~3));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) po[r * 36] = acc[r] * (64.0f / 9.0f);
+                continue;
+            }
             const f32x4 sum = acc * (1.0f / 9.0f);
             const f16x4 hh = __builtin_convertvector(sum, f16x4);
             const f16x4 ll = __builtin_convertvector((sum - __builtin_convertvector(hh, f32x4)) * LO_SCALE, f16x4);
-            *reinterpret_cast<f16x4 *>(oh + (pout[k] & ~7)) = hh;
-            *reinterpret_cast<f16x4 *>(ol + (pout[k] & ~7)) = ll;
+            *reinterpret_cast<f16x4 *>(oh + (pout[k] & ~3)) = hh;
+            *reinterpret_cast<f16x4 *>(ol + (pout[k] & ~3)) = ll;
         }
     };
     int pooled_img = -1;                                                 // (POOL) the image whose output sits in O, waiting for its pass

@@ -118,6 +118,7 @@ SIGNATURES = {
     "tron_dqn_head_fwd_pooled": (C.c_int, [_vp, _i64, _i32] + [_vp] * 10 + [_vp, _vp, _vp, _vp]),
     "tron_pooled12_bytes": (C.c_int64, [_i64]),
     "tron_conv3x3_ws_fwd_pool12": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "tron_conv3x3_ws_train_fwd_pool12": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tron_dqn_head_workspace": (C.c_int64, [_i64, _i32]),
     "tron_pool12": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "tron_pool_s2": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),

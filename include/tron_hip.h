@@ -494,6 +494,11 @@ int tron_dqn_head_fwd_px16(const void *trunk_px16, int64_t batch, int32_t side, 
 int64_t tron_pooled12_bytes(int64_t batch);
 int tron_conv3x3_ws_fwd_pool12(const void *in_px16, const void *wfrag, const float *bias, const void *res_px16,
                                void *pooled, int64_t batch, void *stream);
+/* The learner's forward of the same layer pair (DDQN.py:127): conv6's pre-activation is kept as the PX16 image pre_px16
+ * (as tron_conv3x3_ws_train_fwd keeps it), the pooled output leaves as f32 planes pooled_f32 [batch][64][6][6] with the bits
+ * tron_pool12_px16 gives on conv6's PX16 output; that output itself — read by nothing but the pooling — is not stored. */
+int tron_conv3x3_ws_train_fwd_pool12(const void *in_px16, const void *wfrag, const float *bias, const void *res_px16,
+                                     void *pre_px16, float *pooled_f32, int64_t batch, void *stream);
 int tron_dqn_head_fwd_pooled(const void *pooled, int64_t batch, int32_t side, const float *conv7_w,
                              const float *conv7_b, const float *fc1_w, const float *fc1_b, const float *fc2_w,
                              const float *fc2_b, const float *actor1_w, const float *actor1_b, const float *actor2_w,

@@ -313,3 +313,49 @@ def test_trunk_px_is_the_path_the_learner_takes(fused):
         names.add(type(f).__name__)
         stack += [n for n, _ in f.next_functions]
     assert "_BodyPXBackward" in names, names
+
+
+@pytest.mark.parametrize("B", [1, 255, 257, 1000, 4096])
+def test_training_conv6_with_the_pooling_in_one_launch(fused, B):
+    """tron_conv3x3_ws_train_fwd_pool12 (the learner's conv6 + AvgPool2d(3, 2, 1), DQNNet.py:48-52, conv6's output left in LDS)
+    against tron_conv3x3_ws_train_fwd followed by tron_pool12_px16: the pooled planes and the pre-activation image bit for bit."""
+    from tron import _native as nat
+    torch.manual_seed(B)
+    x = _to_px(fused, torch.randn(B, 64, 12, 12, device="cuda") * 1.5)
+    r = _to_px(fused, torch.randn(B, 64, 12, 12, device="cuda"))
+    w = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
+    bias = torch.randn(64, device="cuda") * 0.1
+    frag = fused._split_jobs([w], "tron_conv3x3_ws_split_weights", False)[0]
+    pooled, z = fused.conv_ws_train_pool12(x, frag, bias, r)
+    a6, z2 = fused.conv_ws_train(x, 64, frag, bias, residual=r)
+    ref = torch.empty(B, 64 * 36, dtype=torch.float32, device="cuda")
+    nat.check(nat.lib().tron_pool12_px16(nat.ptr(a6.buf), nat.ptr(ref), B, nat.stream_ptr()), "tron_pool12_px16")
+    assert torch.equal(z.buf, z2.buf)
+    assert torch.equal(pooled, ref)
+    want = torch.nn.functional.avg_pool2d(a6.float().double(), 3, stride=2, padding=1).reshape(B, -1)
+    assert (pooled.double() - want).abs().max().item() < 1e-5
+
+
+def test_learner_body_pools_inside_conv6(fused, monkeypatch):
+    """`_BodyPX` at 12x12 takes the one-launch conv6 + pooling; with two launches (TRON_POOL_FUSED=0) the output and every
+    gradient have the same bits."""
+    from Net.DQNNet import Net
+    torch.manual_seed(5)
+    net = Net(3, 10).cuda()
+    net.dropout.p = 0.0
+    codes = _codes(300, 12, 9)
+    up = torch.randn(300, 4, device="cuda")
+    calls = []
+    real = fused.conv_ws_train_pool12
+    monkeypatch.setattr(fused, "conv_ws_train_pool12", lambda *a: (calls.append(1), real(*a))[1])
+    q = net.forward_codes(codes)
+    (q * up).sum().backward()
+    assert len(calls) == 1
+    grads = [p.grad.clone() for p in net.parameters()]
+    monkeypatch.setattr(fused, "use_pool_fused_train", False)
+    net.zero_grad(set_to_none=True)
+    q2 = net.forward_codes(codes)
+    (q2 * up).sum().backward()
+    assert len(calls) == 1 and torch.equal(q, q2)
+    for (n, p), g in zip(net.named_parameters(), grads):
+        assert torch.equal(p.grad, g), n
