@@ -42,7 +42,7 @@ for key, v in rows.items():
         if m:
             S, R, ci, co, ipi, waves, tps, res, f32o = map(int, m.groups()[:9])
             mode = int(m.group(10) or 0)                                 # 0: gradient-free chain, 1: training forward (+ z), 2: input gradient
-            row["shape"] = (("ws", "ws train", "ws dgrad", "ws +pool")[mode] + f" {ci}->{co} {S}x{S}" + (" +res" if res else "") + (" +f32" if f32o else ""))
+            row["shape"] = (("ws", "ws train", "ws dgrad", "ws +pool", "ws train +pool")[mode] + f" {ci}->{co} {S}x{S}" + (" +res" if res else "") + (" +f32" if f32o else ""))
             if a.batch:
                 row["flops"] = 2.0 * a.batch * S * S * 9 * ci * co
                 row["tflops_f32_equivalent"] = row["flops"] / row["avg_us"] / 1e6
