@@ -662,6 +662,164 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_f16x3(const f16 *__restri
     }
 }
 
+
+// ---- the same product on a 128 x 192 tile (N % 192 == 0: conv7's dense form, N = 576) --------------------------------------
+// k_gemm_f16x3's 128 x 64 tile pulls (128 + 64) rows of K through L2 -> LDS per 128 x 64 outputs; this one (128 + 192) rows per
+// 128 x 192: 1.8x less feed per output, and a wave's A fragments serve six column tiles instead of two (LDS reads per MFMA 0.44
+// against 0.67).  8 waves = 4 (rows) x 2 (columns), a wave 32 x 96 outputs = 2 x 6 MFMA tiles, 96 accumulator registers.
+// splitk > 1: slice blockIdx.y of the K chunks, raw sums to partial[slice][M][N] (k_gemm_finish adds them in slice order).
+constexpr int WN = 192, WW_HALF = WN * GPITCH;
+constexpr int GW_LDS = 2 * A_HALF + 2 * WW_HALF;    // 102 400 bytes
+__global__ __launch_bounds__(G_THREADS, 2) void k_gemm_wide(const f16 *__restrict__ Ah, const f16 *__restrict__ Al,
+                                                            const f16 *__restrict__ Wh, const f16 *__restrict__ Wl,
+                                                            const float *__restrict__ bias, int bias_div, int M, int N, int K, int act,
+                                                            float *__restrict__ out_f32, f16 *__restrict__ out_h, f16 *__restrict__ out_l,
+                                                            const float *__restrict__ a_scale, int splitk, float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *a_h = lds, *a_l = lds + A_HALF, *w_h = lds + 2 * A_HALF, *w_l = w_h + WW_HALF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 3, wn = wave >> 2, li = lane & 15, g = lane >> 4;
+    const int nblocks = N / WN;
+    const int m0 = (blockIdx.x / nblocks) * GM, n0 = (blockIdx.x % nblocks) * WN;
+
+    f32x4 ra[4], rw[6];
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                    // A: [2 halves][128 rows][8 pieces]
+            const int q = tid + j * G_THREADS, half = q >> 10, r = q & 1023, row = r >> 3, pc = r & 7;
+            int m = m0 + row;
+            m = m < M ? m : M - 1;
+            ra[j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(half ? Al : Ah) + ((size_t)m * K + (size_t)kc * GK) * 2 + pc * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {                                    // W: [2 halves][192 rows][8 pieces]
+            const int q = tid + j * G_THREADS, half = q >= 1536 ? 1 : 0, r = q - half * 1536, row = r >> 3, pc = r & 7;
+            rw[j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(half ? Wl : Wh) + ((size_t)(n0 + row) * K + (size_t)kc * GK) * 2 + pc * 16);
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = tid + j * G_THREADS, half = q >> 10, r = q & 1023, row = r >> 3, pc = r & 7;
+            *reinterpret_cast<f32x4 *>(lds + half * A_HALF + row * GPITCH + pc * 16) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int q = tid + j * G_THREADS, half = q >= 1536 ? 1 : 0, r = q - half * 1536, row = r >> 3, pc = r & 7;
+            *reinterpret_cast<f32x4 *>(lds + 2 * A_HALF + half * WW_HALF + row * GPITCH + pc * 16) = rw[j];
+        }
+    };
+
+    f32x4 acc0[2][6], acc1[2][6];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            acc0[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc1[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    const int a_off = (wm * 32 + li) * GPITCH + g * 16, b_off = (wn * 96 + li) * GPITCH + g * 16;
+    const int nk_all = K / GK, per = (nk_all + splitk - 1) / splitk;
+    const int kb = (int)blockIdx.y * per, nk = kb + per < nk_all ? kb + per : nk_all;
+    if (kb < nk) {
+        load_chunk(kb);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int kc = kb; kc < nk; ++kc) {
+        if (kc + 1 < nk) load_chunk(kc + 1);                            // in flight under the MFMAs
+#pragma unroll
+        for (int s = 0; s < GK / 32; ++s) {
+            f16x8 ah[2], al[2], bh[6], bl[6];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const f16x8 *>(a_h + a_off + t * 16 * GPITCH + s * 64);
+                al[t] = *reinterpret_cast<const f16x8 *>(a_l + a_off + t * 16 * GPITCH + s * 64);
+            }
+#pragma unroll
+            for (int n = 0; n < 6; ++n) {
+                bh[n] = *reinterpret_cast<const f16x8 *>(w_h + b_off + n * 16 * GPITCH + s * 64);
+                bl[n] = *reinterpret_cast<const f16x8 *>(w_l + b_off + n * 16 * GPITCH + s * 64);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 6; ++n) acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc1[t][n], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 6; ++n) acc0[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc0[t][n], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < 6; ++n) acc1[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc1[t][n], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kc + 1 < nk) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+    const float out_scale = a_scale ? ACT_UNSCALE / *a_scale : ACT_UNSCALE;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        const int col = n0 + wn * 96 + n * 16 + li;
+        const float bv = bias ? bias[col / bias_div] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 raw = acc0[t][n] + acc1[t][n] * LO_UNSCALE;
+            const f32x4 v = raw * out_scale + bv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + t * 16 + 4 * g + r;
+                if (m >= M) continue;
+                if (partial) {
+                    partial[((size_t)blockIdx.y * M + m) * N + col] = raw[r];
+                    continue;
+                }
+                const float y = act ? mish1(v[r]) : v[r];
+                if (out_f32) out_f32[(size_t)m * N + col] = y;
+                if (out_h) {
+                    f16 hh, ll;
+                    split(y * ACT_SCALE, hh, ll);
+                    out_h[(size_t)m * N + col] = hh;
+                    out_l[(size_t)m * N + col] = ll;
+                }
+            }
+        }
+    }
+}
+
+// the K slices of k_gemm_wide added in slice order, then its epilogue; four columns per thread
+__global__ void k_gemm_finish(const float *__restrict__ partial, int splitk, int64_t M, int N, const float *__restrict__ bias,
+                              int bias_div, int act, const float *__restrict__ a_scale, float *__restrict__ out_f32,
+                              f16 *__restrict__ out_h, f16 *__restrict__ out_l)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4, total = M * N;
+    if (i >= total) return;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(partial + i);
+    for (int s = 1; s < splitk; ++s) v += *reinterpret_cast<const f32x4 *>(partial + (size_t)s * total + i);
+    const float out_scale = a_scale ? ACT_UNSCALE / *a_scale : ACT_UNSCALE;
+    const int col = (int)(i % N);
+    f32x4 y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float x = v[r] * out_scale + (bias ? bias[(col + r) / bias_div] : 0.0f);
+        y[r] = act ? mish1(x) : x;
+    }
+    if (out_f32) *reinterpret_cast<f32x4 *>(out_f32 + i) = y;
+    if (out_h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            f16 hh, ll;
+            split(y[r] * ACT_SCALE, hh, ll);
+            out_h[i + r] = hh;
+            out_l[i + r] = ll;
+        }
+    }
+}
+
 // actor2: q[b][a] = x[b] . w[a] + bias[a] in f32 (64 x 4 MACs per sample), and the greedy action
 __global__ void k_q_head(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, int B,
                          int K, float *__restrict__ q, int8_t *__restrict__ greedy)
@@ -692,8 +850,27 @@ __global__ void k_q_head(const float *__restrict__ x, const float *__restrict__ 
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
+// Which launches take k_gemm_wide, and in how many K slices (0: k_gemm_f16x3).  Measured (profiles/r04_head_gemm_wide.txt): the wide
+// tile wins where K is long — conv7's dense forward (K = 2 304: 89 -> 75 us at 4 096 rows, 150 -> 121 at 8 192, 1 035 -> 804 at
+// 65 536) and its weight gradient (K = the batch: 99 -> 80 us) — and loses at K = 576 (conv7's input gradient: 68 -> 74 us).
+// Few tiles are cut along K so that most of the 256 CUs have one: the slices' raw sums go through `partial` and k_gemm_finish.
+inline int wide_splitk(int64_t M, int N, int K)
+{
+    if (N % WN != 0 || K % GK != 0 || K < 1024 || M >= (1ll << 31)) return 0;
+    const int64_t tiles = ((M + GM - 1) / GM) * (N / WN);
+    const int nk = K / GK;
+    if (tiles < 32) return 0;
+    return (tiles < 80 && nk >= 16) ? 4 : ((tiles < 160 && nk >= 8) ? 2 : 1);
+}
+inline int64_t wide_partial_bytes(int64_t M, int N, int K)
+{
+    const int s = wide_splitk(M, N, K);
+    return s > 1 ? align256((int64_t)s * M * N * 4) : 0;
+}
+
+
 struct HeadPlan {                      // byte offsets into the workspace
-    int64_t a7h, a7l, d7h, d7l, c7h, c7l, w1h, w1l, c1h, c1l, w2h, w2l, c2h, c2l, w3h, w3l, c3, total;
+    int64_t a7h, a7l, d7h, d7l, c7h, c7l, w1h, w1l, c1h, c1l, w2h, w2l, c2h, c2l, w3h, w3l, c3, part, total;
 };
 HeadPlan plan(int64_t B, int K7, int N7, int64_t a7_per_image = 0, int d7_rows = 0)
 {
@@ -709,13 +886,15 @@ HeadPlan plan(int64_t B, int K7, int N7, int64_t a7_per_image = 0, int d7_rows =
     p.c2h = take(B * 128 * 2); p.c2l = take(B * 128 * 2);
     p.w3h = take(64 * 128 * 2); p.w3l = take(64 * 128 * 2);
     p.c3 = take(B * 64 * 4);
+    p.part = take(a7_per_image ? 0 : wide_partial_bytes(B, N7, K7));     // (conv7's dense form: the K slices of k_gemm_wide)
     p.total = o;
     return p;
 }
 
 template <int MODE, int PS = 13>
 int gemm(const f16 *Ah, const f16 *Al, const f16 *Wh, const f16 *Wl, const float *bias, int bias_div, int64_t M, int N, int K,
-         int act, float *out_f32, f16 *out_h, f16 *out_l, hipStream_t st, const float *a_scale = nullptr, int cls = 0)
+         int act, float *out_f32, f16 *out_h, f16 *out_l, hipStream_t st, const float *a_scale = nullptr, int cls = 0,
+         float *partial_ws = nullptr)
 {
     static uint64_t prepared = 0;
     int dev = 0;
@@ -728,6 +907,24 @@ int gemm(const f16 *Ah, const f16 *Al, const f16 *Wh, const f16 *Wl, const float
     }
     if (M >= (1ll << 31) || N % GN != 0 || K % GK != 0) return TRON_ERR_UNSUPPORTED;
     if (M == 0) return TRON_OK;
+    if (MODE == G_PLAIN) {
+        const int splitk = wide_splitk(M, N, K);
+        if (splitk == 1 || (splitk > 1 && partial_ws)) {
+            static uint64_t prepared_wide = 0;
+            if (!(prepared_wide & (1ull << (dev & 63)))) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_wide), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS) != hipSuccess)
+                    (void)hipGetLastError();
+                prepared_wide |= 1ull << (dev & 63);
+            }
+            const int64_t tiles = ((M + GM - 1) / GM) * (N / WN);
+            hipLaunchKernelGGL(k_gemm_wide, dim3((unsigned)tiles, splitk), dim3(G_THREADS), GW_LDS, st, Ah, Al, Wh, Wl, bias, bias_div, (int)M, N, K, act,
+                               out_f32, out_h, out_l, a_scale, splitk, splitk > 1 ? partial_ws : nullptr);
+            if (splitk > 1)
+                hipLaunchKernelGGL(k_gemm_finish, dim3((unsigned)((M * N / 4 + 255) / 256)), dim3(256), 0, st, partial_ws, splitk, M, N, bias, bias_div,
+                                   act, a_scale, out_f32, out_h, out_l);
+            return hipGetLastError() == hipSuccess ? TRON_OK : TRON_ERR_LAUNCH;
+        }
+    }
     const int64_t blocks = ((M + GM - 1) / GM) * (N / GN);
     hipLaunchKernelGGL((k_gemm_f16x3<MODE, PS>), dim3((unsigned)blocks), dim3(G_THREADS), G_LDS, st, Ah, Al, Wh, Wl, bias, bias_div,
                        (int)M, N, K, act, out_f32, out_h, out_l, a_scale, cls);
@@ -1192,7 +1389,7 @@ extern "C" int64_t tron_gemm_f16x3_workspace(int64_t M, int32_t N, int64_t K)
 {
     if (M < 1 || N < 1 || K < 1 || N % 64 != 0 || M >= (1ll << 31) || K >= (1ll << 31)) return 0;
     const int64_t kpad = (K + 63) / 64 * 64;
-    return 2 * align256(M * kpad * 2) + 2 * align256((int64_t)N * kpad * 2) + 256;
+    return 2 * align256(M * kpad * 2) + 2 * align256((int64_t)N * kpad * 2) + wide_partial_bytes(M, N, kpad) + 256;
 }
 
 extern "C" int tron_gemm_f16x3(const float *A, int32_t a_transposed, const float *B, int32_t b_transposed, const float *bias,
@@ -1221,7 +1418,8 @@ extern "C" int tron_gemm_f16x3(const float *A, int32_t a_transposed, const float
     else
         hipLaunchKernelGGL(k_split_scaled, dim3(blocks_for((int64_t)N * K)), dim3(256), 0, st, B, (int64_t)N * K, (const float *)nullptr, 1.0f, bh, bl);
     if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
-    return gemm<G_PLAIN>(ah, al, bh, bl, bias, 1, M, N, (int)kpad, 0, C, nullptr, nullptr, st, a_scale);
+    return gemm<G_PLAIN>(ah, al, bh, bl, bias, 1, M, N, (int)kpad, 0, C, nullptr, nullptr, st, a_scale, 0,
+                         reinterpret_cast<float *>(ws + 2 * abytes + 2 * bbytes));
 }
 
 
@@ -1286,7 +1484,8 @@ static int head_fwd(const void *trunk, int src, int64_t batch, int32_t side, con
                          0, px16 ? 1 : 0, 256 * N7};
     hipLaunchKernelGGL(k_head_weights, dim3(1024, 4), dim3(256), 0, st, hw);
     if (hipGetLastError() != hipSuccess) return TRON_ERR_LAUNCH;
-    int rc = gemm<G_PLAIN>(a7h, a7l, H(p.d7h), H(p.d7l), conv7_b, OS * OS, batch, N7, K7, 1, nullptr, H(p.c7h), H(p.c7l), st);
+    int rc = gemm<G_PLAIN>(a7h, a7l, H(p.d7h), H(p.d7l), conv7_b, OS * OS, batch, N7, K7, 1, nullptr, H(p.c7h), H(p.c7l), st, nullptr, 0,
+                           reinterpret_cast<float *>(ws + p.part));
     if (rc == TRON_OK) rc = gemm<G_PLAIN>(H(p.c7h), H(p.c7l), H(p.w1h), H(p.w1l), fc1_b, 1, batch, 256, N7, 1, nullptr, H(p.c1h), H(p.c1l), st);
     if (rc == TRON_OK) rc = gemm<G_PLAIN>(H(p.c1h), H(p.c1l), H(p.w2h), H(p.w2l), fc2_b, 1, batch, 128, 256, 1, nullptr, H(p.c2h), H(p.c2l), st);
     float *c3 = reinterpret_cast<float *>(ws + p.c3);
