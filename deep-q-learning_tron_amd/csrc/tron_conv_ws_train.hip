@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void k_wsb_finish(const float *__restrict__ st
 // f32 gradient planes of the trunk's output are never written: 1 = pooled planes f32 [B][C][PS*PS] (12x12: the dense conv7 path),
 // 2 = channels-last f32 [B][PS*PS][C] (26x26: the DGRAD7 GEMMs' output).  scale4[0] must then bring (4/9) max |pooled g| * 1.1
 // below 2^15: tron_absmax_pow2(pooled g, 15).
+constexpr int GOUT_TILE = 16 * 36 * 8;                                   // floats: 16 images of 6x6 (or one of up to 24x24: 13x13 here)
+__host__ __device__ inline int gout_images(int S) { return S <= 12 ? 16 : 1; }   // (26x26: 676 pixels fill the threads; four at a time measured 6 % slower)
 template <int SRC>
 __global__ __launch_bounds__(256) void k_gout_px(const float *__restrict__ gout, const unsigned char *__restrict__ z, int64_t B, int C,
                                                  int S, const float *__restrict__ scale4, unsigned char *__restrict__ out,
@@ -88,30 +90,37 @@ __global__ __launch_bounds__(256) void k_gout_px(const float *__restrict__ gout,
 {
     const int SS = S * S, PS = S / 2, PP = PS * PS;
     __shared__ float red[256 * 9];
-    __shared__ __attribute__((aligned(16))) float tile[SRC ? 172 * 8 : 8];   // (SRC 1 / 2) the pooled gradient of one image's octet: [pooled pixel][8 channels]
+    // (SRC 1 / 2) the pooled gradients of NI images' octet: [image][pooled pixel][8 channels].  NI images are walked as one index
+    // space (image, pixel): a 12x12 image alone keeps 144 of the 256 threads busy and costs two barriers — 124 us at 4 096 images,
+    // 86 us with 16 at a time (profiles/r04_gout_px.txt)
+    __shared__ __attribute__((aligned(16))) float tile[SRC ? GOUT_TILE : 8];
+    const int NI = SRC ? gout_images(S) : 1;
     const int oct = blockIdx.y, groups = gridDim.x, grp = blockIdx.x;
     const float s = scale4[0];
     if (grp == 0 && oct == 0 && threadIdx.x == 0) { info[0] = s; info[1] = 1.0f / s; }
     const size_t half = (size_t)(C / 8) * SS * 16;
     float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mx = 0.0f;
-    for (int64_t img = grp; img < B; img += groups) {                    // this block's images: grp, grp + groups, ...
+    for (int64_t img0 = (int64_t)grp * NI; img0 < B; img0 += (int64_t)groups * NI) {   // this block's images, NI at a time
+        const int ni = B - img0 < NI ? (int)(B - img0) : NI;
         if (SRC) {
-            __syncthreads();                                             // (the previous image's tile is no longer read)
+            __syncthreads();                                             // (the previous images' tiles are no longer read)
             if (SRC == 1) {
-                for (int i = threadIdx.x; i < 8 * PP; i += 256) {        // planes [B][C][PP]: the octet's 8 planes are contiguous
-                    const int j = i / PP, pp = i - j * PP;
-                    tile[pp * 8 + j] = gout[((size_t)img * C + oct * 8) * PP + i];
+                for (int i = threadIdx.x; i < ni * 8 * PP; i += 256) {   // planes [B][C][PP]: the octet's 8 planes are contiguous
+                    const int il = i / (8 * PP), r = i - il * 8 * PP, j = r / PP, pp = r - j * PP;
+                    tile[(il * PP + pp) * 8 + j] = gout[((size_t)(img0 + il) * C + oct * 8) * PP + r];
                 }
             } else {
-                for (int i = threadIdx.x; i < 2 * PP; i += 256) {        // channels-last [B][PP][C]: 8 consecutive floats per pooled pixel
-                    const int pp = i >> 1, q = i & 1;
-                    *reinterpret_cast<f32x4 *>(tile + pp * 8 + 4 * q) =
-                        *reinterpret_cast<const f32x4 *>(gout + ((size_t)img * PP + pp) * C + oct * 8 + 4 * q);
+                for (int i = threadIdx.x; i < ni * 2 * PP; i += 256) {   // channels-last [B][PP][C]: 8 consecutive floats per pooled pixel
+                    const int il = i / (2 * PP), r = i - il * 2 * PP, pp = r >> 1, q = r & 1;
+                    *reinterpret_cast<f32x4 *>(tile + (il * PP + pp) * 8 + 4 * q) =
+                        *reinterpret_cast<const f32x4 *>(gout + ((size_t)(img0 + il) * PP + pp) * C + oct * 8 + 4 * q);
                 }
             }
             __syncthreads();
         }
-        for (int p = threadIdx.x; p < SS; p += 256) {
+        for (int ip = threadIdx.x; ip < ni * SS; ip += 256) {
+            const int il = ip / SS, p = ip - il * SS;
+            const int64_t img = img0 + il;
             const unsigned char *zp = z + (size_t)img * 2 * half + ((size_t)oct * SS + p) * 16;
             const f16x8 zh = *reinterpret_cast<const f16x8 *>(zp), zl = *reinterpret_cast<const f16x8 *>(zp + half);
             float gg[8];
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256) void k_gout_px(const float *__restrict__ gout,
                 const int y = p / S, x = p - y * S;
                 const int py0 = y >> 1, px0 = x >> 1;
                 const bool two_y = (y & 1) && py0 + 1 < PS, two_x = (x & 1) && px0 + 1 < PS;
-                const float *t00 = tile + (py0 * PS + px0) * 8;
+                const float *t00 = tile + (il * PP + py0 * PS + px0) * 8;
                 const float wx = two_x ? 1.0f : 0.0f, wy = two_y ? 1.0f : 0.0f;
                 const float *t01 = two_x ? t00 + 8 : t00, *t10 = two_y ? t00 + PS * 8 : t00, *t11 = (two_x && two_y) ? t00 + PS * 8 + 8 : t00;
 #pragma unroll
@@ -837,10 +846,11 @@ extern "C" int tron_px16_grad_from_pooled(const float *grad_pooled, int32_t chan
     if ((reinterpret_cast<uintptr_t>(pre_px16) | reinterpret_cast<uintptr_t>(grad_px16) | reinterpret_cast<uintptr_t>(workspace) |
          reinterpret_cast<uintptr_t>(grad_pooled)) & 15u)
         return TRON_ERR_BAD_ARG;
-    if ((side / 2) * (side / 2) > 172) return TRON_ERR_UNSUPPORTED;      // (the kernel's LDS tile: pooled planes up to 13 x 13)
+    if (gout_images(side) * (side / 2) * (side / 2) * 8 > GOUT_TILE) return TRON_ERR_UNSUPPORTED;      // (the kernel's LDS tile: pooled planes up to 13 x 13)
     if (batch == 0) return TRON_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int groups = (int)(batch < 1024 ? batch : 1024);
+    const int64_t batches = (batch + gout_images(side) - 1) / gout_images(side);
+    int groups = (int)(batches < 1024 ? batches : 1024);
     float *stats = reinterpret_cast<float *>(workspace);
     const dim3 grid((unsigned)groups, (unsigned)(channels / 8));
     if (channels_last)

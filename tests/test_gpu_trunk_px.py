@@ -97,14 +97,14 @@ def test_conv1_training_forward(fused, S, cin):
     assert torch.equal(a.buf, fused.conv1_px16(codes, conv, 5.0).buf)
 
 
-@pytest.mark.parametrize("S,mag", [(12, 1.0), (26, 1e-6), (26, 1.0)])
-def test_gradient_image_entry_from_the_pooled_gradient(fused, S, mag):
+@pytest.mark.parametrize("S,mag,B", [(12, 1.0, 19), (26, 1e-6, 19), (26, 1.0, 19), (12, 1.0, 16 * 1024 + 21), (26, 1.0, 4 * 1024 + 5)])
+def test_gradient_image_entry_from_the_pooled_gradient(fused, S, mag, B):
     """tron_px16_grad_from_pooled: AvgPool2d(3, 2, 1)'s backward + mish'(z) + bias sums in one pass, from pooled planes (12x12) and
     from the channels-last pooled gradient (26x26), against float64 autograd of mish -> avg_pool."""
     from tron import _native as nat
     L = nat.lib()
     torch.manual_seed(S)
-    B, C, PS = 19, 64, S // 2
+    C, PS = 64, S // 2                                # (the kernel walks 16 / 4 images at a time, <= 1024 workgroups per octet: ragged and looping batches)
     z = torch.randn(B, C, S, S, device="cuda") * 2.5
     gpool = torch.randn(B, C, PS, PS, device="cuda") * mag
     zd = z.double().requires_grad_(True)
