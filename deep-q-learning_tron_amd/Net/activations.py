@@ -970,6 +970,12 @@ class _LinearHIP(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             B, O, I = x.shape[0], weight.shape[0], weight.shape[1]
             L = nat.lib()
+            from Net import fused
+            if O * I >= _LIN_WGRAD_GEMM and fused.use_gemm:              # (as `_TailMLP`: large layers on the split-f16 GEMM)
+                from Net.kfac import _pow2_scale
+                gw = fused.gemm_f16x3(gy, x, a_transposed=True, b_transposed=True, a_scale=_pow2_scale(gy))
+                if gw is not None:
+                    return gx, gw, (gy.sum(0) if ctx.has_bias else None)
             gw = torch.empty_like(weight)
             gb = torch.empty(O, dtype=torch.float32, device=x.device) if ctx.has_bias else None
             ws = torch.empty(max(16, int(L.tron_linear_wgrad_workspace(B, O, I))), dtype=torch.uint8, device=x.device)
@@ -981,6 +987,9 @@ class _LinearHIP(torch.autograd.Function):
 
 import os as _os
 _use_linear_hip = _os.environ.get("TRON_LINEAR_HIP", "1") != "0"           # 0: the library's weight-gradient GEMMs (A/B measurements)
+# tron_linear_wgrad is plain f32 FMAs on 64 x 64 tiles: right for the head's small layers (<= 150 K outputs), 239 us for fc1 behind
+# 24x24 boards (256 x 3136 outputs over a batch of 4 096: 6.6 GFLOP) — from this many outputs on the weight gradient is tron_gemm_f16x3
+_LIN_WGRAD_GEMM = int(_os.environ.get("TRON_LIN_WGRAD_GEMM", str(1 << 19)))
 
 
 def linear(layer, x):
@@ -1028,6 +1037,7 @@ class _TailMLP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gq):
         from tron import _native as nat
+        from Net import fused
         L = nat.lib()
         x, y1, d1, y2, d2, y3, a3, w1, w2, w3, w4, *masks = ctx.saved_tensors
         dev = x.device
@@ -1037,6 +1047,11 @@ class _TailMLP(torch.autograd.Function):
 
         def wgrad(gy, inp, w):
             O, I = w.shape
+            if O * I >= _LIN_WGRAD_GEMM and fused.use_gemm:    # fc1 behind 24x24 boards (256 x 3136): the split-f16 GEMM, the bias sum apart
+                from Net.kfac import _pow2_scale
+                gw = fused.gemm_f16x3(gy, inp, a_transposed=True, b_transposed=True, a_scale=_pow2_scale(gy))
+                if gw is not None:
+                    return gw, gy.sum(0)
             gw, gb = torch.empty_like(w), torch.empty(O, dtype=torch.float32, device=dev)
             ws = torch.empty(max(16, int(L.tron_linear_wgrad_workspace(B, O, I))), dtype=torch.uint8, device=dev)
             nat.check(L.tron_linear_wgrad(nat.ptr(gy), nat.ptr(inp), B, O, I, nat.ptr(gw), nat.ptr(gb), nat.ptr(ws), nat.stream_ptr()), "tron_linear_wgrad")
