@@ -382,16 +382,20 @@ __global__ __launch_bounds__(256) void k_pool12_from_px(const unsigned char *__r
     }
 }
 
-// 26x26: the channels-last split image [B][13][13][64] (what k_pool_split_cl<26> writes).  One thread = one pooled pixel x one
-// channel octet: a 16-byte store per half.
-__global__ __launch_bounds__(256) void k_pool_split26_px(const unsigned char *__restrict__ x, int64_t B, f16 *__restrict__ oh,
-                                                         f16 *__restrict__ ol)
+// 26x26: the channels-last split image [B][13][13][64] (what k_pool_split_cl<26> writes).  A workgroup = 64 pooled pixels x 8
+// octets, a WAVE = one octet: a wave's loads of one tap sit 32 bytes apart in ONE octet plane (whole cache lines over a row's three
+// taps) — with a thread = (pooled pixel, octet) and the octet fastest they were 16 bytes in each of eight planes, re-fetched from L2
+// tap after tap (252 us at 4 096 images; this: 222).  The 16-byte results go through LDS so that the stores are the pixels'
+// contiguous 128 bytes (a thread walking the eight octets itself, storing 16 bytes at a 128-byte stride, was slower than either).
+__global__ __launch_bounds__(512) void k_pool_split26_px(const unsigned char *__restrict__ x, int64_t B, f16 *__restrict__ oh,
+                                                           f16 *__restrict__ ol)
 {
-    constexpr int S = 26, PS = 13, C = 64, HALF = (C / 8) * S * S * 16;
-    const int64_t total = B * PS * PS * 8;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int oct = (int)(i & 7);
-        const int64_t pix = i >> 3, b = pix / (PS * PS);
+    constexpr int S = 26, PS = 13, C = 64, HALF = (C / 8) * S * S * 16, ROW = 144;
+    __shared__ __attribute__((aligned(16))) unsigned char th[64 * ROW], tl[64 * ROW];
+    const int lane = threadIdx.x & 63, oct = threadIdx.x >> 6;
+    const int64_t total = B * PS * PS, pix0 = (int64_t)blockIdx.x * 64, pix = pix0 + lane;
+    if (pix < total) {
+        const int64_t b = pix / (PS * PS);
         const int r = (int)(pix - b * (PS * PS)), py = r / PS, px = r % PS;
         float sum[8];
         px16_window_sum(x + (size_t)b * 2 * HALF, S, HALF, oct, py, px, sum);
@@ -403,8 +407,14 @@ __global__ __launch_bounds__(256) void k_pool_split26_px(const unsigned char *__
             h[j] = hh;
             l[j] = ll;
         }
-        *reinterpret_cast<f16x8h *>(oh + (size_t)pix * C + oct * 8) = h;
-        *reinterpret_cast<f16x8h *>(ol + (size_t)pix * C + oct * 8) = l;
+        *reinterpret_cast<f16x8h *>(th + lane * ROW + oct * 16) = h;
+        *reinterpret_cast<f16x8h *>(tl + lane * ROW + oct * 16) = l;
+    }
+    __syncthreads();
+    const int p = threadIdx.x >> 3, part = threadIdx.x & 7;
+    if (pix0 + p < total) {
+        *reinterpret_cast<f16x8h *>(oh + (size_t)(pix0 + p) * C + part * 8) = *reinterpret_cast<const f16x8h *>(th + p * ROW + part * 16);
+        *reinterpret_cast<f16x8h *>(ol + (size_t)(pix0 + p) * C + part * 8) = *reinterpret_cast<const f16x8h *>(tl + p * ROW + part * 16);
     }
 }
 
@@ -1452,7 +1462,7 @@ static int head_fwd(const void *trunk, int src, int64_t batch, int32_t side, con
         const HeadPlan p = plan(batch, K7, N1, (int64_t)P7_PIX * 64, 64);
         unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
         auto H = [&](int64_t off) { return reinterpret_cast<f16 *>(ws + off); };
-        if (px16) hipLaunchKernelGGL(k_pool_split26_px, dim3((unsigned)((batch * 169 * 8 + 255) / 256 < (1 << 20) ? (batch * 169 * 8 + 255) / 256 : (1 << 20))), dim3(256), 0, st, trunk_px, batch, H(p.a7h), H(p.a7l));
+        if (px16) hipLaunchKernelGGL(k_pool_split26_px, dim3((unsigned)((batch * 169 + 63) / 64)), dim3(512), 0, st, trunk_px, batch, H(p.a7h), H(p.a7l));
         else hipLaunchKernelGGL(k_pool_split_cl<26>, dim3((unsigned)(batch * 13)), dim3(256), 0, st, trunk_out, H(p.a7h), H(p.a7l));
         const HeadWeights hw{conv7_w, fc1_w, fc2_w, actor1_w, H(p.d7h), H(p.d7l), H(p.w1h), H(p.w1l), H(p.w2h), H(p.w2l), H(p.w3h), H(p.w3l),
                              1, 0, 256 * N1};
@@ -1564,7 +1574,7 @@ int p7_fwd(const float *x, int64_t B, const float *w, const float *bias, void *s
         pre = reinterpret_cast<float *>(ws + p.pre);
         hipLaunchKernelGGL(k_nchw_to_cl_split<PS * PS>, dim3((unsigned)(B * ((PS * PS + 31) / 32))), dim3(256), 0, st, x, ph, pl);
     } else if (x_px16) {                                                 // the learner's trunk ends in a PX16 image (S = 26 only)
-        hipLaunchKernelGGL(k_pool_split26_px, dim3((unsigned)((B * 169 * 8 + 255) / 256 < (1 << 20) ? (B * 169 * 8 + 255) / 256 : (1 << 20))), dim3(256), 0, st, x_px16, B, ph, pl);
+        hipLaunchKernelGGL(k_pool_split26_px, dim3((unsigned)((B * 169 + 63) / 64)), dim3(512), 0, st, x_px16, B, ph, pl);
     } else {
         hipLaunchKernelGGL(k_pool_split_cl<S>, dim3((unsigned)(B * PS)), dim3(256), 0, st, x, ph, pl);   // (a 16-channel-slab form that reads each plane once, contiguously, was 11 % slower: LDS-bound)
     }
