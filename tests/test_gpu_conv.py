@@ -562,11 +562,14 @@ def test_conv3x3_module_matches_float64_conv2d(fused, S, B, cin, cout, bias):
 
 @pytest.mark.parametrize("M,N,K,ta,tb", [(1, 64, 64, False, False), (300, 576, 2304, False, False), (4096, 2304, 576, False, True),
                                           (576, 2304, 4096, True, True), (576, 2304, 300, True, True), (129, 128, 1000, True, True),
-                                          (4099, 64, 128, False, False)])
+                                          (4099, 64, 128, False, False),
+                                          # k_gemm_wide (N % 192 == 0, K >= 1024, >= 32 tiles of 128 x 192) with ragged M: one, two and four K slices
+                                          (12345, 576, 2304, False, False), (5000, 576, 2304, False, False), (3000, 576, 2304, False, False)])
 @pytest.mark.parametrize("magnitude", [1.0, 1e-7])
 def test_gemm_f16x3_matches_float64(fused, M, N, K, ta, tb, magnitude):
     """tron_gemm_f16x3 (the training head's dense products, Net/activations.py::_PoolConv7): every operand layout, ragged M,
-    a reduction length that needs zero padding, a gradient-sized A operand with its device-side power-of-two scale."""
+    a reduction length that needs zero padding, a gradient-sized A operand with its device-side power-of-two scale; the 128 x 64 tile
+    and the 128 x 192 tile with its K slices (csrc/tron_head.hip: wide_splitk)."""
     from Net.kfac import _pow2_scale
     torch.manual_seed(M + N + K)
     a = torch.randn((K, M) if ta else (M, K), device="cuda") * magnitude
